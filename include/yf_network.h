@@ -1,0 +1,205 @@
+/* C-ABI of libyf_network.so -- the MI355X drop-in for the reference's X-CUBE-AI network boundary.
+ *
+ * Part 1 re-declares, ABI-identically, the types and the eight+two entry points the reference application binds
+ * (reference stm32/X-CUBE-AI/App/network.h:103-213, network_data.h:62-72, Middlewares/ST/AI/Inc/ai_platform.h).
+ * The declarations are authored here (ST's headers are SLA0044-licensed and are not copied); tests/test_abi.py
+ * compiles a probe against the reference's own headers and checks every sizeof/offsetof/enum value below.
+ * A maintainer keeps including the reference's network.h / network_data.h and links this library in place of
+ * network.c + network_data.c + NetworkRuntime700_CM7_Keil.lib.
+ *
+ * Part 2 declares the yf_* extension entry points (device-resident batches, detections, frame preparation, timing).
+ *
+ * Do not include this header together with the reference's ai_platform.h in one translation unit.
+ */
+#ifndef YF_NETWORK_H
+#define YF_NETWORK_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define YF_API __attribute__((visibility("default")))          /* == AI_API_ENTRY, ai_platform.h:109-111 */
+#else
+#define YF_API
+#endif
+
+/* ------------------------------------------------------------------ Part 1: reference boundary ---------- */
+typedef void*    ai_handle;                 /* ai_platform.h:431 */
+typedef bool     ai_bool;
+typedef int32_t  ai_i32;
+typedef uint32_t ai_u32;
+typedef uint16_t ai_u16;
+typedef uint8_t  ai_u8;
+typedef int8_t   ai_i8;
+typedef uint32_t ai_signature;
+typedef int32_t  ai_buffer_format;          /* ai_platform.h:211 */
+
+#define AI_HANDLE_PTR(ptr_)   ((ai_handle)(ptr_))
+#define AI_HANDLE_NULL        AI_HANDLE_PTR(NULL)
+#define AI_MAGIC_MARKER       (0xA1FACADE)  /* ai_platform.h:129 */
+#define AI_MAGIC_SIGNATURE    (0xa1facade)  /* ai_platform.h:85 */
+
+/* ai_platform.h:392-413: AI_BUFFER_FMT_SET(type, sign, float, bits, fbits) evaluated (checked by tests/test_abi.py) */
+#define AI_BUFFER_FORMAT_U8       ((ai_buffer_format)0x00040440)
+#define AI_BUFFER_FORMAT_S8       ((ai_buffer_format)0x00840440)
+#define AI_BUFFER_FMT_FLAG_CONST  (0x1U << 30)                   /* ai_platform.h:225 */
+
+typedef struct ai_error_ {                  /* ai_platform.h:467-470 */
+  ai_u32 type : 8;
+  ai_u32 code : 24;
+} ai_error;
+
+typedef struct ai_buffer_meta_info_ ai_buffer_meta_info;         /* opaque here; always NULL on this path */
+
+typedef struct ai_buffer_ {                 /* ai_platform.h:517-525; 32 bytes on LP64 */
+  ai_buffer_format      format;
+  ai_u16                n_batches;          /* u16: at most 65535 frames per ai_network_run call */
+  ai_u16                height;
+  ai_u16                width;
+  ai_u32                channels;
+  ai_handle             data;
+  ai_buffer_meta_info*  meta_info;
+} ai_buffer;
+
+typedef struct ai_buffer_array_ {           /* ai_platform.h:532-536 */
+  ai_u16      flags;
+  ai_u16      size;
+  ai_buffer*  buffer;
+} ai_buffer_array;
+
+typedef struct ai_platform_version_ { ai_u8 major, minor, micro, reserved; } ai_platform_version;   /* ai_platform.h:593-598 */
+
+typedef struct ai_network_params_ {         /* ai_platform.h:348-357,606-608 */
+  union {
+    struct { ai_buffer params; ai_buffer activations; };
+    struct { ai_signature map_signature; ai_buffer_array map_weights; ai_buffer_array map_activations; };
+  };
+} ai_network_params;
+
+typedef struct ai_network_report_ {         /* ai_platform.h:626-655 */
+  const char*          model_name;
+  const char*          model_signature;
+  const char*          model_datetime;
+  const char*          compile_datetime;
+  const char*          runtime_revision;
+  ai_platform_version  runtime_version;
+  const char*          tool_revision;
+  ai_platform_version  tool_version;
+  ai_platform_version  tool_api_version;
+  ai_platform_version  api_version;
+  ai_platform_version  interface_api_version;
+  ai_u32               n_macc;
+  ai_u16               n_inputs;
+  ai_u16               n_outputs;
+  ai_buffer*           inputs;
+  ai_buffer*           outputs;
+  union {
+    struct { ai_buffer params; ai_buffer activations; };
+    struct { ai_signature map_signature; ai_buffer_array map_weights; ai_buffer_array map_activations; };
+  };
+  ai_u32               n_nodes;
+  ai_signature         signature;
+} ai_network_report;
+
+/* ai_platform.h:546-586 (values used on this path) */
+enum {
+  AI_ERROR_NONE = 0x00, AI_ERROR_TOOL_PLATFORM_API_MISMATCH = 0x01, AI_ERROR_TYPES_MISMATCH = 0x02,
+  AI_ERROR_INVALID_HANDLE = 0x10, AI_ERROR_INVALID_STATE = 0x11, AI_ERROR_INVALID_INPUT = 0x12,
+  AI_ERROR_INVALID_OUTPUT = 0x13, AI_ERROR_INVALID_PARAM = 0x14, AI_ERROR_INVALID_SIGNATURE = 0x15,
+  AI_ERROR_INVALID_SIZE = 0x16, AI_ERROR_INVALID_VALUE = 0x17, AI_ERROR_INIT_FAILED = 0x30,
+  AI_ERROR_ALLOCATION_FAILED = 0x31, AI_ERROR_DEALLOCATION_FAILED = 0x32, AI_ERROR_CREATE_FAILED = 0x33
+};
+enum {
+  AI_ERROR_CODE_NONE = 0x0000, AI_ERROR_CODE_NETWORK = 0x0010, AI_ERROR_CODE_NETWORK_PARAMS = 0x0011,
+  AI_ERROR_CODE_NETWORK_WEIGHTS = 0x0012, AI_ERROR_CODE_NETWORK_ACTIVATIONS = 0x0013, AI_ERROR_CODE_LAYER = 0x0014,
+  AI_ERROR_CODE_TENSOR = 0x0015, AI_ERROR_CODE_ARRAY = 0x0016, AI_ERROR_CODE_INVALID_PTR = 0x0017,
+  AI_ERROR_CODE_INVALID_SIZE = 0x0018, AI_ERROR_CODE_INVALID_FORMAT = 0x0019, AI_ERROR_CODE_OUT_OF_RANGE = 0x0020,
+  AI_ERROR_CODE_INVALID_BATCH = 0x0021, AI_ERROR_CODE_MISSED_INIT = 0x0030, AI_ERROR_CODE_IN_USE = 0x0040
+};
+
+/* network.h:38-72, network_data.h:28-36 */
+#define AI_NETWORK_IN_1_HEIGHT   (56)
+#define AI_NETWORK_IN_1_WIDTH    (56)
+#define AI_NETWORK_IN_1_CHANNEL  (3)
+#define AI_NETWORK_IN_1_SIZE     (56 * 56 * 3)
+#define AI_NETWORK_OUT_1_HEIGHT  (7)
+#define AI_NETWORK_OUT_1_WIDTH   (7)
+#define AI_NETWORK_OUT_1_CHANNEL (18)
+#define AI_NETWORK_OUT_1_SIZE    (7 * 7 * 18)
+#define AI_NETWORK_N_NODES       (31)
+#define AI_NETWORK_DATA_ACTIVATIONS_SIZE (29784)
+#define AI_NETWORK_DATA_WEIGHTS_SIZE     (11304)
+
+/* replaces network.c:3369-3377 (ai_platform_network_create): binds *network to the static singleton context.
+ * network_config must be NULL (AI_NETWORK_DATA_CONFIG, network_data.h:26). */
+YF_API ai_error  ai_network_create(ai_handle* network, const ai_buffer* network_config);
+/* replaces network.c:3385-3399: reads the weight blob the caller hands over (MAGIC-framed pointer map of
+ * network_data.c:395-401, or the ai_buffer_array form of network_data.c:412-432), builds the device tables and
+ * uploads them to HBM.  The activations arena is accepted and ignored (activations live in LDS). */
+YF_API ai_bool   ai_network_init(ai_handle network, const ai_network_params* params);
+/* replaces network.c:3402-3407 (ai_platform_network_process): input S8 56x56x3 x n_batches NHWC host memory,
+ * output S8 7x7x18 x n_batches.  Returns the number of frames processed, <= 0 on failure. */
+YF_API ai_i32    ai_network_run(ai_handle network, const ai_buffer* input, ai_buffer* output);
+/* replaces network.c:3409-3413: run without returning an output */
+YF_API ai_i32    ai_network_forward(ai_handle network, const ai_buffer* input);
+/* replaces network.c:3363-3367: first error since the last call; reading resets it (network.h:120-132) */
+YF_API ai_error  ai_network_get_error(ai_handle network);
+/* replaces network.c:3379-3383 */
+YF_API ai_handle ai_network_destroy(ai_handle network);
+/* replace network.c:3271-3361 */
+YF_API ai_bool   ai_network_get_info(ai_handle network, ai_network_report* report);
+YF_API ai_bool   ai_network_get_report(ai_handle network, ai_network_report* report);
+/* replace network_data.c:393-403 and :412-432 (this library ships its own copy of the weight blob) */
+YF_API ai_handle ai_network_data_weights_get(void);
+YF_API ai_bool   ai_network_data_params_get(ai_handle network, ai_network_params* params);
+/* replaces the closed-library symbol the reference's own network_data.c:431 calls
+ * (ai_platform_interface.h:869-872), so that file can also be compiled unchanged beside this library */
+YF_API ai_bool   ai_platform_bind_network_params(ai_handle network, ai_network_params* params,
+                                                 const ai_buffer_array* map_weights,
+                                                 const ai_buffer_array* map_activations);
+
+/* ------------------------------------------------------------------ Part 2: extensions ------------------- */
+typedef struct yf_det_ {      /* one detection; mirrors the fields printed at yoloface.c:148 / drawn at tflite_prediction.py:63 */
+  int32_t frame;
+  uint8_t anchor, row, col;
+  int8_t  q_conf;             /* raw int8 confidence logit */
+  float   conf;               /* sigmoid of the dequantised logit */
+  int32_t x1, y1, x2, y2;
+} yf_det;
+
+enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anchor-major, conf > 0.7, xyxy * scale, int32 */
+       YF_DECODE_FW = 1 };    /* stm32/X-CUBE-AI/App/yoloface.c:98-152: cell-major, conf >= 0.7, axis swap, clamp, x2 */
+
+/* Select GPU (default 0 / $LOCAL_RANK is NOT read here; the caller decides).  Call before ai_network_init. */
+YF_API int  yf_network_set_device(ai_handle network, int device);
+/* Kernel variant: frames per workgroup (1,2,4) and waves per workgroup (4,8). 0 keeps the default. */
+YF_API int  yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg);
+/* Device-resident batch: d_in int8[n][56][56][3], d_out int8[n][7][7][18], both in HBM, d_in 4-byte aligned.
+ * stream is a hipStream_t (NULL = default stream); asynchronous.  Returns n or <= 0 (error latched). */
+YF_API long yf_network_run_device(ai_handle network, const void* d_in, void* d_out, long n, void* stream);
+/* Same, and additionally dumps every fused stage's tensor (per-layer parity debugging, the counterpart of the
+ * reference observer API, ai_platform_interface.h:684-731).  d_dump int8[n][yf_network_dump_bytes()]. */
+YF_API long yf_network_run_device_dump(ai_handle network, const void* d_in, void* d_out, void* d_dump, long n, void* stream);
+YF_API long yf_network_dump_bytes(void);
+/* Box decode on the GPU from device-resident heads: d_dets yf_det[n][cap], d_counts int32[n] (true count, may
+ * exceed cap).  mode = YF_DECODE_PY or YF_DECODE_FW. */
+YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                     void* d_dets, void* d_counts, int cap, void* stream);
+/* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
+YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
+/* `iters` back-to-back launches of the fused kernel on `stream`, bracketed by HIP events on that stream;
+ * *ms_per_launch receives the average.  Synchronises the stream. */
+YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_out, long n, int iters, void* stream,
+                                   float* ms_per_launch);
+/* Text of the last HIP/runtime failure (empty string if none). */
+YF_API const char* yf_network_last_error_text(ai_handle network);
+YF_API const char* yf_network_kernel_name(ai_handle network);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YF_NETWORK_H */

@@ -1,0 +1,7 @@
+"""MI355X-native int8 yoloface engine behind the reference's X-CUBE-AI `ai_network_*` C-ABI.
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so import it with
+    import importlib; yf = importlib.import_module("stm32h7-yolo_amd")
+"""
+from .binding import (Network, NetworkError, build, load, LIB_PATH, DET_DTYPE, YF_DECODE_PY, YF_DECODE_FW,  # noqa: F401
+                      IN_BYTES, OUT_BYTES)

@@ -1,0 +1,261 @@
+"""ctypes binding of libyf_network.so (the C-ABI declared in include/yf_network.h).
+
+Host-side mirror of the reference's call sequence (stm32/X-CUBE-AI/App/yoloface.c:188-240):
+    aiInit : ai_network_create -> ai_network_init(AI_NETWORK_PARAMS_INIT(weights, activations))
+    aiRun  : ai_network_run(network, &ai_input, &ai_output)
+The library has no CPU compute path: without a gfx950 GPU `init()` raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libyf_network.so")
+
+AI_BUFFER_FORMAT_U8 = 0x00040440
+AI_BUFFER_FORMAT_S8 = 0x00840440
+AI_BUFFER_FMT_FLAG_CONST = 1 << 30
+AI_MAGIC_MARKER = 0xA1FACADE
+IN_H, IN_W, IN_C = 56, 56, 3
+OUT_H, OUT_W, OUT_C = 7, 7, 18
+IN_BYTES, OUT_BYTES = IN_H * IN_W * IN_C, OUT_H * OUT_W * OUT_C
+WEIGHTS_BYTES, ACTIVATIONS_BYTES = 11304, 29784
+YF_DECODE_PY, YF_DECODE_FW = 0, 1
+
+
+class AiError(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint32, 8), ("code", ctypes.c_uint32, 24)]
+
+
+class AiBuffer(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int32), ("n_batches", ctypes.c_uint16), ("height", ctypes.c_uint16),
+                ("width", ctypes.c_uint16), ("channels", ctypes.c_uint32), ("data", ctypes.c_void_p),
+                ("meta_info", ctypes.c_void_p)]
+
+
+class AiBufferArray(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_uint16), ("size", ctypes.c_uint16), ("buffer", ctypes.POINTER(AiBuffer))]
+
+
+class _ParamsLegacy(ctypes.Structure):
+    _fields_ = [("params", AiBuffer), ("activations", AiBuffer)]
+
+
+class _ParamsMap(ctypes.Structure):
+    _fields_ = [("map_signature", ctypes.c_uint32), ("map_weights", AiBufferArray), ("map_activations", AiBufferArray)]
+
+
+class AiNetworkParams(ctypes.Union):
+    _anonymous_ = ("legacy", "map")
+    _fields_ = [("legacy", _ParamsLegacy), ("map", _ParamsMap)]
+
+
+class AiPlatformVersion(ctypes.Structure):
+    _fields_ = [("major", ctypes.c_uint8), ("minor", ctypes.c_uint8), ("micro", ctypes.c_uint8), ("reserved", ctypes.c_uint8)]
+
+
+class AiNetworkReport(ctypes.Structure):
+    _anonymous_ = ("p",)
+    _fields_ = [("model_name", ctypes.c_char_p), ("model_signature", ctypes.c_char_p), ("model_datetime", ctypes.c_char_p),
+                ("compile_datetime", ctypes.c_char_p), ("runtime_revision", ctypes.c_char_p),
+                ("runtime_version", AiPlatformVersion), ("tool_revision", ctypes.c_char_p),
+                ("tool_version", AiPlatformVersion), ("tool_api_version", AiPlatformVersion),
+                ("api_version", AiPlatformVersion), ("interface_api_version", AiPlatformVersion),
+                ("n_macc", ctypes.c_uint32), ("n_inputs", ctypes.c_uint16), ("n_outputs", ctypes.c_uint16),
+                ("inputs", ctypes.POINTER(AiBuffer)), ("outputs", ctypes.POINTER(AiBuffer)),
+                ("p", AiNetworkParams), ("n_nodes", ctypes.c_uint32), ("signature", ctypes.c_uint32)]
+
+
+class YfDet(ctypes.Structure):
+    _fields_ = [("frame", ctypes.c_int32), ("anchor", ctypes.c_uint8), ("row", ctypes.c_uint8), ("col", ctypes.c_uint8),
+                ("q_conf", ctypes.c_int8), ("conf", ctypes.c_float), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32),
+                ("x2", ctypes.c_int32), ("y2", ctypes.c_int32)]
+
+
+DET_DTYPE = np.dtype([("frame", "<i4"), ("anchor", "u1"), ("row", "u1"), ("col", "u1"), ("q_conf", "i1"),
+                      ("conf", "<f4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4")])
+assert DET_DTYPE.itemsize == ctypes.sizeof(YfDet) == 28
+
+EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network_forward", "ai_network_get_error",
+           "ai_network_destroy", "ai_network_get_info", "ai_network_get_report", "ai_network_data_weights_get",
+           "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
+           "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes",
+           "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
+           "yf_network_last_error_text", "yf_network_kernel_name"]
+
+
+def build(force=False):
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "-j4", "all", "../lib/libyf_hostprep.so"],
+                          stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library (building it first if the .so is missing) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, cl = ctypes.c_void_p, ctypes.c_long
+    lib.ai_network_create.restype = AiError
+    lib.ai_network_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(AiBuffer)]
+    lib.ai_network_init.restype = ctypes.c_bool
+    lib.ai_network_init.argtypes = [vp, ctypes.POINTER(AiNetworkParams)]
+    lib.ai_network_run.restype = ctypes.c_int32
+    lib.ai_network_run.argtypes = [vp, ctypes.POINTER(AiBuffer), ctypes.POINTER(AiBuffer)]
+    lib.ai_network_forward.restype = ctypes.c_int32
+    lib.ai_network_forward.argtypes = [vp, ctypes.POINTER(AiBuffer)]
+    lib.ai_network_get_error.restype = AiError
+    lib.ai_network_get_error.argtypes = [vp]
+    lib.ai_network_destroy.restype = vp
+    lib.ai_network_destroy.argtypes = [vp]
+    for f in (lib.ai_network_get_info, lib.ai_network_get_report):
+        f.restype = ctypes.c_bool
+        f.argtypes = [vp, ctypes.POINTER(AiNetworkReport)]
+    lib.ai_network_data_weights_get.restype = vp
+    lib.ai_network_data_weights_get.argtypes = []
+    lib.ai_network_data_params_get.restype = ctypes.c_bool
+    lib.ai_network_data_params_get.argtypes = [vp, ctypes.POINTER(AiNetworkParams)]
+    lib.ai_platform_bind_network_params.restype = ctypes.c_bool
+    lib.ai_platform_bind_network_params.argtypes = [vp, ctypes.POINTER(AiNetworkParams), ctypes.POINTER(AiBufferArray),
+                                                    ctypes.POINTER(AiBufferArray)]
+    lib.yf_network_set_device.argtypes = [vp, ctypes.c_int]
+    lib.yf_network_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.yf_network_run_device.restype = cl
+    lib.yf_network_run_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_run_device_dump.restype = cl
+    lib.yf_network_run_device_dump.argtypes = [vp, vp, vp, vp, cl, vp]
+    lib.yf_network_dump_bytes.restype = cl
+    lib.yf_network_decode_device.restype = cl
+    lib.yf_network_decode_device.argtypes = [vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
+    lib.yf_network_prepare_rgb565_device.restype = cl
+    lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_time_device.restype = cl
+    lib.yf_network_time_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.yf_network_last_error_text.restype = ctypes.c_char_p
+    lib.yf_network_last_error_text.argtypes = [vp]
+    lib.yf_network_kernel_name.restype = ctypes.c_char_p
+    lib.yf_network_kernel_name.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+class NetworkError(RuntimeError):
+    def __init__(self, what, etype, code, text=""):
+        super().__init__(f"{what}: ai_error type=0x{etype:02x} code=0x{code:04x} {text}".strip())
+        self.type, self.code, self.text = etype, code, text
+
+
+def make_buffer(fmt, h, w, ch, n_batches=1, data=None):
+    """AI_BUFFER_OBJ_INIT (reference ai_platform.h:322-330)."""
+    return AiBuffer(fmt, n_batches, h, w, ch, data, None)
+
+
+class Network:
+    """The one network instance of the library (the reference has a static singleton too, network.c:2929)."""
+
+    def __init__(self, device=0, frames_per_wg=0, waves_per_wg=0):
+        self.lib = load()
+        self.handle = ctypes.c_void_p()
+        err = self.lib.ai_network_create(ctypes.byref(self.handle), None)          # yoloface.c:192
+        if err.type != 0:
+            raise NetworkError("ai_network_create", err.type, err.code)
+        self.lib.yf_network_set_device(self.handle, device)
+        if frames_per_wg or waves_per_wg:
+            self.lib.yf_network_configure(self.handle, frames_per_wg, waves_per_wg)
+        self._activations = (ctypes.c_uint8 * ACTIVATIONS_BYTES)()                 # yoloface.c:180-181
+        self.ready = False
+
+    def _raise(self, what):
+        err = self.lib.ai_network_get_error(self.handle)
+        text = (self.lib.yf_network_last_error_text(self.handle) or b"").decode()
+        raise NetworkError(what, err.type, err.code, text)
+
+    def init(self, weights=None):
+        """ai_network_init with AI_NETWORK_PARAMS_INIT(AI_NETWORK_DATA_WEIGHTS(...), AI_NETWORK_DATA_ACTIVATIONS(...))
+        (yoloface.c:199-204).  weights: None = the library's blob via ai_network_data_weights_get()."""
+        p = AiNetworkParams()
+        if weights is None:
+            wptr = self.lib.ai_network_data_weights_get()
+        else:
+            self._w = np.ascontiguousarray(weights, dtype=np.uint8)
+            wptr = self._w.ctypes.data
+        p.params = make_buffer(AI_BUFFER_FORMAT_U8 | AI_BUFFER_FMT_FLAG_CONST, 1, 1, WEIGHTS_BYTES, 1, wptr)
+        p.activations = make_buffer(AI_BUFFER_FORMAT_U8, 1, 1, ACTIVATIONS_BYTES, 1, ctypes.addressof(self._activations))
+        if not self.lib.ai_network_init(self.handle, ctypes.byref(p)):
+            self._raise("ai_network_init")
+        self.ready = True
+        return self
+
+    def run(self, frames):
+        """ai_network_run on host memory: int8 [n,56,56,3] -> int8 [n,7,7,18] (yoloface.c:216-240, n_batches = n)."""
+        x = np.ascontiguousarray(frames, dtype=np.int8).reshape(-1, IN_H, IN_W, IN_C)
+        out = np.empty((x.shape[0], OUT_H, OUT_W, OUT_C), np.int8)
+        done = 0
+        while done < x.shape[0]:                     # n_batches is 16 bit (ai_platform.h:519)
+            n = min(65535, x.shape[0] - done)
+            bi = make_buffer(AI_BUFFER_FORMAT_S8, IN_H, IN_W, IN_C, n, x[done:].ctypes.data)
+            bo = make_buffer(AI_BUFFER_FORMAT_S8, OUT_H, OUT_W, OUT_C, n, out[done:].ctypes.data)
+            if self.lib.ai_network_run(self.handle, ctypes.byref(bi), ctypes.byref(bo)) != n:
+                self._raise("ai_network_run")
+            done += n
+        return out
+
+    def run_device(self, d_in, d_out, n, stream=None, d_dump=None):
+        if d_dump is None:
+            rc = self.lib.yf_network_run_device(self.handle, d_in, d_out, n, stream)
+        else:
+            rc = self.lib.yf_network_run_device_dump(self.handle, d_in, d_out, d_dump, n, stream)
+        if rc != n:
+            self._raise("yf_network_run_device")
+
+    def decode_device(self, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
+        if self.lib.yf_network_decode_device(self.handle, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
+            self._raise("yf_network_decode_device")
+
+    def prepare_rgb565_device(self, d_rgb, d_out, n, stream=None):
+        if self.lib.yf_network_prepare_rgb565_device(self.handle, d_rgb, d_out, n, stream) != n:
+            self._raise("yf_network_prepare_rgb565_device")
+
+    def time_device(self, d_in, d_out, n, iters, stream=None):
+        ms = ctypes.c_float()
+        if self.lib.yf_network_time_device(self.handle, d_in, d_out, n, iters, stream, ctypes.byref(ms)) != n:
+            self._raise("yf_network_time_device")
+        return ms.value
+
+    def configure(self, frames_per_wg, waves_per_wg):
+        if self.lib.yf_network_configure(self.handle, frames_per_wg, waves_per_wg) != 0:
+            self._raise("yf_network_configure")
+
+    @property
+    def kernel_name(self):
+        return (self.lib.yf_network_kernel_name(self.handle) or b"").decode()
+
+    def dump_bytes(self):
+        return self.lib.yf_network_dump_bytes()
+
+    def report(self):
+        r = AiNetworkReport()
+        if not self.lib.ai_network_get_report(self.handle, ctypes.byref(r)):
+            self._raise("ai_network_get_report")
+        return r
+
+    def get_error(self):
+        e = self.lib.ai_network_get_error(self.handle)
+        return e.type, e.code
+
+    def destroy(self):
+        if self.handle:
+            self.lib.ai_network_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+            self.ready = False

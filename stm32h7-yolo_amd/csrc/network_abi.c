@@ -1,0 +1,308 @@
+/* C host layer of libyf_network.so: the reference's ai_network_* boundary re-implemented over the HIP engine.
+ *
+ * Mirrors the generated reference file stm32/X-CUBE-AI/App/network.c:3270-3413 (public APIs) and
+ * network_data.c:393-432 (weights/params getters): same entry points, same argument meaning, same
+ * first-error-latch convention (network.h:120-132), one static context (network.c:2929-2939 `g_network`).
+ * What the reference does on the MCU with pointer binding (network_configure_weights/activations,
+ * network.c:2943-3267) becomes: read the caller's weight blob, build device tables, upload to HBM.
+ *
+ * There is NO CPU compute path in this file or behind it: without a gfx950 GPU ai_network_init fails with
+ * AI_ERROR_INIT_FAILED and ai_network_run returns 0.
+ */
+#include "../../include/yf_network.h"
+#include "yf_engine.h"
+#include "yf_host_prep.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+extern const uint8_t yf_weights_blob[AI_NETWORK_DATA_WEIGHTS_SIZE];   /* gen/yf_weights_blob_gen.c */
+
+enum { ST_NONE = 0, ST_CREATED = 1, ST_READY = 2 };
+
+typedef struct {
+  int state;
+  ai_error first_error;
+  yf_engine* engine;
+  int device;
+  int cfg_frames, cfg_waves;
+  char err_text[512];
+} yf_context;
+
+static yf_context g_network;             /* the reference has exactly one instance too (network.c:35-36) */
+
+static yf_context* acquire(ai_handle h) { return (h == (ai_handle)&g_network && g_network.state != ST_NONE) ? &g_network : NULL; }
+
+static void latch(yf_context* c, unsigned type, unsigned code, const char* text) {
+  if (c->first_error.type == AI_ERROR_NONE) { c->first_error.type = type; c->first_error.code = code; }
+  if (text) snprintf(c->err_text, sizeof c->err_text, "%s", text);
+}
+
+static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = type; e.code = code; return e; }
+
+/* ------------------------------------------------------------------------------------------------ create / destroy */
+YF_API ai_error ai_network_create(ai_handle* network, const ai_buffer* network_config) {
+  if (!network) return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_INVALID_PTR);
+  if (network_config != NULL) { *network = AI_HANDLE_NULL; return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_NETWORK); }
+  if (g_network.state == ST_READY && g_network.engine) { yf_engine_destroy(g_network.engine); }
+  const int dev = g_network.state != ST_NONE ? g_network.device : 0;
+  const int cf = g_network.cfg_frames, cw = g_network.cfg_waves;
+  memset(&g_network, 0, sizeof g_network);
+  g_network.state = ST_CREATED;
+  g_network.device = dev; g_network.cfg_frames = cf; g_network.cfg_waves = cw;
+  *network = (ai_handle)&g_network;
+  return mk_error(AI_ERROR_NONE, AI_ERROR_CODE_NONE);
+}
+
+YF_API ai_handle ai_network_destroy(ai_handle network) {
+  yf_context* c = acquire(network);
+  if (!c) return network;                       /* not destroyed: same handle comes back (network.h:155-157) */
+  if (c->engine) yf_engine_destroy(c->engine);
+  memset(c, 0, sizeof *c);
+  return AI_HANDLE_NULL;
+}
+
+YF_API ai_error ai_network_get_error(ai_handle network) {
+  yf_context* c = acquire(network);
+  if (!c) return mk_error(AI_ERROR_INVALID_HANDLE, AI_ERROR_CODE_NETWORK);
+  const ai_error e = c->first_error;
+  c->first_error = mk_error(AI_ERROR_NONE, AI_ERROR_CODE_NONE);
+  return e;
+}
+
+/* ------------------------------------------------------------------------------------------------ init */
+static size_t buffer_elems(const ai_buffer* b) { return (size_t)b->height * b->width * b->channels; }
+
+/* The weights arrive either as the legacy {params, activations} pair whose params.data points at the
+ * {AI_MAGIC_MARKER, blob, AI_MAGIC_MARKER} pointer map (network_data.c:395-401, used by yoloface.c:199-202), or as
+ * the signed ai_buffer_array map produced by ai_network_data_params_get (network_data.c:412-432). */
+static const uint8_t* resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act) {
+  if (p->map_signature == (ai_signature)AI_MAGIC_SIGNATURE) {
+    if (p->map_weights.size < 1 || !p->map_weights.buffer) return NULL;
+    const ai_buffer* wb = &p->map_weights.buffer[0];
+    *bytes = buffer_elems(wb);
+    *act = (p->map_activations.size >= 1) ? &p->map_activations.buffer[0] : NULL;
+    return (const uint8_t*)wb->data;
+  }
+  const ai_buffer* wb = &p->params;
+  *bytes = buffer_elems(wb);
+  *act = &p->activations;
+  if (!wb->data) return NULL;
+  const uintptr_t* map = (const uintptr_t*)wb->data;
+  if (map[0] == (uintptr_t)AI_MAGIC_MARKER) {
+    if (map[2] != (uintptr_t)AI_MAGIC_MARKER) return NULL;
+    return (const uint8_t*)map[1];
+  }
+  return (const uint8_t*)wb->data;                /* bare blob pointer */
+}
+
+YF_API ai_bool ai_network_init(ai_handle network, const ai_network_params* params) {
+  yf_context* c = acquire(network);
+  if (!c) return false;
+  if (!params) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, "params is NULL"); return false; }
+  size_t wbytes = 0;
+  const ai_buffer* act = NULL;
+  const uint8_t* blob = resolve_weights(params, &wbytes, &act);
+  if (!blob) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, "weights buffer/map is invalid"); return false; }
+  if (wbytes < AI_NETWORK_DATA_WEIGHTS_SIZE) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_INVALID_SIZE, "weights buffer smaller than 11304 bytes"); return false; }
+  /* the activations arena is caller-owned scratch on the MCU; here activations live in LDS.  It is accepted and
+   * left untouched, but a too-small arena is still reported the way the reference runtime would. */
+  if (act && act->data && buffer_elems(act) < AI_NETWORK_DATA_ACTIVATIONS_SIZE) {
+    latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_ACTIVATIONS, "activations buffer smaller than 29784 bytes"); return false;
+  }
+  if (c->engine) { yf_engine_destroy(c->engine); c->engine = NULL; c->state = ST_CREATED; }
+
+  uint8_t* tables = NULL;
+  yf_table_index ix;
+  const int prc = yf_prepare_tables(blob, wbytes, &tables, &ix);
+  if (prc != YF_PREP_OK) {
+    char t[96]; snprintf(t, sizeof t, "table preparation failed (code %d)", prc);
+    latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, t); return false;
+  }
+  char etext[400] = "";
+  const int erc = yf_engine_create(c->device, tables, &ix, &c->engine, etext, sizeof etext);
+  free(tables);
+  if (erc != YF_ENG_OK) { c->engine = NULL; latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK, etext); return false; }
+  if (c->cfg_frames || c->cfg_waves) {
+    if (yf_engine_configure(c->engine, c->cfg_frames, c->cfg_waves) != YF_ENG_OK) {
+      latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, yf_engine_error(c->engine));
+      yf_engine_destroy(c->engine); c->engine = NULL; return false;
+    }
+  }
+  c->state = ST_READY;
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------------ run */
+static int check_io(yf_context* c, const ai_buffer* b, int is_input) {
+  const unsigned etype = is_input ? AI_ERROR_INVALID_INPUT : AI_ERROR_INVALID_OUTPUT;
+  if (!b || !b->data) { latch(c, etype, AI_ERROR_CODE_INVALID_PTR, is_input ? "input buffer/data is NULL" : "output buffer/data is NULL"); return 0; }
+  /* compare type/sign/bits, ignore the flag bits 24..30 (CONST/STATIC/IS_IO) */
+  if ((b->format & 0x00FFFFFF) != (AI_BUFFER_FORMAT_S8 & 0x00FFFFFF)) { latch(c, etype, AI_ERROR_CODE_INVALID_FORMAT, "buffer format is not S8"); return 0; }
+  const int h = is_input ? AI_NETWORK_IN_1_HEIGHT : AI_NETWORK_OUT_1_HEIGHT, w = is_input ? AI_NETWORK_IN_1_WIDTH : AI_NETWORK_OUT_1_WIDTH;
+  const unsigned ch = is_input ? AI_NETWORK_IN_1_CHANNEL : AI_NETWORK_OUT_1_CHANNEL;
+  if (b->height != h || b->width != w || b->channels != ch) { latch(c, etype, AI_ERROR_CODE_INVALID_SIZE, "buffer shape mismatch"); return 0; }
+  if (b->n_batches < 1) { latch(c, etype, AI_ERROR_CODE_INVALID_BATCH, "n_batches < 1"); return 0; }
+  return 1;
+}
+
+static ai_i32 process(ai_handle network, const ai_buffer* input, ai_buffer* output) {
+  yf_context* c = acquire(network);
+  if (!c) return 0;
+  if (c->state != ST_READY || !c->engine) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_MISSED_INIT, "network not initialised"); return 0; }
+  if (!check_io(c, input, 1)) return 0;
+  if (output) {
+    if (!check_io(c, output, 0)) return 0;
+    if (output->n_batches < input->n_batches) { latch(c, AI_ERROR_INVALID_OUTPUT, AI_ERROR_CODE_INVALID_BATCH, "output holds fewer batches than input"); return 0; }
+  }
+  const long n = input->n_batches;
+  const int rc = yf_engine_run_host(c->engine, input->data, output ? output->data : NULL, n);
+  if (rc != YF_ENG_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_engine_error(c->engine)); return 0; }
+  return (ai_i32)n;
+}
+
+YF_API ai_i32 ai_network_run(ai_handle network, const ai_buffer* input, ai_buffer* output) {
+  yf_context* c = acquire(network);
+  if (c && !output) { latch(c, AI_ERROR_INVALID_OUTPUT, AI_ERROR_CODE_INVALID_PTR, "output is NULL"); return 0; }
+  return process(network, input, output);
+}
+
+YF_API ai_i32 ai_network_forward(ai_handle network, const ai_buffer* input) { return process(network, input, NULL); }
+
+/* ------------------------------------------------------------------------------------------------ report */
+static ai_buffer g_io_in = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_IN_1_HEIGHT, AI_NETWORK_IN_1_WIDTH, AI_NETWORK_IN_1_CHANNEL, NULL, NULL };
+static ai_buffer g_io_out = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_OUT_1_HEIGHT, AI_NETWORK_OUT_1_WIDTH, AI_NETWORK_OUT_1_CHANNEL, NULL, NULL };
+
+YF_API ai_bool ai_network_get_report(ai_handle network, ai_network_report* report) {
+  yf_context* c = acquire(network);
+  if (!c || !report) return false;
+  memset(report, 0, sizeof *report);
+  report->model_name = "network";                         /* AI_NETWORK_MODEL_NAME, network.h:29 */
+  report->model_signature = "yoloface_int8";              /* origin model, network.h:30 */
+  report->model_datetime = "";
+  report->compile_datetime = __DATE__ " " __TIME__;
+  report->runtime_revision = "yf-mi355x (gfx950 fused int8 engine)";
+  report->runtime_version.major = 0; report->runtime_version.minor = 1;
+  report->tool_revision = "tools/gen_model.py";
+  report->tool_version.major = 7;                         /* X-CUBE-AI 7.0.0 generated the reference tables */
+  report->tool_api_version.major = 1; report->tool_api_version.minor = 4;
+  report->api_version.major = 1; report->api_version.minor = 1;
+  report->interface_api_version.major = 1; report->interface_api_version.minor = 3;
+  report->n_macc = 1344320;                               /* network.c:3298, network_generate_report.txt:20 */
+  report->n_inputs = 1; report->n_outputs = 1;
+  report->inputs = &g_io_in; report->outputs = &g_io_out;
+  report->params.format = (ai_buffer_format)(AI_BUFFER_FORMAT_U8 | AI_BUFFER_FMT_FLAG_CONST);
+  report->params.n_batches = 1; report->params.height = 1; report->params.width = 1; report->params.channels = AI_NETWORK_DATA_WEIGHTS_SIZE;
+  report->activations.format = AI_BUFFER_FORMAT_U8;
+  report->activations.n_batches = 1; report->activations.height = 1; report->activations.width = 1; report->activations.channels = AI_NETWORK_DATA_ACTIVATIONS_SIZE;
+  report->n_nodes = AI_NETWORK_N_NODES;
+  report->signature = 0;
+  return true;
+}
+
+YF_API ai_bool ai_network_get_info(ai_handle network, ai_network_report* report) { return ai_network_get_report(network, report); }
+
+/* ------------------------------------------------------------------------------------------------ network_data */
+YF_API ai_handle ai_network_data_weights_get(void) {
+  static const uint8_t* map[3];
+  map[0] = (const uint8_t*)(uintptr_t)AI_MAGIC_MARKER;
+  map[1] = yf_weights_blob;
+  map[2] = (const uint8_t*)(uintptr_t)AI_MAGIC_MARKER;
+  return AI_HANDLE_PTR(map);
+}
+
+YF_API ai_bool ai_platform_bind_network_params(ai_handle network, ai_network_params* params,
+                                               const ai_buffer_array* map_weights, const ai_buffer_array* map_activations) {
+  if (!network || !params || !map_weights || !map_activations) return false;
+  memset(params, 0, sizeof *params);
+  params->map_signature = (ai_signature)AI_MAGIC_SIGNATURE;
+  params->map_weights = *map_weights;
+  params->map_activations = *map_activations;
+  return true;
+}
+
+YF_API ai_bool ai_network_data_params_get(ai_handle network, ai_network_params* params) {
+  if (!(network && params)) return false;
+  static ai_buffer act[1] = {{ AI_BUFFER_FORMAT_U8, 1, 1, 1, AI_NETWORK_DATA_ACTIVATIONS_SIZE, NULL, NULL }};
+  static ai_buffer wts[1] = {{ AI_BUFFER_FORMAT_U8, 1, 1, 1, AI_NETWORK_DATA_WEIGHTS_SIZE, NULL, NULL }};
+  wts[0].data = (ai_handle)yf_weights_blob;
+  const ai_buffer_array ma = { 0, 1, act };
+  const ai_buffer_array mw = { 0, 1, wts };
+  return ai_platform_bind_network_params(network, params, &mw, &ma);
+}
+
+/* ------------------------------------------------------------------------------------------------ extensions */
+YF_API int yf_network_set_device(ai_handle network, int device) {
+  yf_context* c = acquire(network);
+  if (!c || device < 0) return -1;
+  if (c->state == ST_READY) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_IN_USE, "set the device before ai_network_init"); return -1; }
+  c->device = device;
+  return 0;
+}
+
+YF_API int yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg) {
+  yf_context* c = acquire(network);
+  if (!c) return -1;
+  c->cfg_frames = frames_per_wg; c->cfg_waves = waves_per_wg;
+  if (c->state == ST_READY && yf_engine_configure(c->engine, frames_per_wg, waves_per_wg) != YF_ENG_OK) {
+    latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_NETWORK_PARAMS, yf_engine_error(c->engine)); return -1;
+  }
+  return 0;
+}
+
+static yf_context* ready(ai_handle network) {
+  yf_context* c = acquire(network);
+  if (!c) return NULL;
+  if (c->state != ST_READY || !c->engine) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_MISSED_INIT, "network not initialised"); return NULL; }
+  return c;
+}
+
+static long finish(yf_context* c, int rc, long n) {
+  if (rc == YF_ENG_OK) return n;
+  latch(c, rc == YF_ENG_ERR_ARG ? AI_ERROR_INVALID_PARAM : AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_engine_error(c->engine));
+  return 0;
+}
+
+YF_API long yf_network_run_device(ai_handle network, const void* d_in, void* d_out, long n, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_run_device(c->engine, d_in, d_out, NULL, n, stream), n);
+}
+
+YF_API long yf_network_run_device_dump(ai_handle network, const void* d_in, void* d_out, void* d_dump, long n, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  if (!d_dump) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_INVALID_PTR, "dump buffer is NULL"); return 0; }
+  return finish(c, yf_engine_run_device(c->engine, d_in, d_out, d_dump, n, stream), n);
+}
+
+YF_API long yf_network_dump_bytes(void) { return yf_engine_dump_bytes(); }
+
+YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                     void* d_dets, void* d_counts, int cap, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_decode_device(c->engine, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream), n);
+}
+
+YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_prepare_rgb565_device(c->engine, d_rgb565, d_out, n, stream), n);
+}
+
+YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_time_device(c->engine, d_in, d_out, n, iters, stream, ms_per_launch), n);
+}
+
+YF_API const char* yf_network_last_error_text(ai_handle network) {
+  yf_context* c = acquire(network);
+  return c ? c->err_text : "invalid handle";
+}
+
+YF_API const char* yf_network_kernel_name(ai_handle network) {
+  yf_context* c = acquire(network);
+  return (c && c->engine) ? yf_engine_kernel_name(c->engine) : "";
+}

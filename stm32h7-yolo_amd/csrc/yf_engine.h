@@ -1,0 +1,35 @@
+/* Thin FFI between the C host layer (network_abi.c) and the HIP engine (yf_engine.hip).
+ * Plain C types only; every function returns 0 on success or a negative code, with text in yf_engine_error(). */
+#ifndef YF_ENGINE_H
+#define YF_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+#include "yf_tables.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yf_engine yf_engine;
+
+enum { YF_ENG_OK = 0, YF_ENG_ERR_HIP = -1, YF_ENG_ERR_ARG = -2, YF_ENG_ERR_NO_DEVICE = -3, YF_ENG_ERR_VARIANT = -4 };
+
+int  yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen);
+void yf_engine_destroy(yf_engine* e);
+int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);
+const char* yf_engine_error(const yf_engine* e);
+const char* yf_engine_kernel_name(const yf_engine* e);
+
+/* device-resident batch; d_dump may be NULL */
+int  yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_dump, long n, void* stream);
+/* host batch: H2D, run, D2H through engine-owned staging buffers; synchronous */
+int  yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n);
+int  yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch);
+int  yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode, float w_scale, float h_scale,
+                             void* d_dets, void* d_counts, int cap, void* stream);
+int  yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream);
+long yf_engine_dump_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,268 @@
+// HIP engine behind the C-ABI: device context, table upload, launches of the fused kernel, box decode and
+// frame-preparation kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include "yf_engine.h"
+#include "yf_kernels.hip.h"
+#include "gen/yf_decode_tables_gen.h"
+#include "../../include/yf_network.h"   // yf_det, YF_DECODE_*
+
+namespace {
+
+__device__ __constant__ uint32_t d_sig_bits[256];
+__device__ __constant__ uint32_t d_exp_bits[256];
+
+// ---------------------------------------------------------------------------------------------- box decode
+// One wave per frame; candidates are visited in the reference order and compacted with ballots so that the
+// record order equals the order the reference loops produce.
+//   YF_DECODE_PY: yoloface/tflite/tflite_prediction.py:42-63  (a, row, col), conf > 0.7
+//   YF_DECODE_FW: stm32/X-CUBE-AI/App/yoloface.c:98-152       (cell, a), conf >= 0.7, LCD axis swap, clamp, x2
+// All transcendental values come from the committed float32 tables; the remaining float32 operations are single
+// IEEE operations (this file is compiled with -ffp-contract=off).
+__global__ void __launch_bounds__(256) decode_kernel(const int8_t* __restrict__ heads, long n, int mode, float w_scale,
+                                                     float h_scale, yf_det* __restrict__ dets, int* __restrict__ counts, int cap) {
+  const int lane = threadIdx.x & 63;
+  const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (frame >= n) return;
+  const int8_t* head = heads + frame * 882;
+  yf_det* out = dets + frame * cap;
+  const float anc_w[3] = {9.f, 12.f, 22.f}, anc_h[3] = {14.f, 17.f, 21.f};
+  int total = 0;
+  for (int base = 0; base < 147; base += 64) {
+    const int i = base + lane;
+    bool keep = false;
+    int a = 0, row = 0, col = 0;
+    const int8_t* p = head;
+    float conf = 0.f;
+    if (i < 147) {
+      if (mode == YF_DECODE_PY) { a = i / 49; const int cell = i - a * 49; row = cell / 7; col = cell - row * 7; }
+      else { const int cell = i / 3; a = i - cell * 3; row = cell / 7; col = cell - row * 7; }
+      p = head + (row * 7 + col) * 18 + a * 6;
+      conf = __uint_as_float(d_sig_bits[p[4] + 128]);
+      keep = (mode == YF_DECODE_PY) ? (conf > 0.7f) : ((double)conf >= 0.7);
+    }
+    const unsigned long long mask = __ballot(keep);
+    const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep && pos < cap) {
+      const float sx = __uint_as_float(d_sig_bits[p[0] + 128]), sy = __uint_as_float(d_sig_bits[p[1] + 128]);
+      const float ew = __uint_as_float(d_exp_bits[p[2] + 128]), eh = __uint_as_float(d_exp_bits[p[3] + 128]);
+      yf_det d;
+      d.frame = (int32_t)frame; d.anchor = (uint8_t)a; d.row = (uint8_t)row; d.col = (uint8_t)col;
+      d.q_conf = p[4]; d.conf = conf;
+      const float cx = (sx + (float)col) * 8.f, cy = (sy + (float)row) * 8.f;
+      const float bw = ew * anc_w[a], bh = eh * anc_h[a];
+      if (mode == YF_DECODE_PY) {
+        float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
+        x1 *= w_scale; x2 *= w_scale; y1 *= h_scale; y2 *= h_scale;
+        d.x1 = (int32_t)x1; d.y1 = (int32_t)y1; d.x2 = (int32_t)x2; d.y2 = (int32_t)y2;
+      } else {
+        int y2 = (int)(cx - bw / 2), y1 = (int)(cx + bw / 2), x1 = (int)(cy - bh / 2), x2 = (int)(cy + bh / 2);
+        if (x1 < 0) x1 = 0;
+        if (y1 < 0) y1 = 0;
+        if (x2 > 55) x2 = 55;
+        if (y2 > 55) y2 = 55;
+        d.x1 = x1 * 2; d.y1 = y1 * 2; d.x2 = x2 * 2; d.y2 = y2 * 2;
+      }
+      out[pos] = d;
+    }
+    total += __popcll(mask);
+  }
+  if (lane == 0) counts[frame] = total;
+}
+
+// ---------------------------------------------------------------------------------------------- frame preparation
+// stm32/X-CUBE-AI/App/yoloface.c:26-93: 112x112 big-endian RGB565 -> 2x2 box average per 5/6/5 field -> re-pack ->
+// shift-expand -> value-128.  One thread per output pixel; 4 x 2-byte loads, 3 byte stores.
+__global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __restrict__ src, int8_t* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 3136) return;
+  const long f = i / 3136; const int r = (int)(i - f * 3136);
+  const int y = r / 56, x = r - y * 56;
+  const uint8_t* s = src + f * (112 * 112 * 2);
+  unsigned sr = 0, sg = 0, sb = 0;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int o = ((2 * y + dy) * 112 + (2 * x + dx)) * 2;
+      const unsigned px = ((unsigned)s[o] << 8) | s[o + 1];
+      sr += (px >> 11) & 0x1F; sg += (px >> 5) & 0x3F; sb += px & 0x1F;
+    }
+  const unsigned color = (((sr >> 2) & 0x1F) << 11) | (((sg >> 2) & 0x3F) << 5) | ((sb >> 2) & 0x1F);
+  int8_t* o8 = dst + f * 9408 + r * 3;
+  o8[0] = (int8_t)(((color & 0xF800) >> 8) - 128);
+  o8[1] = (int8_t)(((color & 0x07E0) >> 3) - 128);
+  o8[2] = (int8_t)(((color & 0x001F) << 3) - 128);
+}
+
+typedef void (*fused_fn)(const yf::NetParams);
+struct Variant { int f, nw; bool dump; fused_fn fn; size_t lds; const char* name; };
+
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW>(), \
+                                  "yoloface56_fused<F=" #F ",NW=" #NW ">" }
+const Variant k_variants[] = {
+  YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
+  YF_VARIANT(2, 4, true),
+};
+
+}  // namespace
+
+struct yf_engine {
+  int device = 0;
+  int cus = 0;
+  uint8_t* d_tab = nullptr;
+  yf_table_index ix;
+  const Variant* var = nullptr;
+  const Variant* var_dump = nullptr;
+  void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
+  hipStream_t own_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+#define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
+    (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
+
+static const Variant* find_variant(int f, int nw, bool dump) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump) return &v;
+  return nullptr;
+}
+
+extern "C" {
+
+int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen) {
+  auto fail = [&](const std::string& m, int code) { if (err && errlen) snprintf(err, errlen, "%s", m.c_str()); return code; };
+  if (!table_blob || !ix || !out) return fail("bad arguments", YF_ENG_ERR_ARG);
+  int ndev = 0;
+  hipError_t rc = hipGetDeviceCount(&ndev);
+  if (rc != hipSuccess || ndev <= 0)
+    return fail(std::string("no HIP device: ") + (rc != hipSuccess ? hipGetErrorString(rc) : "device count is 0"), YF_ENG_ERR_NO_DEVICE);
+  if (device < 0 || device >= ndev) return fail("device index out of range", YF_ENG_ERR_ARG);
+  yf_engine* e = new yf_engine();
+  e->device = device; e->ix = *ix;
+  auto bail = [&](hipError_t r, const char* what) { std::string m = std::string(what) + ": " + hipGetErrorString(r); delete e; return fail(m, YF_ENG_ERR_HIP); };
+  if ((rc = hipSetDevice(device)) != hipSuccess) return bail(rc, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((rc = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(rc, "hipGetDeviceProperties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return fail(std::string("unsupported GPU ") + prop.gcnArchName + " (this library is gfx950 only)", YF_ENG_ERR_NO_DEVICE); }
+  e->cus = prop.multiProcessorCount;
+  if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
+  if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
+  if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_sig_bits), yf_sigmoid_bits, sizeof yf_sigmoid_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(sigmoid)");
+  if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_exp_bits), yf_exp_bits, sizeof yf_exp_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(exp)");
+  for (const Variant& v : k_variants)
+    if ((rc = hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds)) != hipSuccess)
+      return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
+  if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
+  if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
+  e->var = find_variant(2, 4, false);
+  e->var_dump = find_variant(2, 4, true);
+  *out = e;
+  return YF_ENG_OK;
+}
+
+void yf_engine_destroy(yf_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->d_tab) (void)hipFree(e->d_tab);
+  if (e->d_in) (void)hipFree(e->d_in);
+  if (e->d_out) (void)hipFree(e->d_out);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
+  if (!e) return YF_ENG_ERR_ARG;
+  const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
+  const Variant* v = find_variant(f, nw, false);
+  if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
+  e->var = v;
+  return YF_ENG_OK;
+}
+
+const char* yf_engine_error(const yf_engine* e) { return e ? e->err.c_str() : "null engine"; }
+const char* yf_engine_kernel_name(const yf_engine* e) { return e && e->var ? e->var->name : ""; }
+long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
+
+static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s) {
+  if (n <= 0) return YF_ENG_OK;
+  if (((uintptr_t)d_in & 3) != 0) { e->err = "input must be 4-byte aligned"; return YF_ENG_ERR_ARG; }
+  if (((uintptr_t)d_out & 1) != 0) { e->err = "output must be 2-byte aligned"; return YF_ENG_ERR_ARG; }
+  yf::NetParams prm;
+  prm.in = (const int8_t*)d_in; prm.out = (int8_t*)d_out; prm.n = n; prm.tab = e->d_tab; prm.dump = (int8_t*)d_dump;
+  const long groups = (n + v->f - 1) / v->f;
+  const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
+  long grid = (long)e->cus * per_cu;
+  if (grid > groups) grid = groups;
+  hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->nw * 64), v->lds, s, prm);
+  HIPCHK(e, hipGetLastError());
+  return YF_ENG_OK;
+}
+
+int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_dump, long n, void* stream) {
+  if (!e || !d_in || !d_out || n < 0) return YF_ENG_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  return launch(e, d_dump ? e->var_dump : e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);
+}
+
+int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {
+  if (!e || !h_in || n < 0) return YF_ENG_ERR_ARG;        /* h_out may be NULL (ai_network_forward) */
+  if (n == 0) return YF_ENG_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n > e->stage_cap) {
+    if (e->d_in) (void)hipFree(e->d_in);
+    if (e->d_out) (void)hipFree(e->d_out);
+    e->d_in = e->d_out = nullptr; e->stage_cap = 0;
+    HIPCHK(e, hipMalloc(&e->d_in, (size_t)n * 9408));
+    HIPCHK(e, hipMalloc(&e->d_out, (size_t)n * 882));
+    e->stage_cap = n;
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_in, h_in, (size_t)n * 9408, hipMemcpyHostToDevice, e->own_stream));
+  const int rc = launch(e, e->var, e->d_in, e->d_out, nullptr, n, e->own_stream);
+  if (rc) return rc;
+  if (h_out) HIPCHK(e, hipMemcpyAsync(h_out, e->d_out, (size_t)n * 882, hipMemcpyDeviceToHost, e->own_stream));
+  HIPCHK(e, hipStreamSynchronize(e->own_stream));
+  return YF_ENG_OK;
+}
+
+int yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch) {
+  if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(e, hipEventRecord(e->ev0, s));
+  for (int i = 0; i < iters; ++i) { const int rc = launch(e, e->var, d_in, d_out, nullptr, n, s); if (rc) return rc; }
+  HIPCHK(e, hipEventRecord(e->ev1, s));
+  HIPCHK(e, hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *ms_per_launch = ms / iters;
+  return YF_ENG_OK;
+}
+
+int yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode, float w_scale, float h_scale,
+                            void* d_dets, void* d_counts, int cap, void* stream) {
+  if (!e || !d_heads || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW)) return YF_ENG_ERR_ARG;
+  if (n == 0) return YF_ENG_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const int8_t*)d_heads, n, mode, w_scale, h_scale, (yf_det*)d_dets, (int*)d_counts, cap);
+  HIPCHK(e, hipGetLastError());
+  return YF_ENG_OK;
+}
+
+int yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream) {
+  if (!e || !d_rgb565 || !d_out || n < 0) return YF_ENG_ERR_ARG;
+  if (n == 0) return YF_ENG_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(prepare_rgb565_kernel, dim3((unsigned)((n * 3136 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)d_rgb565, (int8_t*)d_out, n);
+  HIPCHK(e, hipGetLastError());
+  return YF_ENG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+/* Host-side preparation of the device tables (plain C, no GPU needed).
+ *
+ * Runs once inside ai_network_init (reference stm32/X-CUBE-AI/App/network.c:3385-3399): the reference binds 48
+ * weight/bias arrays at fixed offsets of the blob it is handed (network_configure_weights, network.c:3108-3267);
+ * this build reads the same blob at the same offsets (gen/yf_model_gen.h) and turns it, together with the baked
+ * quantisation tables (reference network.c:663-1341), into the packed constants the HIP kernels consume.
+ *
+ * Fixed-point preparation follows TFLite 2.10 (the arithmetic the metric names):
+ *   conv / depthwise : QuantizeMultiplier((double)s_in * (double)s_w[c] / (double)s_out)
+ *   LEAKY_RELU       : QuantizeMultiplier((double)(float)(s_in*alpha/s_out)), ...(s_in/s_out)
+ *   ADD              : left_shift 20, QuantizeMultiplierSmallerThanOneExp x3
+ *   QUANTIZE         : QuantizeMultiplier((double)s_in / (double)s_out)
+ */
+#include "yf_host_prep.h"
+#include "gen/yf_model_gen.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static float f32_from_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static float t_scale(int t) { return f32_from_bits(yf_tensor_scale_bits[t]); }
+static int32_t t_zp(int t) { return yf_tensor_zero_point[t]; }
+
+/* ---- TFLite fixed-point helpers (own statement; the oracle has an independent one) ---------------------- */
+void yf_quantize_multiplier(double real, int32_t* mult, int* shift) {
+  if (real == 0.0) { *mult = 0; *shift = 0; return; }
+  int e;
+  const double frac = frexp(real, &e);                  /* real = frac * 2^e, frac in [0.5, 1) */
+  long long fixed = llround(frac * 2147483648.0);       /* half away from zero, like TfLiteRound */
+  if (fixed == (1LL << 31)) { fixed >>= 1; ++e; }
+  if (e < -31) { e = 0; fixed = 0; }
+  *mult = (int32_t)fixed; *shift = e;
+}
+
+static int32_t sat_rounding_doubling_high_mul(int32_t a, int32_t b) {
+  if (a == INT32_MIN && b == INT32_MIN) return INT32_MAX;
+  const long long p = (long long)a * b;
+  /* floor((p + 2^30) / 2^31): identical to gemmlowp's signed nudge + truncating division */
+  return (int32_t)((p + (1LL << 30)) >> 31);
+}
+
+static int32_t rounding_div_pot(int32_t x, int e) {
+  if (e == 0) return x;
+  const int32_t half = (int32_t)1 << (e - 1);
+  /* round half away from zero */
+  return x >= 0 ? (int32_t)(((long long)x + half) >> e) : -(int32_t)((-(long long)x + half) >> e);
+}
+
+int32_t yf_mbqm(int32_t x, int32_t mult, int shift) {
+  const int ls = shift > 0 ? shift : 0, rs = shift > 0 ? 0 : -shift;
+  return rounding_div_pot(sat_rounding_doubling_high_mul(x * (1 << ls), mult), rs);
+}
+
+static int8_t sat8(int32_t v) { return (int8_t)(v < -128 ? -128 : v > 127 ? 127 : v); }
+
+/* ---- LUT builders ------------------------------------------------------------------------------------------ */
+/* TFLite int8 LEAKY_RELU as a table over q in [-128,127] (index q+128). */
+static void build_leaky_lut(int t_in, int t_out, uint8_t* lut) {
+  const float s_in = t_scale(t_in), s_out = t_scale(t_out);
+  const float alpha = 0.1f;                              /* LeakyReluOptions.alpha of all 17 ops (0x3dcccccd) */
+  int32_t m_a, m_i; int sh_a, sh_i;
+  yf_quantize_multiplier((double)(float)(s_in * alpha / s_out), &m_a, &sh_a);
+  yf_quantize_multiplier((double)(float)(s_in / s_out), &m_i, &sh_i);
+  for (int q = -128; q < 128; ++q) {
+    const int32_t v = q - t_zp(t_in);
+    const int32_t u = v >= 0 ? yf_mbqm(v, m_i, sh_i) : yf_mbqm(v, m_a, sh_a);
+    lut[q + 128] = (uint8_t)sat8(t_zp(t_out) + u);
+  }
+}
+
+/* TFLite int8->int8 QUANTIZE (requantize) as a table. */
+static void build_requant_lut(int t_in, int t_out, uint8_t* lut) {
+  int32_t m; int sh;
+  yf_quantize_multiplier((double)t_scale(t_in) / (double)t_scale(t_out), &m, &sh);
+  for (int q = -128; q < 128; ++q)
+    lut[q + 128] = (uint8_t)sat8(yf_mbqm(q - t_zp(t_in), m, sh) + t_zp(t_out));
+}
+
+/* ---- per-channel requantisation constants ----------------------------------------------------------------- */
+/* z_extra = 128 when the result indexes a LUT, 0 when it is the final int8 value. Returns 0 or an error code. */
+static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int z_extra, yf_chan* out) {
+  const float s_in = t_scale(d->t_in), s_out = t_scale(d->t_out);
+  const float s_w = f32_from_bits(d->wscale_bits[ch]);
+  int32_t m; int sh;
+  yf_quantize_multiplier((double)s_in * (double)s_w / (double)s_out, &m, &sh);
+  if (sh > -1 || sh < -30) return YF_PREP_ERR_SHIFT_RANGE;      /* fused epilogue needs 1 <= rshift <= 30 */
+  if (m <= (1 << 30)) return YF_PREP_ERR_SHIFT_RANGE;           /* normalised multiplier (frexp) is > 2^30 unless exact pow2 */
+  int32_t bias;
+  memcpy(&bias, blob + d->b_off + 4 * (size_t)ch, 4);
+  const int rs = -sh;
+  out->bias2 = bias - t_zp(d->t_in) * sum_w;
+  out->mult = m;
+  out->rshift = rs;
+  out->kc = ((int32_t)1 << (rs - 1)) + ((t_zp(d->t_out) + z_extra) << rs);
+  return 0;
+}
+
+static const yf_conv_desc* find_conv(int tfl_op) {
+  for (int i = 0; i < YF_N_CONVS; ++i) if (yf_convs[i].tfl_op == tfl_op) return &yf_convs[i];
+  return NULL;
+}
+
+typedef struct { uint8_t* p; size_t size, cap; } blob_t;
+static size_t blob_alloc(blob_t* b, size_t n) {
+  size_t off = (b->size + 15) & ~(size_t)15;
+  if (off + n > b->cap) {
+    size_t nc = b->cap ? b->cap * 2 : 65536;
+    while (nc < off + n) nc *= 2;
+    b->p = (uint8_t*)realloc(b->p, nc);
+    memset(b->p + b->cap, 0, nc - b->cap);
+    b->cap = nc;
+  }
+  b->size = off + n;
+  return off;
+}
+
+/* stage descriptors: tflite conv op, whether its output indexes a LUT (z_extra) ------------------------------ */
+typedef struct { int id; int tfl_op; int lut; } dense_plan;
+static const dense_plan k_dense[YF_N_DENSE] = {
+  {YF_D_CONV1, 1, 1}, {YF_D_C5, 5, 0}, {YF_D_C6, 6, 1}, {YF_D_C12, 12, 0}, {YF_D_C13, 13, 1}, {YF_D_C17, 17, 0},
+  {YF_D_C19, 19, 1}, {YF_D_C23, 23, 1}, {YF_D_C29, 29, 0}, {YF_D_C30, 30, 1}, {YF_D_C34, 34, 0}, {YF_D_C36, 36, 1},
+  {YF_D_C40, 40, 0}, {YF_D_C42, 42, 1}, {YF_D_C47, 47, 1}, {YF_D_C51, 51, 1}, {YF_D_C53, 53, 0},
+};
+static const int k_dw_ops[YF_N_DW] = {3, 10, 15, 27, 32, 38, 49};
+
+/* conv2d_1 tap -> (k-step, byte slot) map: RGBX pixels, see yf_tables.h */
+static void conv1_slot(int ky, int kx, int c, int* step, int* slot) {
+  const int pix = ky * 3 + kx;              /* 0..8 */
+  if (pix < 8) { *step = 0; *slot = pix * 4 + c; } else { *step = 1; *slot = c; }
+}
+
+int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** out_blob, yf_table_index* ix) {
+  if (!weights_blob || blob_bytes < YF_WEIGHTS_BLOB_BYTES || !out_blob || !ix) return YF_PREP_ERR_ARGS;
+  memset(ix, 0, sizeof *ix);
+  blob_t b = {0, 0, 0};
+  int rc = 0;
+  blob_alloc(&b, YF_INDEX_RESERVED);          /* the index itself is stored at offset 0 (filled in at the end) */
+
+  /* ---------------- dense stages ---------------- */
+  for (int s = 0; s < YF_N_DENSE && !rc; ++s) {
+    const yf_conv_desc* d = find_conv(k_dense[s].tfl_op);
+    if (!d || d->depthwise) { rc = YF_PREP_ERR_MODEL; break; }
+    yf_dense* o = &ix->dense[s];
+    const int kk = d->kh * d->kw * d->cin;
+    o->cout = d->cout; o->cout_pad4 = (uint16_t)((d->cout + 3) & ~3); o->k = (uint16_t)kk;
+    const int8_t* w = (const int8_t*)weights_blob + d->w_off;                      /* OHWI */
+    if (s == YF_D_CONV1) {
+      o->krow = YF_CONV1_KROW;
+    } else if (s == YF_D_C23) {
+      o->krow = 48;                                 /* k order = T14 channel order (38 slots) */
+    } else {
+      o->krow = (uint16_t)((kk + 15) & ~15);
+    }
+    o->w_off = (uint32_t)blob_alloc(&b, (size_t)o->cout_pad4 * o->krow);
+    o->c_off = (uint32_t)blob_alloc(&b, (size_t)o->cout_pad4 * sizeof(yf_chan));
+    for (int ch = 0; ch < d->cout; ++ch) {
+      int8_t* row = (int8_t*)b.p + o->w_off + (size_t)ch * o->krow;
+      int32_t sum_w = 0;
+      for (int k = 0; k < kk; ++k) sum_w += w[(size_t)ch * kk + k];
+      if (s == YF_D_CONV1) {
+        for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) for (int c = 0; c < 3; ++c) {
+          int step, slot; conv1_slot(ky, kx, c, &step, &slot);
+          row[step * 32 + slot] = w[(size_t)ch * 27 + (ky * 3 + kx) * 3 + c];
+        }
+      } else if (s == YF_D_C23) {
+        for (int k = 0; k < 18; ++k) row[k] = w[(size_t)ch * 36 + k];                       /* pool branch */
+        for (int k = 18; k < 36; ++k) row[YF_T14_CONV_BASE + (k - 18)] = w[(size_t)ch * 36 + k];  /* conv branch */
+      } else {
+        memcpy(row, w + (size_t)ch * kk, (size_t)kk);
+      }
+      yf_chan* c = (yf_chan*)(b.p + o->c_off) + ch;
+      rc = build_chan(d, weights_blob, ch, sum_w, k_dense[s].lut ? 128 : 0, c);
+      if (rc) break;
+    }
+  }
+
+  /* ---------------- depthwise stages ---------------- */
+  for (int s = 0; s < YF_N_DW && !rc; ++s) {
+    const yf_conv_desc* d = find_conv(k_dw_ops[s]);
+    if (!d || !d->depthwise) { rc = YF_PREP_ERR_MODEL; break; }
+    yf_dw* o = &ix->dw[s];
+    o->c = d->cout; o->ngroups = (uint16_t)((d->cout + 3) / 4);
+    o->g_off = (uint32_t)blob_alloc(&b, (size_t)o->ngroups * YF_DW_GROUP_BYTES);
+    ix->halo_zp[s] = t_zp(d->t_in);
+    const int8_t* w = (const int8_t*)weights_blob + d->w_off;                      /* 1HWC */
+    for (int g = 0; g < o->ngroups; ++g) {
+      uint32_t* wd = (uint32_t*)(b.p + o->g_off + (size_t)g * YF_DW_GROUP_BYTES);  /* [9 taps][4 lanes] */
+      yf_chan* cc = (yf_chan*)(wd + 36);
+      for (int j = 0; j < 4; ++j) {
+        const int ch = g * 4 + j;
+        if (ch >= d->cout) {                 /* padding channel: harmless constants */
+          for (int t = 0; t < 9; ++t) wd[t * 4 + j] = 0;
+          cc[j].bias2 = 0; cc[j].mult = (1 << 30) + 1; cc[j].rshift = 1; cc[j].kc = 1;
+          continue;
+        }
+        int32_t sum_w = 0;
+        for (int t = 0; t < 9; ++t) {
+          const int8_t wv = w[(size_t)t * d->cout + ch];
+          sum_w += wv;
+          wd[t * 4 + j] = ((uint32_t)(uint8_t)wv) << (8 * j);      /* byte j selects channel j in v_dot4 */
+        }
+        rc = build_chan(d, weights_blob, ch, sum_w, 128, &cc[j]);  /* every depthwise conv feeds a LeakyReLU LUT */
+        if (rc) break;
+      }
+      if (rc) break;
+    }
+  }
+
+  /* ---------------- residual adds ---------------- */
+  static const int add_t[YF_N_ADD][3] = {{62, 67, 68}, {78, 83, 84}, {84, 89, 90}};   /* tfl tensors in1,in2,out */
+  for (int s = 0; s < YF_N_ADD && !rc; ++s) {
+    const float s1 = t_scale(add_t[s][0]), s2 = t_scale(add_t[s][1]), so = t_scale(add_t[s][2]);
+    const double twice_max = (double)(2 * (s1 > s2 ? s1 : s2));
+    yf_add* a = &ix->add[s];
+    int sh;
+    yf_quantize_multiplier((double)s1 / twice_max, &a->m1, &sh); a->s1 = sh;
+    yf_quantize_multiplier((double)s2 / twice_max, &a->m2, &sh); a->s2 = sh;
+    yf_quantize_multiplier(twice_max / (double)((float)(1 << 20) * so), &a->mo, &sh); a->so = sh;
+    if (a->s1 > 0 || a->s2 > 0 || a->so > 0) rc = YF_PREP_ERR_SHIFT_RANGE;      /* ...SmallerThanOneExp */
+    a->zp1 = t_zp(add_t[s][0]); a->zp2 = t_zp(add_t[s][1]); a->zpo = t_zp(add_t[s][2]);
+  }
+
+  /* ---------------- LUTs ---------------- */
+  if (!rc) {
+    ix->lut_off = (uint32_t)blob_alloc(&b, (size_t)YF_N_LUT * 256);
+    uint8_t* L = b.p + ix->lut_off;
+    static const int leaky[][3] = {       /* lut id, tensor in, tensor out (tflite LEAKY_RELU ops) */
+      {YF_L_LEAKY2, 51, 52}, {YF_L_LEAKY4, 53, 54}, {YF_L_LEAKY7, 56, 57}, {YF_L_LEAKY11, 60, 61},
+      {YF_L_LEAKY14, 63, 64}, {YF_L_LEAKY16, 65, 66}, {YF_L_LEAKY20, 69, 70}, {YF_L_LEAKY24, 72, 73},
+      {YF_L_LEAKY28, 76, 77}, {YF_L_LEAKY31, 79, 80}, {YF_L_LEAKY33, 81, 82}, {YF_L_LEAKY37, 85, 86},
+      {YF_L_LEAKY39, 87, 88}, {YF_L_LEAKY48, 94, 95}, {YF_L_LEAKY50, 96, 97}, {YF_L_LEAKY52, 98, 99},
+    };
+    for (unsigned i = 0; i < sizeof leaky / sizeof leaky[0]; ++i)
+      build_leaky_lut(leaky[i][1], leaky[i][2], L + 256 * leaky[i][0]);
+    build_requant_lut(58, 103, L + 256 * YF_L_Q21);          /* QUANTIZE #21: pool_8 branch of concat_22 */
+    build_requant_lut(74, 101, L + 256 * YF_L_Q45);          /* QUANTIZE #45: pool_25 branch of concat_46 */
+    uint8_t l43[256], q44[256];
+    build_leaky_lut(91, 92, l43);                            /* LEAKY_RELU #43 */
+    build_requant_lut(92, 102, q44);                         /* QUANTIZE #44 */
+    for (int i = 0; i < 256; ++i) L[256 * YF_L_L43Q44 + i] = q44[(int)(int8_t)l43[i] + 128];
+  }
+
+  ix->in_zp = t_zp(0);
+  if (rc) { free(b.p); *out_blob = NULL; return rc; }
+  blob_alloc(&b, 64);                       /* zeroed tail so 16-byte reads past the last row stay in bounds */
+  ix->total_bytes = (uint32_t)b.size;
+  memcpy(b.p, ix, sizeof *ix);                /* device-side copy of the index, read by the kernels with scalar loads */
+  *out_blob = b.p;
+  return 0;
+}

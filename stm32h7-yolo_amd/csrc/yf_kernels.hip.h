@@ -1,0 +1,554 @@
+// Fused int8 yoloface forward for gfx950 (MI355X): device code.
+//
+// One workgroup walks groups of F frames through all 31 reference c-layers (reference
+// stm32/X-CUBE-AI/App/network.c:2204-2927; ai_network_run -> ai_platform_network_process, network.c:3402-3407)
+// with every activation resident in LDS; HBM is touched for the 9408-byte input frame and the 882-byte head only.
+//
+//   dense 3x3 / 1x1 conv  : v_mfma_i32_16x16x64_i8, weights as the A operand (rows = output channels), pixels as
+//                           the B operand (columns), block-diagonal packing (BD pixel sets per MFMA) for the skinny
+//                           layers, so every lane ends up owning 4 consecutive output channels of ONE pixel
+//   depthwise 3x3         : v_dot4_i32_i8 against byte-masked weight dwords held in SGPRs
+//   bias+requantize       : TFLite MultiplyByQuantizedMultiplier, fused:  s = (acc*M + 2^30) >> 31 ;
+//                           y = (s + kc + (s>>31)) >> rshift   (exact for rshift >= 1, checked on the host)
+//   LeakyReLU / QUANTIZE  : 256-entry LDS byte LUTs built on the host with TFLite's fixed-point arithmetic
+//   max-pool              : separable, packed 2x int16 max on the byte lanes, clamped coordinates
+//   residual add          : TFLite int8 ADD arithmetic in the producing conv's epilogue
+//   concat                : producers write straight into the concat buffer (no copy)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "yf_tables.h"
+
+namespace yf {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------ LDS plan
+// Per-frame arena (bytes).  Buffers alias by lifetime; see DESIGN.md "LDS plan" for the liveness table.
+constexpr int FRAME_BYTES = 34176;
+constexpr int LUT_BYTES = YF_N_LUT * 256;
+constexpr int OUT_FRAME_BYTES = 882;
+
+// Buf: OFF byte offset in the frame arena, logical W x H, S bytes per pixel, RS pixels per row (incl. halo),
+// PT/PL halo rows/cols in front of logical pixel (0,0).
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_>
+struct Buf {
+  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_;
+  static constexpr int P = W_ * H_;
+  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + ((y + PT_) * RS_ + (x + PL_)) * S_; }
+  __device__ static __forceinline__ int at_p(int p) {
+    if constexpr (RS_ == W_ && PT_ == 0 && PL_ == 0) return OFF_ + p * S_;
+    else { const int y = p / W_; return at(y, p - y * W_); }
+  }
+};
+
+//                 OFF    W   H   S  RS PT PL
+typedef Buf<    0, 56, 56,  4, 60, 1, 4> B_IN;    // RGBX dwords, top halo row, halo column at dword 3
+typedef Buf<13696, 28, 28,  8, 30, 1, 1> B_T1;    // conv2d_1 out (+LeakyReLU), halo ring for dw3
+typedef Buf<20896, 28, 28,  8, 28, 0, 0> B_T2;    // conv2d_3 out
+typedef Buf<16832, 28, 28,  4, 28, 0, 0> B_T3;    // conv2d_5 out
+typedef Buf<    0, 28, 28, 20, 29, 1, 1> B_T4;    // conv2d_6 out, top/left halo for dw10
+typedef Buf<16832, 14, 28, 20, 14, 0, 0> B_HB;    // pool_8 horizontal pass [28 rows][14]
+typedef Buf<24672, 14, 14, 48, 14, 0, 0> B_T14;   // concat_22: pool [0,18) | conv [20,38)
+typedef Buf<16832, 14, 14, 32, 14, 0, 0> B_T6;    // conv2d_10 out
+typedef Buf<    0, 14, 14,  8, 14, 0, 0> B_T7;    // conv2d_12 out
+typedef Buf< 1568, 14, 14, 36, 16, 1, 1> B_T8;    // conv2d_13 out, halo ring
+typedef Buf<10784, 14, 14, 48, 14, 0, 0> B_T9;    // conv2d_15 out
+typedef Buf<20192, 14, 14,  8, 14, 0, 0> B_T11;   // eltwise_18 out
+typedef Buf<    0, 14, 14, 24, 15, 1, 1> B_T15;   // conv2d_23 out, top/left halo
+typedef Buf< 5408,  7,  7, 48,  7, 0, 0> B_T30;   // concat_46: pool [0,24) | conv [24,48)
+typedef Buf< 7760,  7,  7, 32,  7, 0, 0> B_T17;   // conv2d_27 out
+typedef Buf< 9328,  7,  7,  8,  7, 0, 0> B_T18;   // conv2d_29 out
+typedef Buf< 9728,  7,  7, 40,  9, 1, 1> B_T19;   // conv2d_30/36/47 out, halo ring (three lifetimes)
+typedef Buf<12976,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
+typedef Buf<15328,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
+typedef Buf<15720,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
+typedef Buf<16112,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
+
+enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3 };
+
+// ------------------------------------------------------------------------------------------------ arithmetic
+// TFLite MultiplyByQuantizedMultiplier for shift <= -1, fused with "+ zero point (+128)": see yf_tables.h.
+__device__ __forceinline__ int requant(int acc, int mult, int kc, int rshift) {
+  const long long p = (long long)acc * (long long)mult + (1ll << 30);     // v_mad_i64_i32
+  const int s = (int)(p >> 31);
+  return (s + kc + (s >> 31)) >> rshift;
+}
+// generic MBQM with shift <= 0 (residual add path)
+__device__ __forceinline__ int mbqm_le0(int x, int mult, int shift) {
+  const long long p = (long long)x * (long long)mult + (1ll << 30);
+  const int s = (int)(p >> 31);
+  const int rs = -shift;
+  const int half = rs > 0 ? (1 << (rs - 1)) : 0;
+  const int sg = rs > 0 ? (s >> 31) : 0;
+  return (s + half + sg) >> rs;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
+__device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
+  return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
+}
+__device__ __forceinline__ uint32_t lut4(const uint8_t* lut, uint32_t d) {   // per byte: lut[q + 128]
+  const uint32_t x = d ^ 0x80808080u;
+  return (uint32_t)lut[x & 255] | ((uint32_t)lut[(x >> 8) & 255] << 8) | ((uint32_t)lut[(x >> 16) & 255] << 16) |
+         ((uint32_t)lut[x >> 24] << 24);
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {          // v_pk_max_i16
+  v2s x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  v2s r = __builtin_elementwise_max(x, y);
+  uint32_t o; __builtin_memcpy(&o, &r, 4); return o;
+}
+// running per-byte signed max of packed int8x4: bytes are lifted into the high byte of int16 lanes
+struct ByteMax {
+  uint32_t mo = 0x80008000u, me = 0x80008000u;
+  __device__ __forceinline__ void add(uint32_t d) {
+    mo = pkmax(mo, d & 0xFF00FF00u);
+    me = pkmax(me, (d << 8) & 0xFF00FF00u);
+  }
+  __device__ __forceinline__ uint32_t get() const { return (mo & 0xFF00FF00u) | ((me >> 8) & 0x00FF00FFu); }
+};
+
+__device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// ------------------------------------------------------------------------------------------------ halo fill
+// RING: 1-pixel border all round (SAME 3x3 stride 1); otherwise top row + left column (explicit PAD, stride 2)
+template <class B, bool RING, int F, int NT>
+__device__ __forceinline__ void fill_halo(char* frames, int zp, int tid) {
+  const uint32_t v = (uint32_t)(zp & 255) * 0x01010101u;
+  constexpr int DW = B::S / 4;
+  constexpr int HR = B::H + B::PT + (RING ? 1 : 0), WR = B::RS;        // halo'd rows / cols
+  constexpr int NPIX = RING ? (2 * WR + 2 * (HR - 2)) : (WR + HR - 1);
+  for (int i = tid; i < F * NPIX * DW; i += NT) {
+    const int d = i % DW, t = i / DW, k = t % NPIX, f = t / NPIX;
+    int r, c;
+    if constexpr (RING) {
+      if (k < WR) { r = 0; c = k; }
+      else if (k < 2 * WR) { r = HR - 1; c = k - WR; }
+      else { const int m = k - 2 * WR; r = 1 + (m >> 1); c = (m & 1) ? WR - 1 : 0; }
+    } else {
+      if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
+    }
+    *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B::OFF + (r * WR + c) * B::S + 4 * d) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ input staging
+// NHWC int8 frames (9408 B) -> RGBX dwords with halo.  Coalesced 12-byte loads (4 pixels per lane).
+template <int F, int NT>
+__device__ __forceinline__ void stage_input(char* frames, const int8_t* __restrict__ in, long first_frame, long n_frames,
+                                            int zp, int tid) {
+  const uint32_t hv = (uint32_t)(zp & 255) * 0x01010101u;
+  // halo: row 0 (60 dwords) and dword column 3 of rows 1..56
+  for (int i = tid; i < F * (60 + 56); i += NT) {
+    const int f = i / 116, k = i - f * 116;
+    const int idx = k < 60 ? k : (k - 60 + 1) * 60 + 3;
+    *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B_IN::OFF + idx * 4) = hv;
+  }
+  for (int i = tid; i < F * 784; i += NT) {
+    const int f = i / 784, r = i - f * 784;
+    long fi = first_frame + f; if (fi >= n_frames) fi = n_frames - 1;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + fi * 9408 + r * 12);
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+    uint4 px;
+    px.x = d0 & 0x00FFFFFFu;
+    px.y = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
+    px.z = (d1 >> 16) | ((d2 & 0xFFu) << 16);
+    px.w = d2 >> 8;
+    const int y = r / 14, x4 = (r - y * 14) * 4;
+    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * 60 + x4 + 4) * 4) = px;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ epilogue store
+struct AddCtx { int zp1, zp2, zpo, m1, s1, m2, s2, mo, so; };
+
+template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
+__device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
+                                               int p, int chq, const int (&y)[4], const AddCtx& ad) {
+  if constexpr (EPI == EPI_LUT) {
+    const uint8_t* lut = luts + LUT_ID * 256;
+    const uint32_t v = (uint32_t)lut[clampi(y[0], 0, 255)] | ((uint32_t)lut[clampi(y[1], 0, 255)] << 8) |
+                       ((uint32_t)lut[clampi(y[2], 0, 255)] << 16) | ((uint32_t)lut[clampi(y[3], 0, 255)] << 24);
+    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = v;
+  } else if constexpr (EPI == EPI_RAW) {
+    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
+        pack4(clampi(y[0], -128, 127), clampi(y[1], -128, 127), clampi(y[2], -128, 127), clampi(y[3], -128, 127));
+  } else if constexpr (EPI == EPI_ADD) {
+    // tflite ADD: in1 = stored tensor (ADDB), in2 = this conv's output
+    const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq);
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q1 = (int)(int8_t)((o >> (8 * j)) & 255);
+      const int q2 = clampi(y[j], -128, 127);
+      const int a = mbqm_le0((q1 - ad.zp1) * (1 << 20), ad.m1, ad.s1);
+      const int b = mbqm_le0((q2 - ad.zp2) * (1 << 20), ad.m2, ad.s2);
+      r[j] = clampi(mbqm_le0(a + b, ad.mo, ad.so) + ad.zpo, -128, 127);
+    }
+    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = pack4(r[0], r[1], r[2], r[3]);
+  } else {  // EPI_HEAD: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
+    const int v0 = clampi(y[0], -128, 127), v1 = clampi(y[1], -128, 127);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out_all + f * OUT_FRAME_BYTES + p * 18 + chq);
+    dst[0] = (uint16_t)((v0 & 255) | ((v1 & 255) << 8));
+    if (chq + 2 < 18) {
+      const int v2 = clampi(y[2], -128, 127), v3 = clampi(y[3], -128, 127);
+      dst[1] = (uint16_t)((v2 & 255) | ((v3 & 255) << 8));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dense 1x1 stage
+// BD pixel sets per MFMA (block-diagonal A): BD=1: <=16 channels x K<=64, BD=2: <=8 x K<=32, BD=4: <=4 x K<=16.
+template <int F, int NW, int BD, class IN, class OUT, int OUT_CH0, int COUT, int KROW, int EPI, int LUT_ID, class ADDB>
+__device__ __forceinline__ void dense_stage(char* frames, const uint8_t* luts, char* out_all,
+                                            const uint8_t* __restrict__ tab, const yf_dense d, const AddCtx ad,
+                                            int wave, int lane) {
+  constexpr int NCHT = 16 / BD;
+  constexpr int COUT_PAD4 = (COUT + 3) & ~3;
+  constexpr int NTL = (COUT + NCHT - 1) / NCHT;
+  constexpr int PIX_T = 16 * BD;
+  constexpr int P = IN::P;
+  constexpr int TOT = F * P;
+  constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
+  constexpr int JOBS = NTL * MT;
+  constexpr int JPW = (JOBS + NW - 1) / NW;
+  constexpr int RW = IN::S >= 16 ? 16 : IN::S;          // bytes of the pixel vector one lane supplies
+  static_assert(OUT::P == P, "1x1 conv keeps the grid");
+  static_assert(KROW <= 64 / BD, "k does not fit the block");
+  const int g = lane >> 4, c = lane & 15;
+  const int set = g * BD / 4;
+  const int kg = g % (4 / BD);
+  const int koff = kg * 16;
+  const int j0 = wave * JPW;
+  const int j1 = min(j0 + JPW, JOBS);
+  int cur_nt = -1;
+  v4i afrag = {0, 0, 0, 0};
+  int bias[4] = {0, 0, 0, 0}, mult[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+  int chq = 0;
+  for (int j = j0; j < j1; ++j) {
+    const int nt = j / MT, mt = j - nt * MT;
+    if (nt != cur_nt) {
+      cur_nt = nt;
+      const int ch = nt * NCHT + (c % NCHT);
+      const bool a_on = (c / NCHT == set) && (ch < COUT_PAD4) && (koff < KROW);
+      afrag = v4i{0, 0, 0, 0};
+      if (a_on) afrag = *reinterpret_cast<const v4i*>(tab + d.w_off + ch * KROW + koff);
+      chq = nt * NCHT + 4 * kg;
+      const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off) + min(chq, COUT_PAD4 - 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int4 t = *reinterpret_cast<const int4*>(cp + jj);
+        bias[jj] = t.x; mult[jj] = t.y; kc[jj] = t.z; rs[jj] = t.w;
+      }
+    }
+    const int q = mt * PIX_T + set * 16 + c;
+    const int qc = min(q, TOT - 1);
+    const int f = qc / P, p = qc - f * P;
+    char* fbase = frames + f * FRAME_BYTES;
+    v4i b = {0, 0, 0, 0};
+    if (koff < KROW && koff < IN::S) {
+      const char* src = fbase + IN::at_p(p) + koff;
+      if constexpr (RW == 16) b = *reinterpret_cast<const v4i*>(src);
+      else if constexpr (RW == 8) { const int2 t = *reinterpret_cast<const int2*>(src); b[0] = t.x; b[1] = t.y; }
+      else b[0] = *reinterpret_cast<const int*>(src);
+    }
+    v4i acc = {bias[0], bias[1], bias[2], bias[3]};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, b, acc, 0, 0, 0);
+    if (q < TOT && chq < COUT_PAD4) {
+      int y[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
+      epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, chq, y, ad);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ conv2d_1
+// 3x3 stride 2, Cin 3 (RGBX) -> 8: two k-steps, BD=2 (32 output pixels x 8 channels per MFMA pair).
+template <int F, int NW>
+__device__ __forceinline__ void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+                                            const yf_dense d, int wave, int lane) {
+  constexpr int P = 784, TOT = F * P, PIX_T = 32;
+  constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
+  constexpr int JPW = (MT + NW - 1) / NW;
+  const int g = lane >> 4, c = lane & 15;
+  const int set = g >> 1, half = g & 1;
+  // A fragments: rows 0..7 <-> set 0, rows 8..15 <-> set 1; channel = c & 7
+  const bool a_on = ((c >> 3) == set);
+  v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  if (a_on) {
+    const uint8_t* row = tab + d.w_off + (c & 7) * YF_CONV1_KROW;
+    a0 = *reinterpret_cast<const v4i*>(row + 16 * half);
+    a1 = *reinterpret_cast<const v4i*>(row + 32 + 16 * half);
+  }
+  const int chq = 4 * half;
+  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off) + chq;
+  int bias[4], mult[4], kc[4], rs[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int4 t = *reinterpret_cast<const int4*>(cp + jj);
+    bias[jj] = t.x; mult[jj] = t.y; kc[jj] = t.z; rs[jj] = t.w;
+  }
+  // dword offsets of this lane's taps relative to IN[2oy][2ox+3]  (see yf_tables.h, conv2d_1 packing)
+  const int o0 = half ? 61 : 0, o1 = half ? 62 : 1, o2 = half ? 120 : 2, o3 = half ? 121 : 60;
+  const int j0 = wave * JPW, j1 = min(j0 + JPW, MT);
+  const AddCtx ad = {};
+  for (int mt = j0; mt < j1; ++mt) {
+    const int q = mt * PIX_T + set * 16 + c;
+    const int qc = min(q, TOT - 1);
+    const int f = qc / P, p = qc - f * P;
+    const int oy = p / 28, ox = p - oy * 28;
+    char* fbase = frames + f * FRAME_BYTES;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * 60 + 2 * ox + 3);
+    v4i b0, b1 = {0, 0, 0, 0};
+    b0[0] = (int)src[o0]; b0[1] = (int)src[o1]; b0[2] = (int)src[o2]; b0[3] = (int)src[o3];
+    b1[0] = (int)src[122];                        // (ky,kx) = (2,2); weight rows are zero for half 1 / other dwords
+    v4i acc = {bias[0], bias[1], bias[2], bias[3]};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+    if (q < TOT) {
+      int y[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
+      epilogue_store<EPI_LUT, YF_L_LEAKY2, B_T1, 0, B_T1>(fbase, luts, nullptr, f, p, chq, y, ad);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise 3x3
+// IN has a halo holding its zero point; the zero point itself is folded into bias2.  Jobs = channel group x
+// pixel chunk; the group's 36 masked weight dwords and 4 yf_chan are wave-uniform (scalar loads).
+template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
+__device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+                                         const yf_dw d, int wave, int lane) {
+  constexpr int NG = (C + 3) / 4;
+  constexpr int P = OUT::P, TOT = F * P;
+  constexpr int NB = (TOT + 63) / 64;                  // 64-pixel blocks per channel group
+  constexpr int JOBS = NG * NB;
+  constexpr int JPW = (JOBS + NW - 1) / NW;
+  const uint8_t* lut = luts + LUT_ID * 256;
+  const int j1 = min(wave * JPW + JPW, JOBS);
+  int j = wave * JPW;
+  while (j < j1) {
+    const int cg = j / NB;
+    const int jend = min(j1, (cg + 1) * NB);
+    const uint32_t* wg = reinterpret_cast<const uint32_t*>(tab + d.g_off + cg * YF_DW_GROUP_BYTES);
+    const yf_chan* cp = reinterpret_cast<const yf_chan*>(wg + 36);
+    for (; j < jend; ++j) {
+      const int q = (j - cg * NB) * 64 + lane;
+      if (q >= TOT) continue;
+      const int f = q / P, p = q - f * P;
+      const int oy = p / OUT::W, ox = p - oy * OUT::W;
+      char* fbase = frames + f * FRAME_BYTES;
+      // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, col ox*STRIDE+kx
+      const char* src = fbase + IN::OFF + ((oy * STRIDE) * IN::RS + ox * STRIDE) * IN::S + 4 * cg;
+      int acc[4] = {cp[0].bias2, cp[1].bias2, cp[2].bias2, cp[3].bias2};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (int)lds_u32(src + (ky * IN::RS + kx) * IN::S);
+          const int t = ky * 3 + kx;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_sdot4(tap, (int)wg[t * 4 + jj], acc[jj], false);
+        }
+      int idx[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) idx[jj] = clampi(requant(acc[jj], cp[jj].mult, cp[jj].kc, cp[jj].rshift), 0, 255);
+      const uint32_t v = (uint32_t)lut[idx[0]] | ((uint32_t)lut[idx[1]] << 8) | ((uint32_t)lut[idx[2]] << 16) |
+                         ((uint32_t)lut[idx[3]] << 24);
+      *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + 4 * cg) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ max-pools
+// pool_8: 8x8 stride 2 pad 3 on T4 (28x28x18) -> separable; the vertical pass applies QUANTIZE#21 and writes the
+// pool half of concat_22.  Out-of-range taps are handled by clamping the coordinate (max is idempotent).
+template <int F, int NT>
+__device__ __forceinline__ void pool8_h(char* frames, int tid) {
+  for (int i = tid; i < F * 28 * 14 * 5; i += NT) {
+    const int cg = i % 5; int t = i / 5;
+    const int ox = t % 14; t /= 14;
+    const int y = t % 28; const int f = t / 28;
+    char* fbase = frames + f * FRAME_BYTES;
+    ByteMax m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m.add(lds_u32(fbase + B_T4::at(y, clampi(2 * ox - 3 + k, 0, 27)) + 4 * cg));
+    *reinterpret_cast<uint32_t*>(fbase + B_HB::OFF + (y * 14 + ox) * 20 + 4 * cg) = m.get();
+  }
+}
+template <int F, int NT>
+__device__ __forceinline__ void pool8_v(char* frames, const uint8_t* luts, int tid) {
+  const uint8_t* lut = luts + YF_L_Q21 * 256;
+  for (int i = tid; i < F * 14 * 14 * 5; i += NT) {
+    const int cg = i % 5; int t = i / 5;
+    const int ox = t % 14; t /= 14;
+    const int oy = t % 14; const int f = t / 14;
+    char* fbase = frames + f * FRAME_BYTES;
+    ByteMax m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m.add(lds_u32(fbase + B_HB::OFF + (clampi(2 * oy - 3 + k, 0, 27) * 14 + ox) * 20 + 4 * cg));
+    *reinterpret_cast<uint32_t*>(fbase + B_T14::at_p(oy * 14 + ox) + 4 * cg) = lut4(lut, m.get());
+  }
+}
+// pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
+template <int F, int NT>
+__device__ __forceinline__ void pool25(char* frames, const uint8_t* luts, int tid) {
+  const uint8_t* lut = luts + YF_L_Q45 * 256;
+  for (int i = tid; i < F * 49 * 6; i += NT) {
+    const int cg = i % 6; int t = i / 6;
+    const int p = t % 49; const int f = t / 49;
+    const int oy = p / 7, ox = p - oy * 7;
+    char* fbase = frames + f * FRAME_BYTES;
+    ByteMax m;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx)
+        m.add(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, 13), clampi(2 * ox - 1 + kx, 0, 13)) + 4 * cg));
+    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4(lut, m.get());
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ debug dump
+// Observer-style per-stage dump (reference observer API, ai_platform_interface.h:684-731): logical NHWC bytes.
+template <class B, int C, int F, int NT>
+__device__ __forceinline__ void dump_buf(const char* frames, int8_t* dump, long stride, long off, long first_frame,
+                                         long n_frames, int tid, int ch0 = 0, int split = 1 << 30, int gap = 0) {
+  if (!dump) return;
+  for (int i = tid; i < F * B::P * C; i += NT) {
+    const int ch = i % C; const int t = i / C;
+    const int p = t % B::P; const int f = t / B::P;
+    if (first_frame + f >= n_frames) continue;
+    const int phys = ch0 + ch + (ch >= split ? gap : 0);
+    dump[(first_frame + f) * stride + off + (long)p * C + ch] = (int8_t)frames[f * FRAME_BYTES + B::at_p(p) + phys];
+  }
+}
+
+struct DumpOffsets {   // byte offsets of each fused stage's tensor inside one frame's dump record
+  enum { T1 = 0, T2 = T1 + 6272, T3 = T2 + 6272, T4 = T3 + 3136, Q21 = T4 + 14112, T6 = Q21 + 3528, T7 = T6 + 3528,
+         T8 = T7 + 1176, T9 = T8 + 7056, T11 = T9 + 7056, T14 = T11 + 1176, T15 = T14 + 7056, Q45 = T15 + 4704,
+         T17 = Q45 + 1176, T18 = T17 + 1176, T19 = T18 + 392, T20 = T19 + 1960, T22 = T20 + 1960, T23 = T22 + 392,
+         T24 = T23 + 1960, T26 = T24 + 1960, T30 = T26 + 392, T31 = T30 + 2352, T32 = T31 + 1960, T33 = T32 + 1960,
+         TOTAL = T33 + 1568 };
+};
+
+// ------------------------------------------------------------------------------------------------ the kernel
+struct NetParams {
+  const int8_t* in;       // [n][56][56][3] int8
+  int8_t* out;            // [n][7][7][18] int8
+  long n;
+  const uint8_t* tab;     // device table blob (yf_host_prep.c)
+  int8_t* dump;           // optional per-stage dump, [n][DumpOffsets::TOTAL]
+};
+static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
+
+template <int F, int NW, bool DUMP>
+__global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64;
+  constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
+  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);
+  char* out_all = smem + LUT_BYTES;
+  char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  const yf_table_index& ix = *reinterpret_cast<const yf_table_index*>(tab);   // uniform: scalar loads per stage
+
+  for (int i = tid; i < LUT_BYTES / 16; i += NT)
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + ix.lut_off)[i];
+
+  const long n_groups = (prm.n + F - 1) / F;
+  const AddCtx no_add = {};
+  auto addctx = [&](int k) {
+    const yf_add& a = ix.add[k];
+    return AddCtx{a.zp1, a.zp2, a.zpo, a.m1, a.s1, a.m2, a.s2, a.mo, a.so};
+  };
+  constexpr long DS = DumpOffsets::TOTAL;
+#define YF_SYNC() __syncthreads()
+#define YF_DUMP(BUF, C, OFF, ...) \
+  if constexpr (DUMP) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); }
+
+  for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const long first = grp * F;
+    YF_SYNC();                                                         // previous group's arena is dead
+    stage_input<F, NT>(frames, prm.in, first, prm.n, ix.in_zp, tid);
+    fill_halo<B_T1, true, F, NT>(frames, ix.halo_zp[YF_W_DW3], tid);
+    YF_SYNC();
+    conv1_stage<F, NW>(frames, luts, tab, ix.dense[YF_D_CONV1], wave, lane);                        // conv2d_1
+    YF_SYNC(); YF_DUMP(B_T1, 8, T1)
+    dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane);   // conv2d_3
+    YF_SYNC(); YF_DUMP(B_T2, 8, T2)
+    dense_stage<F, NW, 4, B_T2, B_T3, 0, 4, 16, EPI_RAW, 0, B_T3>(frames, luts, out_all, tab, ix.dense[YF_D_C5], no_add, wave, lane);   // conv2d_5
+    YF_SYNC(); YF_DUMP(B_T3, 4, T3)
+    fill_halo<B_T4, false, F, NT>(frames, ix.halo_zp[YF_W_DW10], tid);
+    dense_stage<F, NW, 4, B_T3, B_T4, 0, 18, 16, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, luts, out_all, tab, ix.dense[YF_D_C6], no_add, wave, lane);   // conv2d_6
+    YF_SYNC(); YF_DUMP(B_T4, 18, T4)
+    pool8_h<F, NT>(frames, tid);                                                                   // pool_8 (h)
+    YF_SYNC();
+    pool8_v<F, NT>(frames, luts, tid);                                                             // pool_8 (v) + QUANTIZE#21
+    dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane);   // conv2d_10
+    YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
+    dense_stage<F, NW, 2, B_T6, B_T7, 0, 6, 32, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C12], no_add, wave, lane);  // conv2d_12
+    YF_SYNC(); YF_DUMP(B_T7, 6, T7)
+    fill_halo<B_T8, true, F, NT>(frames, ix.halo_zp[YF_W_DW15], tid);
+    dense_stage<F, NW, 4, B_T7, B_T8, 0, 36, 16, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, luts, out_all, tab, ix.dense[YF_D_C13], no_add, wave, lane);  // conv2d_13
+    YF_SYNC(); YF_DUMP(B_T8, 36, T8)
+    dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane);   // conv2d_15
+    YF_SYNC(); YF_DUMP(B_T9, 36, T9)
+    dense_stage<F, NW, 1, B_T9, B_T11, 0, 6, 48, EPI_ADD, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C17], addctx(YF_A_ADD18), wave, lane);  // conv2d_17 + eltwise_18
+    YF_SYNC(); YF_DUMP(B_T11, 6, T11)
+    dense_stage<F, NW, 4, B_T11, B_T14, YF_T14_CONV_BASE, 18, 16, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, luts, out_all, tab, ix.dense[YF_D_C19], no_add, wave, lane);  // conv2d_19 -> concat_22
+    YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
+    fill_halo<B_T15, false, F, NT>(frames, ix.halo_zp[YF_W_DW27], tid);
+    dense_stage<F, NW, 1, B_T14, B_T15, 0, 24, 48, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, ix.dense[YF_D_C23], no_add, wave, lane);  // conv2d_23
+    YF_SYNC(); YF_DUMP(B_T15, 24, T15)
+    pool25<F, NT>(frames, luts, tid);                                                              // pool_25 + QUANTIZE#45
+    dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane);   // conv2d_27
+    YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
+    dense_stage<F, NW, 2, B_T17, B_T18, 0, 8, 32, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C29], no_add, wave, lane);  // conv2d_29
+    YF_SYNC(); YF_DUMP(B_T18, 8, T18)
+    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW32], tid);
+    dense_stage<F, NW, 4, B_T18, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C30], no_add, wave, lane);  // conv2d_30
+    YF_SYNC(); YF_DUMP(B_T19, 40, T19)
+    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane);   // conv2d_32
+    YF_SYNC(); YF_DUMP(B_T20, 40, T20)
+    dense_stage<F, NW, 1, B_T20, B_T22, 0, 8, 48, EPI_ADD, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C34], addctx(YF_A_ADD35), wave, lane);  // conv2d_34 + eltwise_35
+    YF_SYNC(); YF_DUMP(B_T22, 8, T22)
+    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW38], tid);
+    dense_stage<F, NW, 4, B_T22, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C36], no_add, wave, lane);  // conv2d_36
+    YF_SYNC(); YF_DUMP(B_T19, 40, T23)
+    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane);   // conv2d_38
+    YF_SYNC(); YF_DUMP(B_T20, 40, T24)
+    dense_stage<F, NW, 1, B_T20, B_T26, 0, 8, 48, EPI_ADD, 0, B_T22>(frames, luts, out_all, tab, ix.dense[YF_D_C40], addctx(YF_A_ADD41), wave, lane);  // conv2d_40 + eltwise_41
+    YF_SYNC(); YF_DUMP(B_T26, 8, T26)
+    dense_stage<F, NW, 4, B_T26, B_T30, 24, 24, 16, EPI_LUT, YF_L_L43Q44, B_T30>(frames, luts, out_all, tab, ix.dense[YF_D_C42], no_add, wave, lane);  // conv2d_42 -> concat_46
+    YF_SYNC(); YF_DUMP(B_T30, 48, T30)
+    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW49], tid);
+    dense_stage<F, NW, 1, B_T30, B_T19, 0, 40, 48, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C47], no_add, wave, lane);  // conv2d_47
+    YF_SYNC(); YF_DUMP(B_T19, 40, T31)
+    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane);   // conv2d_49
+    YF_SYNC(); YF_DUMP(B_T20, 40, T32)
+    dense_stage<F, NW, 1, B_T20, B_T33, 0, 32, 48, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C51], no_add, wave, lane);  // conv2d_51
+    YF_SYNC(); YF_DUMP(B_T33, 32, T33)
+    dense_stage<F, NW, 1, B_T33, B_T33, 0, 18, 32, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C53], no_add, wave, lane);  // conv2d_53 (head)
+    YF_SYNC();
+    {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
+      const long valid = min((long)F, prm.n - first);
+      const int n16 = (int)(valid * (OUT_FRAME_BYTES / 2));
+      uint16_t* dst = reinterpret_cast<uint16_t*>(prm.out + first * OUT_FRAME_BYTES);
+      const uint16_t* srcp = reinterpret_cast<const uint16_t*>(out_all);
+      for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
+    }
+  }
+#undef YF_DUMP
+#undef YF_SYNC
+}
+
+template <int F, int NW>
+constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+
+}  // namespace yf

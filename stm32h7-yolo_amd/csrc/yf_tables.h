@@ -1,0 +1,94 @@
+/* Device constant tables of the fused yoloface int8 engine: shared by the host preparation (yf_host_prep.c),
+ * the HIP kernels (yf_engine.hip) and the table-level CPU emulator used only by tests (tests/csrc/).
+ *
+ * One "stage" = one fused reference c-layer (reference stm32/X-CUBE-AI/App/network.c:2204-2927 lists the 31
+ * c-layers; SURVEY.md Appendix A maps them to the 54 tflite ops).  Everything a stage needs at run time is
+ * precomputed here once, at ai_network_init time (reference network.c:3385-3399 does the equivalent pointer
+ * binding on the MCU).
+ */
+#ifndef YF_TABLES_H
+#define YF_TABLES_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per output channel requantisation constants (16 B) --------------------------------------------------
+ * acc  = bias2 + sum w*x_raw                      (bias2 = bias - zp_in * sum(w): input zero point folded)
+ * s    = SRDHM(acc, mult)                         (== floor((acc*mult + 2^30) / 2^31))
+ * y    = (s + kc + (s >> 31)) >> rshift           (== RoundingDivideByPOT(s, rshift) + Z, needs rshift >= 1)
+ *        kc = 2^(rshift-1) + (Z << rshift);  Z = zp_out + 128 when the value indexes a LUT, zp_out otherwise
+ * The identity is exact for rshift >= 1; the host refuses to initialise a model with a channel outside it. */
+typedef struct {
+  int32_t bias2;
+  int32_t mult;
+  int32_t kc;
+  int32_t rshift;
+} yf_chan;
+
+/* ---- dense (MFMA) stage ----------------------------------------------------------------------------------
+ * Weight rows are stored [cout_pad4][krow] int8, krow = K rounded up to 16, zero filled; the k order is the
+ * channel order of the stage's INPUT buffer (which may be a permutation of the tflite order: concat buffers). */
+typedef struct {
+  uint32_t w_off;      /* byte offset of the weight rows in the table blob (16-B aligned) */
+  uint32_t c_off;      /* byte offset of the yf_chan array (cout_pad4 entries) */
+  uint16_t cout, cout_pad4, k, krow;
+} yf_dense;
+
+/* ---- depthwise stage: per group of 4 channels: 9 taps x 4 masked weight dwords, then 4 yf_chan ------------ */
+typedef struct {
+  uint32_t g_off;      /* byte offset of group 0; each group is YF_DW_GROUP_BYTES */
+  uint16_t c, ngroups;
+} yf_dw;
+#define YF_DW_GROUP_BYTES (36 * 4 + 4 * 16)
+
+/* ---- residual add (tflite ADD, int8): out = clamp(zpo + MBQM(MBQM((a-zp1)<<20,m1,s1) + MBQM((b-zp2)<<20,m2,s2), mo, so)) */
+typedef struct {
+  int32_t zp1, zp2, zpo;
+  int32_t m1, s1, m2, s2, mo, so;
+} yf_add;
+
+enum {
+  /* dense stages in execution order */
+  YF_D_CONV1 = 0, YF_D_C5, YF_D_C6, YF_D_C12, YF_D_C13, YF_D_C17, YF_D_C19, YF_D_C23, YF_D_C29, YF_D_C30,
+  YF_D_C34, YF_D_C36, YF_D_C40, YF_D_C42, YF_D_C47, YF_D_C51, YF_D_C53, YF_N_DENSE
+};
+enum { YF_W_DW3 = 0, YF_W_DW10, YF_W_DW15, YF_W_DW27, YF_W_DW32, YF_W_DW38, YF_W_DW49, YF_N_DW };
+enum { YF_A_ADD18 = 0, YF_A_ADD35, YF_A_ADD41, YF_N_ADD };
+
+/* 256-entry byte LUTs (index q+128, value int8 stored as a byte), in execution order.
+ * LEAKY_n = TFLite int8 LEAKY_RELU of tflite op n; Q21/Q45 = QUANTIZE ops; L43Q44 = QUANTIZE#44 o LEAKY#43. */
+enum {
+  YF_L_LEAKY2 = 0, YF_L_LEAKY4, YF_L_LEAKY7, YF_L_Q21, YF_L_LEAKY11, YF_L_LEAKY14, YF_L_LEAKY16, YF_L_LEAKY20,
+  YF_L_LEAKY24, YF_L_Q45, YF_L_LEAKY28, YF_L_LEAKY31, YF_L_LEAKY33, YF_L_LEAKY37, YF_L_LEAKY39, YF_L_L43Q44,
+  YF_L_LEAKY48, YF_L_LEAKY50, YF_L_LEAKY52, YF_N_LUT
+};
+
+/* conv2d_1 packs its 27 taps into two MFMA k-steps over RGBX pixels (4 bytes per pixel, X weight = 0):
+ * step 0 carries the pixels (ky,kx) = (0,0)(0,1)(0,2)(1,0) | (1,1)(1,2)(2,0)(2,1) (two 16-byte halves),
+ * step 1 carries (2,2) in its first dword.  Row layout [8 cout][2 steps][32 B]. */
+#define YF_CONV1_KROW 64
+
+typedef struct {
+  yf_dense dense[YF_N_DENSE];
+  yf_dw    dw[YF_N_DW];
+  yf_add   add[YF_N_ADD];
+  uint32_t lut_off;          /* YF_N_LUT * 256 bytes */
+  uint32_t total_bytes;
+  int32_t  in_zp;            /* input zero point (-128): halo fill of the staged frame */
+  int32_t  halo_zp[YF_N_DW]; /* zero point of each depthwise INPUT buffer: its halo fill value */
+} yf_table_index;
+
+/* The table blob starts with a copy of the index (so kernels fetch stage descriptors with scalar loads instead of
+ * carrying ~120 dwords of kernel arguments in SGPRs). */
+#define YF_INDEX_RESERVED 512
+
+/* Channel order of concat_22's buffer T14: pool branch at [0,18), conv branch at [20,38) (4-byte aligned
+ * starts so that packed 4-channel stores stay aligned); conv2d_23's k order follows it. */
+#define YF_T14_CONV_BASE 20
+
+#ifdef __cplusplus
+}
+#endif
+#endif
