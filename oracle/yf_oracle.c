@@ -453,6 +453,14 @@ int yfo_run(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* o
 }
 
 /* ------------------------------------------------------------------ box decode */
+/* float -> int32 as the reference's hosts do it: truncation; out-of-range or NaN gives INT32_MIN (x86 cvttss2si,
+ * which is what numpy's astype(int32) and a C cast produce on the reference's PC).  Only reachable with exp()
+ * of extreme logits (q >= ~100); stated explicitly so that the GPU decode can match it bit for bit. */
+static inline int32_t f2i(float v) {
+  if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
+  return (int32_t)v;
+}
+static inline int32_t dbl(int32_t v) { return (int32_t)((uint32_t)v * 2u); }
 static const float k_anchors[3][2] = {{9.f, 14.f}, {12.f, 17.f}, {22.f, 21.f}};  /* tflite_prediction.py:45-47, yoloface.c:20 */
 
 /* tflite_prediction.py:42-63.  Every transcendental is a lookup in the committed float32 tables
@@ -476,7 +484,7 @@ int yfo_decode_py(const int8_t* head, int gh, int gw, int frame, const float* si
           yfo_det* d = &dets[n];
           d->frame = frame; d->anchor = (uint8_t)a; d->row = (uint8_t)row; d->col = (uint8_t)col;
           d->q_conf = p[4]; d->conf = conf;
-          d->x1 = (int32_t)x1; d->y1 = (int32_t)y1; d->x2 = (int32_t)x2; d->y2 = (int32_t)y2;   /* astype(int32) */
+          d->x1 = f2i(x1); d->y1 = f2i(y1); d->x2 = f2i(x2); d->y2 = f2i(y2);   /* astype(int32) */
         }
         ++n;
       }
@@ -496,7 +504,7 @@ int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* e
       float y = (sig[p[1] + 128] + grid_y) * 8;
       float w = ex[p[2] + 128] * k_anchors[j][0];
       float h = ex[p[3] + 128] * k_anchors[j][1];
-      int y2 = (int)(x - w / 2), y1 = (int)(x + w / 2), x1 = (int)(y - h / 2), x2 = (int)(y + h / 2);
+      int y2 = f2i(x - w / 2), y1 = f2i(x + w / 2), x1 = f2i(y - h / 2), x2 = f2i(y + h / 2);
       if (x1 < 0) x1 = 0;
       if (y1 < 0) y1 = 0;
       if (x2 > 55) x2 = 55;
@@ -505,7 +513,7 @@ int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* e
         yfo_det* d = &dets[n];
         d->frame = frame; d->anchor = (uint8_t)j; d->row = (uint8_t)grid_y; d->col = (uint8_t)grid_x;
         d->q_conf = p[4]; d->conf = conf;
-        d->x1 = x1 * 2; d->y1 = y1 * 2; d->x2 = x2 * 2; d->y2 = y2 * 2;        /* as printed at yoloface.c:148 */
+        d->x1 = dbl(x1); d->y1 = dbl(y1); d->x2 = dbl(x2); d->y2 = dbl(y2);    /* as printed at yoloface.c:148 */
       }
       ++n;
     }

@@ -15,6 +15,12 @@ namespace {
 __device__ __constant__ uint32_t d_sig_bits[256];
 __device__ __constant__ uint32_t d_exp_bits[256];
 
+// float -> int32 with the x86 convention of the reference's hosts (cvttss2si): truncate, out of range -> INT32_MIN
+__device__ __forceinline__ int f2i_x86(float v) {
+  return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+__device__ __forceinline__ int dbl_wrap(int v) { return (int)((unsigned)v * 2u); }
+
 // ---------------------------------------------------------------------------------------------- box decode
 // One wave per frame; candidates are visited in the reference order and compacted with ballots so that the
 // record order equals the order the reference loops produce.
@@ -57,14 +63,14 @@ __global__ void __launch_bounds__(256) decode_kernel(const int8_t* __restrict__ 
       if (mode == YF_DECODE_PY) {
         float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
         x1 *= w_scale; x2 *= w_scale; y1 *= h_scale; y2 *= h_scale;
-        d.x1 = (int32_t)x1; d.y1 = (int32_t)y1; d.x2 = (int32_t)x2; d.y2 = (int32_t)y2;
+        d.x1 = f2i_x86(x1); d.y1 = f2i_x86(y1); d.x2 = f2i_x86(x2); d.y2 = f2i_x86(y2);
       } else {
-        int y2 = (int)(cx - bw / 2), y1 = (int)(cx + bw / 2), x1 = (int)(cy - bh / 2), x2 = (int)(cy + bh / 2);
+        int y2 = f2i_x86(cx - bw / 2), y1 = f2i_x86(cx + bw / 2), x1 = f2i_x86(cy - bh / 2), x2 = f2i_x86(cy + bh / 2);
         if (x1 < 0) x1 = 0;
         if (y1 < 0) y1 = 0;
         if (x2 > 55) x2 = 55;
         if (y2 > 55) y2 = 55;
-        d.x1 = x1 * 2; d.y1 = y1 * 2; d.x2 = x2 * 2; d.y2 = y2 * 2;
+        d.x1 = dbl_wrap(x1); d.y1 = dbl_wrap(y1); d.x2 = dbl_wrap(x2); d.y2 = dbl_wrap(y2);
       }
       out[pos] = d;
     }

@@ -1,0 +1,151 @@
+"""The drop-in boundary: exported symbols, struct layouts, error behaviour without a GPU, and (container only) the
+reference-header caller.  No compute calls need a GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_reference
+
+HEADER = os.path.join(ROOT, "include", "yf_network.h")
+PROBE = os.path.join(ROOT, "tests", "abi", "layout_probe.c")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    return re.findall(r"YF_API\s+[\w\s\*]+?\b(\w+)\s*\(", src)
+
+
+def test_library_exports_every_declared_symbol(yf):
+    lib = yf.load()
+    names = _declared_functions()
+    assert len(names) >= 21 and "ai_network_run" in names and "ai_platform_bind_network_params" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/yf_network.h but not exported"
+    binding = __import__("importlib").import_module("stm32h7-yolo_amd.binding")
+    assert sorted(binding.EXPORTS) == sorted(names)
+
+
+def _run_probe(tmp_path, own):
+    exe = str(tmp_path / ("probe_own" if own else "probe_ref"))
+    inc = ["-I" + os.path.join(ROOT, "include"), "-DYF_OWN_HEADER"] if own else ["-I/root/reference/stm32/Middlewares/ST/AI/Inc"]
+    subprocess.check_call(["gcc", "-std=gnu11", PROBE, "-o", exe] + inc)
+    return subprocess.check_output([exe]).decode()
+
+
+def test_struct_layout_matches_ctypes_binding(tmp_path, yf):
+    b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")
+    out = _run_probe(tmp_path, True)
+    lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
+    assert int(lines["ai_buffer"].split(":")[0]) == ctypes.sizeof(b.AiBuffer) == 32
+    assert [int(v) for v in lines["ai_buffer"].split(":")[1].split()] == [
+        b.AiBuffer.format.offset, b.AiBuffer.n_batches.offset, b.AiBuffer.height.offset, b.AiBuffer.width.offset,
+        b.AiBuffer.channels.offset, b.AiBuffer.data.offset, b.AiBuffer.meta_info.offset]
+    assert int(lines["ai_network_params"].split(":")[0]) == ctypes.sizeof(b.AiNetworkParams) == 64
+    assert int(lines["ai_network_report"].split(":")[0]) == ctypes.sizeof(b.AiNetworkReport) == 168
+    assert int(lines["ai_buffer_array"].split(":")[0]) == ctypes.sizeof(b.AiBufferArray) == 16
+    assert "S8=0x%08x U8=0x%08x" % (b.AI_BUFFER_FORMAT_S8, b.AI_BUFFER_FORMAT_U8) in out
+
+
+@pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
+def test_own_header_is_abi_identical_to_reference_header(tmp_path):
+    """sizeof / offsetof / enum values of include/yf_network.h vs the reference's ai_platform.h
+    (Middlewares/ST/AI/Inc/ai_platform.h:392-413,467-470,517-536,546-586,606-655)."""
+    assert _run_probe(tmp_path, True) == _run_probe(tmp_path, False)
+
+
+@pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
+def test_reference_network_data_links_against_library():
+    """The reference's unmodified network_data.c + a caller on the reference's headers link against the library
+    (ai_platform_bind_network_params is the only runtime symbol that file needs, network_data.c:431)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_ref_caller")
+    undefined = subprocess.check_output(["nm", "-u", exe]).decode()
+    needed = sorted(set(re.findall(r"U (ai_\w+)", undefined)))
+    assert needed == ["ai_network_create", "ai_network_destroy", "ai_network_get_error", "ai_network_get_report",
+                      "ai_network_init", "ai_network_run", "ai_platform_bind_network_params"]
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the behaviour WITHOUT a GPU")
+def test_product_fails_loudly_without_gpu(yf):
+    """No CPU fallback: init reports AI_ERROR_INIT_FAILED and run refuses (reference error convention,
+    network.h:120-132: first error latched, reading resets it)."""
+    net = yf.Network()
+    with pytest.raises(yf.NetworkError) as ei:
+        net.init()
+    assert ei.value.type == 0x30 and "HIP" in ei.value.text
+    assert net.get_error() == (0, 0)                       # latch was reset by the read
+    with pytest.raises(yf.NetworkError) as ei:
+        net.run(np.zeros((1, 56, 56, 3), np.int8))
+    assert (ei.value.type, ei.value.code) == (0x11, 0x30)  # INVALID_STATE / MISSED_INIT
+    net.destroy()
+
+
+def test_handle_and_param_validation(yf):
+    lib = yf.load()
+    b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")
+    # create rejects a non-NULL config and a NULL handle pointer
+    h = ctypes.c_void_p()
+    cfg = b.make_buffer(b.AI_BUFFER_FORMAT_U8, 1, 1, 4)
+    assert lib.ai_network_create(ctypes.byref(h), ctypes.byref(cfg)).type == 0x33
+    assert lib.ai_network_create(None, None).type == 0x33
+    assert lib.ai_network_create(ctypes.byref(h), None).type == 0
+    # a foreign handle is refused everywhere
+    bogus = ctypes.c_void_p(0x1234)
+    assert lib.ai_network_get_error(bogus).type == 0x10
+    assert not lib.ai_network_init(bogus, None)
+    assert lib.ai_network_run(bogus, None, None) == 0
+    # init: NULL params, short weights, short activations
+    assert not lib.ai_network_init(h, None)
+    e = lib.ai_network_get_error(h)
+    assert (e.type, e.code) == (0x30, 0x11)
+    p = b.AiNetworkParams()
+    blob = (ctypes.c_uint8 * 100)()
+    p.params = b.make_buffer(b.AI_BUFFER_FORMAT_U8 | b.AI_BUFFER_FMT_FLAG_CONST, 1, 1, 100, 1, ctypes.addressof(blob))
+    assert not lib.ai_network_init(h, ctypes.byref(p))
+    e = lib.ai_network_get_error(h)
+    assert (e.type, e.code) == (0x30, 0x18)
+    p.params = b.make_buffer(b.AI_BUFFER_FORMAT_U8 | b.AI_BUFFER_FMT_FLAG_CONST, 1, 1, 11304, 1, lib.ai_network_data_weights_get())
+    act = (ctypes.c_uint8 * 64)()
+    p.activations = b.make_buffer(b.AI_BUFFER_FORMAT_U8, 1, 1, 64, 1, ctypes.addressof(act))
+    assert not lib.ai_network_init(h, ctypes.byref(p))
+    e = lib.ai_network_get_error(h)
+    assert (e.type, e.code) == (0x30, 0x13)
+    # first error is latched: two failures, the first one is reported, then the latch is clear
+    assert not lib.ai_network_init(h, None)
+    assert lib.ai_network_run(h, None, None) == 0
+    e = lib.ai_network_get_error(h)
+    assert (e.type, e.code) == (0x30, 0x11)
+    assert lib.ai_network_get_error(h).type == 0
+    # weights getters: MAGIC-framed pointer map and the ai_buffer_array form
+    m = ctypes.cast(lib.ai_network_data_weights_get(), ctypes.POINTER(ctypes.c_void_p))
+    assert m[0] == 0xA1FACADE and m[2] == 0xA1FACADE and m[1]
+    mp = b.AiNetworkParams()
+    assert lib.ai_network_data_params_get(h, ctypes.byref(mp))
+    assert mp.map_signature == 0xA1FACADE and mp.map_weights.size == 1 and mp.map_weights.buffer[0].channels == 11304
+    assert mp.map_weights.buffer[0].data == m[1]
+    # report works on a created (not yet initialised) network
+    r = b.AiNetworkReport()
+    assert lib.ai_network_get_report(h, ctypes.byref(r))
+    assert r.model_name == b"network" and r.n_macc == 1344320 and r.n_nodes == 31 and r.n_inputs == 1
+    assert (r.inputs[0].height, r.inputs[0].width, r.inputs[0].channels) == (56, 56, 3)
+    assert (r.outputs[0].height, r.outputs[0].width, r.outputs[0].channels) == (7, 7, 18)
+    assert lib.ai_network_destroy(h) is None
+    assert lib.ai_network_destroy(bogus) == 0x1234        # not destroyed: handle comes back
+
+
+def test_library_weight_blob_is_the_generated_one(yf):
+    lib = yf.load()
+    m = ctypes.cast(lib.ai_network_data_weights_get(), ctypes.POINTER(ctypes.c_void_p))
+    blob = bytes((ctypes.c_uint8 * 11304).from_address(m[1]))
+    src = open(os.path.join(ROOT, "stm32h7-yolo_amd", "csrc", "gen", "yf_weights_blob_gen.c")).read()
+    body = src[src.index("{") + 1: src.rindex("}")]
+    assert blob == bytes(int(v) for v in re.findall(r"\d+", body))

@@ -1,0 +1,293 @@
+"""Parity tests proper (run on a real MI355X with -m gpu): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs -- bit-exact (integer/byte work).  Full BASELINE sizes are additionally checked
+through size-independent properties (determinism, permutation equivariance, golden frames embedded in the batch)."""
+import ctypes
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+STAGES = [("T1", 2), ("T2", 4), ("T3", 5), ("T4", 7), ("Q21", 21), ("T6", 11), ("T7", 12), ("T8", 14), ("T9", 16),
+          ("T11", 18), ("T14", 22), ("T15", 24), ("Q45", 45), ("T17", 28), ("T18", 29), ("T19", 31), ("T20", 33),
+          ("T22", 35), ("T23", 37), ("T24", 39), ("T26", 41), ("T30", 46), ("T31", 48), ("T32", 50), ("T33", 52)]
+VARIANTS = [(1, 4), (2, 4), (4, 4), (2, 8), (4, 8)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def rnd(seed, n):
+    return np.random.default_rng(seed).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
+
+
+def test_native_library_is_loaded(network):
+    maps = open("/proc/self/maps").read()
+    assert "libyf_network.so" in maps
+    assert "yoloface56_fused" in network.kernel_name
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 257])
+def test_ai_network_run_host_path_equals_oracle(network, oracle, n):
+    """reference call: ai_network_run(network, &ai_input, &ai_output) with n_batches = n (yoloface.c:226-231)"""
+    network.configure(2, 4)
+    x = rnd(100 + n, n)
+    assert np.array_equal(network.run(x), oracle.run(x, threads=8))
+
+
+def test_golden_fixtures(network, golden):
+    heads = network.run(golden["inputs"])
+    assert np.array_equal(heads, golden["heads"])
+
+
+def test_edge_frames(network, oracle):
+    x = np.stack([np.full((56, 56, 3), v, np.int8) for v in (-128, -1, 0, 1, 127)])
+    x = np.concatenate([x, rnd(5, 3) // 64, (rnd(6, 2) | 0x7F).astype(np.int8)])   # low-contrast and saturated frames
+    assert np.array_equal(network.run(x), oracle.run(x))
+
+
+def test_every_fused_stage_equals_the_matching_tflite_op(network, oracle, torch_cuda):
+    """Observer-style dump (yf_network_run_device_dump) vs the oracle's per-op outputs: 25 fused stage tensors."""
+    torch = torch_cuda
+    from oracle.np_restatement import load_yfm
+    m = load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+    sizes = [int(np.prod(m["tensors"][o["out"]]["shape"][1:])) for o in m["ops"]]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    n = 5
+    x = rnd(42, n)
+    head_ref, dump_ref = oracle.run(x, dump=True)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+    d_dump = torch.zeros((n, network.dump_bytes()), dtype=torch.int8, device="cuda")
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), n, None, d_dump.data_ptr())
+    torch.cuda.synchronize()
+    dump = d_dump.cpu().numpy()
+    off = 0
+    for name, op in STAGES:
+        got = dump[:, off:off + sizes[op]]
+        ref = dump_ref[:, offs[op]:offs[op] + sizes[op]]
+        assert np.array_equal(got, ref), f"stage {name} (tflite op {op})"
+        off += sizes[op]
+    assert off == network.dump_bytes()
+    assert np.array_equal(d_out.cpu().numpy(), head_ref)
+
+
+@pytest.mark.parametrize("fw", VARIANTS)
+def test_kernel_variants_and_ragged_tails(network, oracle, torch_cuda, fw):
+    torch = torch_cuda
+    network.configure(*fw)
+    for n in (1, 7, 130):
+        x = rnd(7 * n + fw[0], n)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((n + 1, 7, 7, 18), 77, dtype=torch.int8, device="cuda")     # canary frame after the batch
+        network.run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:n], oracle.run(x, threads=8))
+        assert (got[n] == 77).all(), "wrote past the last frame"
+    network.configure(2, 4)
+
+
+def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
+    """BASELINE.json configs[1]: batch 4096 on one GPU; golden frames are embedded at the front of the batch
+    (SURVEY.md 8(d)); whole batch compared with the oracle, plus determinism and permutation equivariance."""
+    torch = torch_cuda
+    n = 4096
+    x = rnd(1, n)
+    x[:6] = golden["inputs"]
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
+    a = d_out.cpu().numpy()
+    assert np.array_equal(a[:6], golden["heads"])
+    assert np.array_equal(a, oracle.run(x, threads=16))
+    d_out.zero_()
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), a)                       # deterministic
+    perm = np.random.default_rng(2).permutation(n)
+    d_in2 = torch.from_numpy(x[perm]).cuda()
+    network.run_device(d_in2.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), a[perm])                # frames are independent
+
+
+def test_full_size_32768_properties(network, oracle, torch_cuda):
+    """BASELINE.json configs[2] size (32768 frames, here on one GPU): the batch is 8 shuffled copies of a 4096-frame
+    block, so every copy must reproduce the block's heads (checked against the oracle on the block)."""
+    torch = torch_cuda
+    block = rnd(2, 4096)
+    ref = oracle.run(block, threads=16)
+    rng = np.random.default_rng(3)
+    perms = [rng.permutation(4096) for _ in range(8)]
+    x = np.concatenate([block[p] for p in perms])
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((32768, 7, 7, 18), dtype=torch.int8, device="cuda")
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), 32768)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for k, p in enumerate(perms):
+        assert np.array_equal(got[k * 4096:(k + 1) * 4096], ref[p])
+
+
+def test_max_n_batches_65535_through_the_abi(network, oracle):
+    """ai_buffer.n_batches is 16 bit (ai_platform.h:519): the largest single ai_network_run call."""
+    lib = network.lib
+    b = importlib.import_module("stm32h7-yolo_amd.binding")
+    n = 65535
+    base = rnd(4, 256)
+    x = np.tile(base, (n // 256 + 1, 1, 1, 1))[:n]
+    out = np.empty((n, 7, 7, 18), np.int8)
+    bi = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, n, x.ctypes.data)
+    bo = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 7, 7, 18, n, out.ctypes.data)
+    assert lib.ai_network_run(network.handle, ctypes.byref(bi), ctypes.byref(bo)) == n
+    ref = oracle.run(base, threads=8)
+    assert np.array_equal(out[:256], ref)
+    assert np.array_equal(out[-255:], ref[:255])           # 65535 = 255 * 256 + 255
+    assert np.array_equal(out[256 * 100:256 * 101], ref)
+
+
+def test_run_argument_errors_are_latched(network):
+    """Error behaviour of the reference boundary: <= 0 return, first error readable once (network.h:120-132)."""
+    lib = network.lib
+    b = importlib.import_module("stm32h7-yolo_amd.binding")
+    x = np.zeros((2, 56, 56, 3), np.int8)
+    out = np.zeros((2, 7, 7, 18), np.int8)
+    good_in = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, 2, x.ctypes.data)
+    good_out = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 7, 7, 18, 2, out.ctypes.data)
+    cases = [
+        (b.make_buffer(b.AI_BUFFER_FORMAT_U8, 56, 56, 3, 2, x.ctypes.data), good_out, (0x12, 0x19)),
+        (b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 1, 2, x.ctypes.data), good_out, (0x12, 0x18)),
+        (b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, 0, x.ctypes.data), good_out, (0x12, 0x21)),
+        (b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, 2, None), good_out, (0x12, 0x17)),
+        (good_in, b.make_buffer(b.AI_BUFFER_FORMAT_S8, 7, 7, 18, 1, out.ctypes.data), (0x13, 0x21)),
+        (good_in, b.make_buffer(b.AI_BUFFER_FORMAT_S8, 7, 7, 17, 2, out.ctypes.data), (0x13, 0x18)),
+    ]
+    for bi, bo, want in cases:
+        assert lib.ai_network_run(network.handle, ctypes.byref(bi), ctypes.byref(bo)) == 0
+        e = lib.ai_network_get_error(network.handle)
+        assert (e.type, e.code) == want
+        assert lib.ai_network_get_error(network.handle).type == 0
+    assert lib.ai_network_run(network.handle, ctypes.byref(good_in), None) == 0
+    assert lib.ai_network_get_error(network.handle).type == 0x13
+    assert lib.ai_network_forward(network.handle, ctypes.byref(good_in)) == 2          # run without output
+    assert lib.ai_network_run(network.handle, ctypes.byref(good_in), ctypes.byref(good_out)) == 2
+
+
+def test_weights_come_from_the_callers_blob(yf, network, oracle):
+    """ai_network_init reads the blob it is handed (network.c:3108-3267 binds the caller's blob): perturbing one
+    weight byte of a caller-owned copy changes the output; the pristine copy reproduces the oracle."""
+    lib = network.lib
+    m = ctypes.cast(lib.ai_network_data_weights_get(), ctypes.POINTER(ctypes.c_void_p))
+    blob = np.frombuffer((ctypes.c_uint8 * 11304).from_address(m[1]), np.uint8).copy()
+    x = rnd(8, 4)
+    ref = oracle.run(x)
+    network.init(weights=blob)
+    assert np.array_equal(network.run(x), ref)
+    bad = blob.copy()
+    bad[10656 + 5] ^= 0x40            # one weight of the head conv (ST blob offset 10656, network.c:3259)
+    network.init(weights=bad)
+    assert not np.array_equal(network.run(x), ref)
+    network.init()
+    assert np.array_equal(network.run(x), ref)
+
+
+def _dets(buf, counts, cap):
+    out = []
+    for f in range(counts.shape[0]):
+        out.append([(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["q_conf"]), float(d["conf"]),
+                     int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in buf[f, :min(int(counts[f]), cap)]])
+    return out
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_box_decode_on_gpu_equals_oracle(yf, network, oracle, golden, torch_cuda, mode):
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    heads = rng.integers(-60, 40, (300, 7, 7, 18), dtype=np.int8)
+    heads[:6] = golden["heads"]
+    heads[6] = 127                                    # every candidate fires: 147 detections
+    heads[7] = -128
+    n, cap = heads.shape[0], 147
+    d_h = torch.from_numpy(heads).cuda()
+    d_d = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_c = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    ws, hs = (410 / 56.0, 362 / 56.0) if mode == 0 else (1.0, 1.0)
+    network.decode_device(d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap, mode, ws, hs)
+    torch.cuda.synchronize()
+    buf = d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap)
+    counts = d_c.cpu().numpy()
+    got = _dets(buf, counts, cap)
+    for f in range(n):
+        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f)
+        assert counts[f] == len(ref)
+        assert got[f] == [(d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9]) for d in ref], f"frame {f}"
+        assert all(int(d["frame"]) == f for d in buf[f, :counts[f]])
+    assert counts[6] == 147 and counts[7] == 0
+    # fixed capacity smaller than the true count: count is still the true count, records are the first `cap`
+    d_d2 = torch.zeros((n, 5, 28), dtype=torch.uint8, device="cuda")
+    network.decode_device(d_h.data_ptr(), n, d_d2.data_ptr(), d_c.data_ptr(), 5, mode, ws, hs)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_c.cpu().numpy(), counts)
+    buf2 = d_d2.cpu().numpy().view(yf.DET_DTYPE).reshape(n, 5)
+    assert _dets(buf2, counts, 5)[6] == got[6][:5]
+
+
+def test_frame_preparation_on_gpu_equals_oracle(network, oracle, torch_cuda):
+    """yoloface.c:26-93 (RGB565 112x112 -> int8 56x56x3), then the whole camera-format -> head pipeline."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    raw = rng.integers(0, 256, (9, 112 * 112 * 2), dtype=np.uint8)
+    raw[0] = 0
+    raw[1] = 255
+    d_raw = torch.from_numpy(raw).cuda()
+    d_x = torch.zeros((9, 56, 56, 3), dtype=torch.int8, device="cuda")
+    d_out = torch.zeros((9, 7, 7, 18), dtype=torch.int8, device="cuda")
+    network.prepare_rgb565_device(d_raw.data_ptr(), d_x.data_ptr(), 9)
+    network.run_device(d_x.data_ptr(), d_out.data_ptr(), 9)
+    torch.cuda.synchronize()
+    ref = np.stack([oracle.prepare_rgb565(r) for r in raw])
+    assert np.array_equal(d_x.cpu().numpy(), ref)
+    assert np.array_equal(d_out.cpu().numpy(), oracle.run(ref))
+
+
+def test_interpreter_mirror(oracle, golden, network):
+    """tflite_prediction.py:23-41 call sequence on the mirror class (shares the library's single network)."""
+    ip = importlib.import_module("stm32h7-yolo_amd.interpreter")
+    it = ip.Interpreter(model_path="yoloface_int8.tflite")
+    it.allocate_tensors()
+    i_d, o_d = it.get_input_details(), it.get_output_details()
+    assert tuple(i_d[0]["shape"]) == (1, 56, 56, 3) and i_d[0]["dtype"] == np.int8
+    it.set_tensor(i_d[0]["index"], golden["inputs"][5:6])
+    it.invoke()
+    out = it.get_tensor(o_d[0]["index"])
+    assert np.array_equal(out, golden["heads"][5:6])
+    boxes = ip.decode_boxes(out[0], 0.7, 1.0, 1.0)
+    want = golden["meta"]["frames"][5]["detections_py"]
+    assert [tuple(int(v) for v in b) for b in boxes] == [(d["x1"], d["y1"], d["x2"], d["y2"]) for d in want]
+    network.init()            # the mirror re-initialised the singleton; leave it ready for later tests
+
+
+def test_reference_header_caller_binary(golden, tmp_path):
+    """oracle/_ref/abi_ref_caller = reference network_data.c + a caller on the reference's headers, linked against
+    libyf_network.so in the build container (oracle/Makefile.ref).  Both initialisation forms."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_ref_caller")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/abi_ref_caller was not built (needs /root/reference at build time)")
+    fin = os.path.join(ROOT, "tests", "golden", "golden_inputs.bin")
+    for extra in ([], ["map"]):
+        fout = str(tmp_path / "heads.bin")
+        r = subprocess.run([exe, fin, fout, "6"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "OK 6" in r.stdout and "macc 1344320" in r.stdout
+        assert np.array_equal(np.fromfile(fout, np.int8).reshape(6, 7, 7, 18), golden["heads"])

@@ -1,0 +1,230 @@
+"""CPU tests of the product's host logic (stm32h7-yolo_amd/csrc/yf_host_prep.c): the device tables are checked
+against the oracle's independent fixed-point statement.  No GPU, no compute calls."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, "stm32h7-yolo_amd")
+N_DENSE, N_DW, N_ADD, N_LUT = 17, 7, 3, 19
+DENSE_OPS = [1, 5, 6, 12, 13, 17, 19, 23, 29, 30, 34, 36, 40, 42, 47, 51, 53]
+DENSE_LUT = [1, 0, 1, 0, 1, 0, 1, 1, 0, 1, 0, 1, 0, 1, 1, 1, 0]
+DW_OPS = [3, 10, 15, 27, 32, 38, 49]
+LEAKY_LUT_IDS = {2: 0, 4: 1, 7: 2, 11: 4, 14: 5, 16: 6, 20: 7, 24: 8, 28: 10, 31: 11, 33: 12, 37: 13, 39: 14, 48: 16, 50: 17, 52: 18}
+
+
+class Dense(ctypes.Structure):
+    _fields_ = [("w_off", ctypes.c_uint32), ("c_off", ctypes.c_uint32), ("cout", ctypes.c_uint16),
+                ("cout_pad4", ctypes.c_uint16), ("k", ctypes.c_uint16), ("krow", ctypes.c_uint16)]
+
+
+class Dw(ctypes.Structure):
+    _fields_ = [("g_off", ctypes.c_uint32), ("c", ctypes.c_uint16), ("ngroups", ctypes.c_uint16)]
+
+
+class Add(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("zp1", "zp2", "zpo", "m1", "s1", "m2", "s2", "mo", "so")]
+
+
+class Index(ctypes.Structure):
+    _fields_ = [("dense", Dense * N_DENSE), ("dw", Dw * N_DW), ("add", Add * N_ADD), ("lut_off", ctypes.c_uint32),
+                ("total_bytes", ctypes.c_uint32), ("in_zp", ctypes.c_int32), ("halo_zp", ctypes.c_int32 * N_DW)]
+
+
+@pytest.fixture(scope="module")
+def prep():
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "../lib/libyf_hostprep.so"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(PKG, "lib", "libyf_hostprep.so"))
+    lib.yf_prepare_tables.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Index)]
+    lib.yf_quantize_multiplier.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]
+    lib.yf_mbqm.restype = ctypes.c_int32
+    lib.yf_mbqm.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int]
+    blob = (ctypes.c_uint8 * 11304).in_dll(lib, "yf_weights_blob")
+    out, ix = ctypes.c_void_p(), Index()
+    rc = lib.yf_prepare_tables(blob, 11304, ctypes.byref(out), ctypes.byref(ix))
+    assert rc == 0
+    tab = bytes((ctypes.c_uint8 * ix.total_bytes).from_address(out.value))
+    return dict(lib=lib, blob=bytes(blob), ix=ix, tab=tab)
+
+
+@pytest.fixture(scope="module")
+def pack():
+    from oracle.np_restatement import load_yfm
+    return load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+
+
+def test_quantize_multiplier_agrees_with_oracle(prep, oracle):
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([10.0 ** rng.uniform(-12, 3, 4000), [0.0, 0.5, 1.0, 0.25, 1 - 2.0**-40, 2.0**-33, 3e-12]])
+    for v in vals:
+        a, b, c, d = ctypes.c_int32(), ctypes.c_int(), ctypes.c_int32(), ctypes.c_int()
+        prep["lib"].yf_quantize_multiplier(float(v), ctypes.byref(a), ctypes.byref(b))
+        oracle.lib.yfo_quantize_multiplier(float(v), ctypes.byref(c), ctypes.byref(d))
+        assert (a.value, b.value) == (c.value, d.value), v
+
+
+def test_mbqm_agrees_with_oracle(prep, oracle):
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.integers(-2**27, 2**27, 3000), [0, 1, -1, 2**30, -2**30]])
+    for x in xs:
+        m = int(rng.integers(1 << 30, (1 << 31) - 1))
+        sh = int(rng.integers(-20, 1))
+        assert prep["lib"].yf_mbqm(int(x), m, sh) == oracle.lib.yfo_mbqm(int(x), m, sh)
+
+
+def test_index_is_embedded_and_blocks_are_aligned(prep):
+    ix, tab = prep["ix"], prep["tab"]
+    assert tab[:ctypes.sizeof(Index)] == bytes(ix)
+    assert ctypes.sizeof(Index) <= 512
+    for d in ix.dense:
+        assert d.w_off % 16 == 0 and d.c_off % 16 == 0 and d.krow % 16 == 0 and d.cout_pad4 % 4 == 0
+    for d in ix.dw:
+        assert d.g_off % 16 == 0
+    assert ix.lut_off % 16 == 0 and ix.total_bytes >= ix.lut_off + N_LUT * 256 + 16
+    assert ix.in_zp == -128
+    assert list(ix.halo_zp) == [-108, -99, -96, -94, -107, -102, -114]    # zero points of tflite tensors 52,57,64,73,80,86,95
+
+
+def test_leaky_and_requant_luts_equal_oracle(prep, oracle, pack):
+    ix, tab = prep["ix"], prep["tab"]
+    lut = np.frombuffer(tab, np.int8, N_LUT * 256, ix.lut_off).reshape(N_LUT, 256)
+    for op, lid in LEAKY_LUT_IDS.items():
+        assert np.array_equal(lut[lid], oracle.leaky_lut(op)), f"LEAKY_RELU #{op}"
+    T = pack["tensors"]
+
+    def requant(t_in, t_out):
+        m, sh = ctypes.c_int32(), ctypes.c_int()
+        oracle.lib.yfo_quantize_multiplier(float(np.float32(T[t_in]["scale"][0])) / float(np.float32(T[t_out]["scale"][0])),
+                                           ctypes.byref(m), ctypes.byref(sh))
+        return np.array([np.clip(oracle.lib.yfo_mbqm(q - T[t_in]["zp"], m.value, sh.value) + T[t_out]["zp"], -128, 127)
+                         for q in range(-128, 128)], np.int8)
+    assert np.array_equal(lut[3], requant(58, 103))            # QUANTIZE #21
+    assert np.array_equal(lut[9], requant(74, 101))            # QUANTIZE #45
+    q44 = requant(92, 102)
+    l43 = oracle.leaky_lut(43)
+    assert np.array_equal(lut[15], q44[l43.astype(int) + 128])  # QUANTIZE #44 o LEAKY_RELU #43
+
+
+def _chan(tab, off, i):
+    return struct.unpack_from("<4i", tab, off + 16 * i)
+
+
+def _check_requant_identity(oracle, bias2, mult, kc, rs, zp_out, z_extra, rng):
+    """(s + kc + (s>>31)) >> rs == MBQM(acc, mult, -rs) + zp_out + z_extra on random and tie-prone accumulators."""
+    accs = np.concatenate([rng.integers(-2**21, 2**21, 200), [0, 1, -1, bias2, -bias2]])
+    # accumulators whose SRDHM lands exactly on a rounding tie of the second shift (both signs)
+    half = 1 << (rs - 1)
+    for k in (-3, -2, -1, 0, 1, 2):
+        target = k * (1 << rs) + half
+        a = int(round(target * 2.0**31 / mult))
+        accs = np.concatenate([accs, [a - 1, a, a + 1, -a - 1, -a, -a + 1]])
+    for acc in accs:
+        acc = int(acc)
+        s = oracle.lib.yfo_srdhm(acc, mult)
+        fused = (s + kc + (s >> 31)) >> rs
+        ref = oracle.lib.yfo_mbqm(acc, mult, -rs) + zp_out + z_extra
+        assert fused == ref, (acc, mult, rs)
+
+
+def test_dense_tables(prep, oracle, pack):
+    ix, tab, blob = prep["ix"], prep["tab"], prep["blob"]
+    T, ops = pack["tensors"], pack["ops"]
+    rng = np.random.default_rng(2)
+    for s, op in enumerate(DENSE_OPS):
+        o, d = ops[op], ix.dense[s]
+        t_in = o["ins"][0] if op not in (1,) else 0
+        wt, bt, to = T[o["ins"][1]], T[o["ins"][2]], T[o["out"]]
+        w = wt["data"].reshape(wt["shape"]).astype(np.int64)       # OHWI
+        cout = wt["shape"][0]
+        assert d.cout == cout and d.cout_pad4 == (cout + 3) // 4 * 4
+        zp_in = T[t_in]["zp"]
+        for ch in range(cout):
+            row = np.frombuffer(tab, np.int8, d.krow, d.w_off + ch * d.krow).astype(np.int64)
+            wf = w[ch].reshape(-1)
+            if op == 1:      # RGBX slots, two k-steps (yf_tables.h)
+                exp = np.zeros(64, np.int64)
+                for ky in range(3):
+                    for kx in range(3):
+                        pix = ky * 3 + kx
+                        base = pix * 4 if pix < 8 else 32
+                        exp[base:base + 3] = w[ch, ky, kx, :]
+                assert np.array_equal(row, exp)
+            elif op == 23:   # T14 channel order: pool [0,18) | conv [20,38)
+                exp = np.zeros(48, np.int64)
+                exp[:18] = wf[:18]
+                exp[20:38] = wf[18:]
+                assert np.array_equal(row, exp)
+            else:
+                assert np.array_equal(row[:wf.size], wf) and not row[wf.size:].any()
+            bias2, mult, kc, rs = _chan(tab, d.c_off, ch)
+            assert bias2 == int(bt["data"][ch]) - zp_in * int(wf.sum())
+            m, sh = ctypes.c_int32(), ctypes.c_int()
+            eff = float(np.float32(T[t_in]["scale"][0])) * float(np.float32(wt["scale"][ch])) / float(np.float32(to["scale"][0]))
+            oracle.lib.yfo_quantize_multiplier(eff, ctypes.byref(m), ctypes.byref(sh))
+            assert (mult, -rs) == (m.value, sh.value) and rs >= 1 and mult > (1 << 30)
+            z = 128 if DENSE_LUT[s] else 0
+            assert kc == (1 << (rs - 1)) + ((to["zp"] + z) << rs)
+            if ch % 5 == 0:
+                _check_requant_identity(oracle, bias2, mult, kc, rs, to["zp"], z, rng)
+
+
+def test_depthwise_tables(prep, oracle, pack):
+    ix, tab = prep["ix"], prep["tab"]
+    T, ops = pack["tensors"], pack["ops"]
+    rng = np.random.default_rng(3)
+    for s, op in enumerate(DW_OPS):
+        o, d = ops[op], ix.dw[s]
+        t_in = o["ins"][0]
+        if ops[op - 1]["op"] == 34:            # explicit PAD in front: quantisation comes from the PAD input
+            t_in = ops[op - 1]["ins"][0]
+        wt, bt, to = T[o["ins"][1]], T[o["ins"][2]], T[o["out"]]
+        w = wt["data"].reshape(wt["shape"]).astype(np.int64)       # 1HWC
+        c = wt["shape"][3]
+        assert d.c == c and d.ngroups == (c + 3) // 4
+        for g in range(d.ngroups):
+            base = d.g_off + g * (36 * 4 + 64)
+            wd = np.frombuffer(tab, "<u4", 36, base).reshape(9, 4)
+            for j in range(4):
+                ch = g * 4 + j
+                if ch >= c:
+                    assert not wd[:, j].any()
+                    continue
+                taps = w[0].reshape(9, c)[:, ch]
+                assert np.array_equal(wd[:, j], (taps & 255).astype(np.uint32) << (8 * j))
+                bias2, mult, kc, rs = _chan(tab, base + 144, j)
+                assert bias2 == int(bt["data"][ch]) - T[t_in]["zp"] * int(taps.sum())
+                m, sh = ctypes.c_int32(), ctypes.c_int()
+                eff = float(np.float32(T[t_in]["scale"][0])) * float(np.float32(wt["scale"][ch])) / float(np.float32(to["scale"][0]))
+                oracle.lib.yfo_quantize_multiplier(eff, ctypes.byref(m), ctypes.byref(sh))
+                assert (mult, -rs) == (m.value, sh.value) and rs >= 1
+                assert kc == (1 << (rs - 1)) + ((to["zp"] + 128) << rs)
+                if ch % 7 == 0:
+                    _check_requant_identity(oracle, bias2, mult, kc, rs, to["zp"], 128, rng)
+
+
+def test_add_tables(prep, oracle, pack):
+    T, ops = pack["tensors"], pack["ops"]
+    for s, op in enumerate((18, 35, 41)):
+        a, o = prep["ix"].add[s], ops[op]
+        t1, t2, to = T[o["ins"][0]], T[o["ins"][1]], T[o["out"]]
+        assert (a.zp1, a.zp2, a.zpo) == (t1["zp"], t2["zp"], to["zp"])
+        s1, s2, so = np.float32(t1["scale"][0]), np.float32(t2["scale"][0]), np.float32(to["scale"][0])
+        twice = float(np.float32(2) * max(s1, s2))
+        for real, (mm, ss) in ((float(s1) / twice, (a.m1, a.s1)), (float(s2) / twice, (a.m2, a.s2)),
+                               (twice / float(np.float32(1 << 20) * so), (a.mo, a.so))):
+            m, sh = ctypes.c_int32(), ctypes.c_int()
+            oracle.lib.yfo_quantize_multiplier(real, ctypes.byref(m), ctypes.byref(sh))
+            assert (mm, ss) == (m.value, sh.value) and ss <= 0
+
+
+def test_prepare_rejects_bad_arguments(prep):
+    lib = prep["lib"]
+    out, ix = ctypes.c_void_p(), Index()
+    small = (ctypes.c_uint8 * 100)()
+    assert lib.yf_prepare_tables(small, 100, ctypes.byref(out), ctypes.byref(ix)) == 1
+    assert lib.yf_prepare_tables(None, 11304, ctypes.byref(out), ctypes.byref(ix)) == 1
