@@ -195,6 +195,10 @@ YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rg
  * *ms_per_launch receives the average.  Synchronises the stream. */
 YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_out, long n, int iters, void* stream,
                                    float* ms_per_launch);
+/* Debug: the stage-dump build of the kernel, left after `stop_stage` fused stages (1 = input staging ... 25 = conv2d_51;
+ * <= 0 or > 25 = whole network): the differences between successive stops give a per-stage time profile. */
+YF_API long yf_network_time_stages(ai_handle network, const void* d_in, void* d_out, long n, int iters, int stop_stage,
+                                   void* stream, float* ms_per_launch);
 /* Text of the last HIP/runtime failure (empty string if none). */
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);

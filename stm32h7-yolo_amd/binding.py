@@ -83,7 +83,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes",
            "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_last_error_text", "yf_network_kernel_name"]
+           "yf_network_time_stages", "yf_network_last_error_text", "yf_network_kernel_name"]
 
 
 def build(force=False):
@@ -142,6 +142,8 @@ def load():
     lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
     lib.yf_network_time_device.restype = cl
     lib.yf_network_time_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.yf_network_time_stages.restype = cl
+    lib.yf_network_time_stages.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.yf_network_last_error_text.restype = ctypes.c_char_p
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
@@ -231,6 +233,12 @@ class Network:
         ms = ctypes.c_float()
         if self.lib.yf_network_time_device(self.handle, d_in, d_out, n, iters, stream, ctypes.byref(ms)) != n:
             self._raise("yf_network_time_device")
+        return ms.value
+
+    def time_stages(self, d_in, d_out, n, iters, stop_stage, stream=None):
+        ms = ctypes.c_float()
+        if self.lib.yf_network_time_stages(self.handle, d_in, d_out, n, iters, stop_stage, stream, ctypes.byref(ms)) != n:
+            self._raise("yf_network_time_stages")
         return ms.value
 
     def configure(self, frames_per_wg, waves_per_wg):

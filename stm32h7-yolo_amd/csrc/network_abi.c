@@ -297,6 +297,12 @@ YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_
   return finish(c, yf_engine_time_device(c->engine, d_in, d_out, n, iters, stream, ms_per_launch), n);
 }
 
+YF_API long yf_network_time_stages(ai_handle network, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_time_stages(c->engine, d_in, d_out, n, iters, stop_stage, stream, ms_per_launch), n);
+}
+
 YF_API const char* yf_network_last_error_text(ai_handle network) {
   yf_context* c = acquire(network);
   return c ? c->err_text : "invalid handle";

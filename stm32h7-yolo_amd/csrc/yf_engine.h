@@ -24,6 +24,8 @@ int  yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_d
 /* host batch: H2D, run, D2H through engine-owned staging buffers; synchronous */
 int  yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n);
 int  yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch);
+/* debug kernel (stage dump build) stopped after `stop_stage` fused stages: per-stage timing */
+int  yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch);
 int  yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                              void* d_dets, void* d_counts, int cap, void* stream);
 int  yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream);

@@ -195,12 +195,12 @@ const char* yf_engine_error(const yf_engine* e) { return e ? e->err.c_str() : "n
 const char* yf_engine_kernel_name(const yf_engine* e) { return e && e->var ? e->var->name : ""; }
 long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
 
-static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s) {
+static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s, int stop_stage = -1) {
   if (n <= 0) return YF_ENG_OK;
   if (((uintptr_t)d_in & 3) != 0) { e->err = "input must be 4-byte aligned"; return YF_ENG_ERR_ARG; }
   if (((uintptr_t)d_out & 1) != 0) { e->err = "output must be 2-byte aligned"; return YF_ENG_ERR_ARG; }
   yf::NetParams prm;
-  prm.in = (const int8_t*)d_in; prm.out = (int8_t*)d_out; prm.n = n; prm.tab = e->d_tab; prm.dump = (int8_t*)d_dump;
+  prm.in = (const int8_t*)d_in; prm.out = (int8_t*)d_out; prm.n = n; prm.tab = e->d_tab; prm.dump = (int8_t*)d_dump; prm.stop_stage = stop_stage;
   const long groups = (n + v->f - 1) / v->f;
   const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
   long grid = (long)e->cus * per_cu;
@@ -242,6 +242,20 @@ int yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, i
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(e, hipEventRecord(e->ev0, s));
   for (int i = 0; i < iters; ++i) { const int rc = launch(e, e->var, d_in, d_out, nullptr, n, s); if (rc) return rc; }
+  HIPCHK(e, hipEventRecord(e->ev1, s));
+  HIPCHK(e, hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *ms_per_launch = ms / iters;
+  return YF_ENG_OK;
+}
+
+int yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch) {
+  if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(e, hipEventRecord(e->ev0, s));
+  for (int i = 0; i < iters; ++i) { const int rc = launch(e, e->var_dump, d_in, d_out, nullptr, n, s, stop_stage); if (rc) return rc; }
   HIPCHK(e, hipEventRecord(e->ev1, s));
   HIPCHK(e, hipEventSynchronize(e->ev1));
   float ms = 0.f;

@@ -441,6 +441,7 @@ struct NetParams {
   long n;
   const uint8_t* tab;     // device table blob (yf_host_prep.c)
   int8_t* dump;           // optional per-stage dump, [n][DumpOffsets::TOTAL]
+  int stop_stage;         // debug kernel only: leave the group after this many stages (stage timing); <0 = run all
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
@@ -470,70 +471,98 @@ __global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm)
   constexpr long DS = DumpOffsets::TOTAL;
 #define YF_SYNC() __syncthreads()
 #define YF_DUMP(BUF, C, OFF, ...) \
-  if constexpr (DUMP) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); }
+  if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
+  int stage_no = 0;
+#define YF_STAGE_END() if constexpr (DUMP) { if (++stage_no == prm.stop_stage) continue; }
 
   for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long first = grp * F;
     YF_SYNC();                                                         // previous group's arena is dead
+    stage_no = 0;
     stage_input<F, NT>(frames, prm.in, first, prm.n, ix.in_zp, tid);
     fill_halo<B_T1, true, F, NT>(frames, ix.halo_zp[YF_W_DW3], tid);
     YF_SYNC();
+    YF_STAGE_END()
     conv1_stage<F, NW>(frames, luts, tab, ix.dense[YF_D_CONV1], wave, lane);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
+    YF_STAGE_END()
     dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
+    YF_STAGE_END()
     dense_stage<F, NW, 4, B_T2, B_T3, 0, 4, 16, EPI_RAW, 0, B_T3>(frames, luts, out_all, tab, ix.dense[YF_D_C5], no_add, wave, lane);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
+    YF_STAGE_END()
     fill_halo<B_T4, false, F, NT>(frames, ix.halo_zp[YF_W_DW10], tid);
     dense_stage<F, NW, 4, B_T3, B_T4, 0, 18, 16, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, luts, out_all, tab, ix.dense[YF_D_C6], no_add, wave, lane);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
+    YF_STAGE_END()
     pool8_h<F, NT>(frames, tid);                                                                   // pool_8 (h)
     YF_SYNC();
+    YF_STAGE_END()
     pool8_v<F, NT>(frames, luts, tid);                                                             // pool_8 (v) + QUANTIZE#21
     dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
+    YF_STAGE_END()
     dense_stage<F, NW, 2, B_T6, B_T7, 0, 6, 32, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C12], no_add, wave, lane);  // conv2d_12
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
+    YF_STAGE_END()
     fill_halo<B_T8, true, F, NT>(frames, ix.halo_zp[YF_W_DW15], tid);
     dense_stage<F, NW, 4, B_T7, B_T8, 0, 36, 16, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, luts, out_all, tab, ix.dense[YF_D_C13], no_add, wave, lane);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
+    YF_STAGE_END()
     dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
+    YF_STAGE_END()
     dense_stage<F, NW, 1, B_T9, B_T11, 0, 6, 48, EPI_ADD, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C17], addctx(YF_A_ADD18), wave, lane);  // conv2d_17 + eltwise_18
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
+    YF_STAGE_END()
     dense_stage<F, NW, 4, B_T11, B_T14, YF_T14_CONV_BASE, 18, 16, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, luts, out_all, tab, ix.dense[YF_D_C19], no_add, wave, lane);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
+    YF_STAGE_END()
     fill_halo<B_T15, false, F, NT>(frames, ix.halo_zp[YF_W_DW27], tid);
     dense_stage<F, NW, 1, B_T14, B_T15, 0, 24, 48, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, ix.dense[YF_D_C23], no_add, wave, lane);  // conv2d_23
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
+    YF_STAGE_END()
     pool25<F, NT>(frames, luts, tid);                                                              // pool_25 + QUANTIZE#45
     dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane);   // conv2d_27
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
+    YF_STAGE_END()
     dense_stage<F, NW, 2, B_T17, B_T18, 0, 8, 32, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C29], no_add, wave, lane);  // conv2d_29
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
+    YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW32], tid);
     dense_stage<F, NW, 4, B_T18, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C30], no_add, wave, lane);  // conv2d_30
     YF_SYNC(); YF_DUMP(B_T19, 40, T19)
+    YF_STAGE_END()
     dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane);   // conv2d_32
     YF_SYNC(); YF_DUMP(B_T20, 40, T20)
+    YF_STAGE_END()
     dense_stage<F, NW, 1, B_T20, B_T22, 0, 8, 48, EPI_ADD, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C34], addctx(YF_A_ADD35), wave, lane);  // conv2d_34 + eltwise_35
     YF_SYNC(); YF_DUMP(B_T22, 8, T22)
+    YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW38], tid);
     dense_stage<F, NW, 4, B_T22, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C36], no_add, wave, lane);  // conv2d_36
     YF_SYNC(); YF_DUMP(B_T19, 40, T23)
+    YF_STAGE_END()
     dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane);   // conv2d_38
     YF_SYNC(); YF_DUMP(B_T20, 40, T24)
+    YF_STAGE_END()
     dense_stage<F, NW, 1, B_T20, B_T26, 0, 8, 48, EPI_ADD, 0, B_T22>(frames, luts, out_all, tab, ix.dense[YF_D_C40], addctx(YF_A_ADD41), wave, lane);  // conv2d_40 + eltwise_41
     YF_SYNC(); YF_DUMP(B_T26, 8, T26)
+    YF_STAGE_END()
     dense_stage<F, NW, 4, B_T26, B_T30, 24, 24, 16, EPI_LUT, YF_L_L43Q44, B_T30>(frames, luts, out_all, tab, ix.dense[YF_D_C42], no_add, wave, lane);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP(B_T30, 48, T30)
+    YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW49], tid);
     dense_stage<F, NW, 1, B_T30, B_T19, 0, 40, 48, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C47], no_add, wave, lane);  // conv2d_47
     YF_SYNC(); YF_DUMP(B_T19, 40, T31)
+    YF_STAGE_END()
     dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane);   // conv2d_49
     YF_SYNC(); YF_DUMP(B_T20, 40, T32)
+    YF_STAGE_END()
     dense_stage<F, NW, 1, B_T20, B_T33, 0, 32, 48, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C51], no_add, wave, lane);  // conv2d_51
     YF_SYNC(); YF_DUMP(B_T33, 32, T33)
+    YF_STAGE_END()
     dense_stage<F, NW, 1, B_T33, B_T33, 0, 18, 32, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C53], no_add, wave, lane);  // conv2d_53 (head)
     YF_SYNC();
     {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
@@ -545,6 +574,7 @@ __global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm)
     }
   }
 #undef YF_DUMP
+#undef YF_STAGE_END
 #undef YF_SYNC
 }
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Collapse the rocprofv3 CSVs of tools/profile_pmc.sh into one JSON summary for the fused kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    out = sys.argv[1]
+    res = {"kernel": None, "counters": {}, "dispatches": {}}
+    for f in glob.glob(os.path.join(out, "trace", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            if "yoloface" in r["Name"]:
+                res["kernel"] = r["Name"]
+                res["trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+            acc, cnt = {}, {}
+            for r in csv.DictReader(open(f)):
+                if "yoloface" not in r.get("Kernel_Name", ""):
+                    continue
+                k = r["Counter_Name"]
+                acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+                cnt[k] = cnt.get(k, 0) + 1
+                for key in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size"):
+                    if key in r:
+                        res["dispatches"][key] = r[key]
+            for k in acc:
+                res["counters"][k] = {"per_launch": acc[k] / cnt[k], "launches": cnt[k]}
+    c = res["counters"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch_kb, write_kb = c["FETCH_SIZE"]["per_launch"], c["WRITE_SIZE"]["per_launch"]
+        res["hbm"] = {"fetch_bytes_raw": fetch_kb * 1024, "write_bytes": write_kb * 1024,
+                      "note": "FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x "
+                              "(MI355X_MICROARCH.md, HBM) -- see profiles/README.md for the calibration used"}
+    json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
