@@ -105,13 +105,15 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 }
 
 typedef void (*fused_fn)(const yf::NetParams);
-struct Variant { int f, nw; bool dump; fused_fn fn; size_t lds; const char* name; };
+struct Variant { int f, nw; bool dump; bool dwm; fused_fn fn; size_t lds; const char* name; };
 
-#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW>(), \
-                                  "yoloface56_fused<F=" #F ",NW=" #NW ">" }
+#define YF_VARIANT(F, NW, DUMP, DWM) { F, NW, DUMP, DWM, (fused_fn)yf::yoloface56_fused<F, NW, DUMP, DWM>, yf::lds_bytes<F, NW>(), \
+                                  "yoloface56_fused<F=" #F ",NW=" #NW ",DW=" #DWM ">" }
+// DW=true: depthwise on the matrix pipe (one-hot tap packing); DW=false: v_dot4 path (kept for A/B measurements)
 const Variant k_variants[] = {
-  YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
-  YF_VARIANT(2, 4, true),
+  YF_VARIANT(1, 4, false, true), YF_VARIANT(2, 4, false, true), YF_VARIANT(4, 4, false, true), YF_VARIANT(2, 8, false, true), YF_VARIANT(4, 8, false, true),
+  YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
+  YF_VARIANT(2, 4, true, true), YF_VARIANT(2, 8, true, true),
 };
 
 }  // namespace
@@ -132,8 +134,8 @@ struct yf_engine {
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
-static const Variant* find_variant(int f, int nw, bool dump) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool dwm = true) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.dwm == dwm) return &v;
   return nullptr;
 }
 
@@ -164,8 +166,8 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
-  e->var = find_variant(2, 4, false);
-  e->var_dump = find_variant(2, 4, true);
+  e->var = find_variant(2, 8, false);
+  e->var_dump = find_variant(2, 8, true);
   *out = e;
   return YF_ENG_OK;
 }
@@ -184,10 +186,14 @@ void yf_engine_destroy(yf_engine* e) {
 
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
+  /* frames_per_wg + 100 selects the v_dot4 depthwise build of the same shape (A/B measurements) */
+  const bool dot4 = frames_per_wg >= 100;
+  if (dot4) frames_per_wg -= 100;
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
-  const Variant* v = find_variant(f, nw, false);
+  const Variant* v = find_variant(f, nw, false, !dot4);
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
+  if (const Variant* dv = find_variant(f, nw, true)) e->var_dump = dv;     /* debug build of the same shape, if compiled */
   return YF_ENG_OK;
 }
 

@@ -117,9 +117,9 @@ static size_t blob_alloc(blob_t* b, size_t n) {
 /* stage descriptors: tflite conv op, whether its output indexes a LUT (z_extra) ------------------------------ */
 typedef struct { int id; int tfl_op; int lut; } dense_plan;
 static const dense_plan k_dense[YF_N_DENSE] = {
-  {YF_D_CONV1, 1, 1}, {YF_D_C5, 5, 0}, {YF_D_C6, 6, 1}, {YF_D_C12, 12, 0}, {YF_D_C13, 13, 1}, {YF_D_C17, 17, 0},
-  {YF_D_C19, 19, 1}, {YF_D_C23, 23, 1}, {YF_D_C29, 29, 0}, {YF_D_C30, 30, 1}, {YF_D_C34, 34, 0}, {YF_D_C36, 36, 1},
-  {YF_D_C40, 40, 0}, {YF_D_C42, 42, 1}, {YF_D_C47, 47, 1}, {YF_D_C51, 51, 1}, {YF_D_C53, 53, 0},
+  {YF_D_CONV1, 1, 1}, {YF_D_C5, 5, 0}, {YF_D_C6, 6, 1}, {YF_D_C12, 12, 0}, {YF_D_C13, 13, 1}, {YF_D_C17, 17, 1},
+  {YF_D_C19, 19, 1}, {YF_D_C23, 23, 1}, {YF_D_C29, 29, 0}, {YF_D_C30, 30, 1}, {YF_D_C34, 34, 1}, {YF_D_C36, 36, 1},
+  {YF_D_C40, 40, 1}, {YF_D_C42, 42, 1}, {YF_D_C47, 47, 1}, {YF_D_C51, 51, 1}, {YF_D_C53, 53, 0},
 };
 static const int k_dw_ops[YF_N_DW] = {3, 10, 15, 27, 32, 38, 49};
 
@@ -216,14 +216,24 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     yf_quantize_multiplier((double)s1 / twice_max, &a->m1, &sh); a->s1 = sh;
     yf_quantize_multiplier((double)s2 / twice_max, &a->m2, &sh); a->s2 = sh;
     yf_quantize_multiplier(twice_max / (double)((float)(1 << 20) * so), &a->mo, &sh); a->so = sh;
-    if (a->s1 > 0 || a->s2 > 0 || a->so > 0) rc = YF_PREP_ERR_SHIFT_RANGE;      /* ...SmallerThanOneExp */
+    if (a->s1 > 0 || a->s2 > 0 || a->so > -1 || a->so < -30 || a->mo <= (1 << 30)) rc = YF_PREP_ERR_SHIFT_RANGE;
     a->zp1 = t_zp(add_t[s][0]); a->zp2 = t_zp(add_t[s][1]); a->zpo = t_zp(add_t[s][2]);
+    a->rso = -a->so;
+    a->kco = ((int32_t)1 << (a->rso - 1)) + (a->zpo << a->rso);
   }
 
   /* ---------------- LUTs ---------------- */
   if (!rc) {
-    ix->lut_off = (uint32_t)blob_alloc(&b, (size_t)YF_N_LUT * 256);
+    ix->lut_off = (uint32_t)blob_alloc(&b, (size_t)YF_N_LUT * 256 + YF_ADDLUT_BYTES);
     uint8_t* L = b.p + ix->lut_off;
+    int32_t* AL = (int32_t*)(L + YF_N_LUT * 256);            /* [add][A|B][256] */
+    for (int s = 0; s < YF_N_ADD; ++s) {
+      const yf_add* a = &ix->add[s];
+      for (int q = -128; q < 128; ++q) {
+        AL[(s * 2 + 0) * 256 + q + 128] = yf_mbqm((q - a->zp1) * (1 << 20), a->m1, a->s1);
+        AL[(s * 2 + 1) * 256 + q + 128] = yf_mbqm((q - a->zp2) * (1 << 20), a->m2, a->s2);
+      }
+    }
     static const int leaky[][3] = {       /* lut id, tensor in, tensor out (tflite LEAKY_RELU ops) */
       {YF_L_LEAKY2, 51, 52}, {YF_L_LEAKY4, 53, 54}, {YF_L_LEAKY7, 56, 57}, {YF_L_LEAKY11, 60, 61},
       {YF_L_LEAKY14, 63, 64}, {YF_L_LEAKY16, 65, 66}, {YF_L_LEAKY20, 69, 70}, {YF_L_LEAKY24, 72, 73},

@@ -27,7 +27,7 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------ LDS plan
 // Per-frame arena (bytes).  Buffers alias by lifetime; see DESIGN.md "LDS plan" for the liveness table.
 constexpr int FRAME_BYTES = 34176;
-constexpr int LUT_BYTES = YF_N_LUT * 256;
+constexpr int LUT_BYTES = YF_N_LUT * 256 + YF_ADDLUT_BYTES;    // byte LUTs, then the int32 add tables
 constexpr int OUT_FRAME_BYTES = 882;
 
 // Buf: OFF byte offset in the frame arena, logical W x H, S bytes per pixel, RS pixels per row (incl. halo),
@@ -109,6 +109,12 @@ struct ByteMax {
 };
 
 __device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret_cast<const uint32_t*>(p); }
+// wave-uniform table reads: the constant address space makes the compiler use scalar loads (SGPR results)
+typedef const __attribute__((address_space(4))) v4i* cv4i_ptr;
+typedef const __attribute__((address_space(4))) uint32_t* cu32_ptr;
+struct I4 { int x, y, z, w; };
+__device__ __forceinline__ I4 uniform_int4(const void* p) { const v4i v = *(cv4i_ptr)(uintptr_t)p; return I4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_ptr)(uintptr_t)p; }
 
 // ------------------------------------------------------------------------------------------------ halo fill
 // RING: 1-pixel border all round (SAME 3x3 stride 1); otherwise top row + left column (explicit PAD, stride 2)
@@ -160,7 +166,7 @@ __device__ __forceinline__ void stage_input(char* frames, const int8_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue store
-struct AddCtx { int zp1, zp2, zpo, m1, s1, m2, s2, mo, so; };
+struct AddCtx { int mo, kco, rso; };
 
 template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
 __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
@@ -174,16 +180,17 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, cons
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
         pack4(clampi(y[0], -128, 127), clampi(y[1], -128, 127), clampi(y[2], -128, 127), clampi(y[3], -128, 127));
   } else if constexpr (EPI == EPI_ADD) {
-    // tflite ADD: in1 = stored tensor (ADDB), in2 = this conv's output
-    const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq);
+    // tflite ADD (LUT_ID = add index): in1 = stored tensor (ADDB) -> table A, in2 = this conv's output -> table B,
+    // then one fused requantisation of the sum.
+    const int* la = reinterpret_cast<const int*>(luts + YF_N_LUT * 256) + LUT_ID * 512;
+    const int* lb = la + 256;
+    const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq) ^ 0x80808080u;
     int r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int q1 = (int)(int8_t)((o >> (8 * j)) & 255);
-      const int q2 = clampi(y[j], -128, 127);
-      const int a = mbqm_le0((q1 - ad.zp1) * (1 << 20), ad.m1, ad.s1);
-      const int b = mbqm_le0((q2 - ad.zp2) * (1 << 20), ad.m2, ad.s2);
-      r[j] = clampi(mbqm_le0(a + b, ad.mo, ad.so) + ad.zpo, -128, 127);
+      const int sa = la[(o >> (8 * j)) & 255];
+      const int sb = lb[clampi(y[j], 0, 255)];
+      r[j] = clampi(requant(sa + sb, ad.mo, ad.kco, ad.rso), -128, 127);
     }
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = pack4(r[0], r[1], r[2], r[3]);
   } else {  // EPI_HEAD: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
@@ -259,6 +266,76 @@ __device__ __forceinline__ void dense_stage(char* frames, const uint8_t* luts, c
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
       epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, chq, y, ad);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dense 1x1, BD = 4
+// The skinny-K layers (K <= 16: conv2d_5/6/13/19/30/36/42).  64 pixels per MFMA, 4 output channels per tile.
+// A job = one 64-pixel m-tile x TPJ consecutive 4-channel tiles: pixel index arithmetic, the B fragment and the
+// output address are computed once per job and shared by its tiles; with BD = 4 every lane of the wave uses the SAME
+// four channels of a tile, so the requantisation constants are wave-uniform scalar loads instead of VGPRs.
+template <int F, int NW, int TPJ, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID>
+__device__ __forceinline__ void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+                                             const yf_dense d, int wave, int lane) {
+  constexpr int NTL = (COUT + 3) / 4;
+  constexpr int NCH = (NTL + TPJ - 1) / TPJ;                // channel-tile chunks
+  constexpr int P = IN::P, TOT = F * P;
+  constexpr int MT = (TOT + 63) / 64;
+  constexpr int JOBS = NCH * MT;
+  constexpr int JPW = (JOBS + NW - 1) / NW;
+  constexpr int RW = IN::S >= 16 ? 16 : IN::S;
+  static_assert(OUT::P == P, "1x1 conv keeps the grid");
+  static_assert(EPI == EPI_LUT || EPI == EPI_RAW, "epilogue kind");
+  const int g = lane >> 4, c = lane & 15;
+  const int j0 = wave * JPW, j1 = min(j0 + JPW, JOBS);
+  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
+  const uint8_t* lut = luts + LUT_ID * 256;
+  int cur_chunk = -1;
+  v4i a[TPJ];
+  for (int j = j0; j < j1; ++j) {
+    const int chunk = j / MT, mt = j - chunk * MT;
+    if (chunk != cur_chunk) {
+      cur_chunk = chunk;
+#pragma unroll
+      for (int t = 0; t < TPJ; ++t) {
+        const int nt = chunk * TPJ + t;
+        a[t] = v4i{0, 0, 0, 0};
+        if ((c >> 2) == g && nt < NTL) a[t] = *reinterpret_cast<const v4i*>(tab + d.w_off + (nt * 4 + (c & 3)) * 16);
+      }
+    }
+    const int q = mt * 64 + lane;                             // pixel set g, column c
+    const int qc = min(q, TOT - 1);
+    const int f = qc / P, p = qc - f * P;
+    char* fbase = frames + f * FRAME_BYTES;
+    v4i b = {0, 0, 0, 0};
+    {
+      const char* src = fbase + IN::at_p(p);
+      if constexpr (RW == 16) b = *reinterpret_cast<const v4i*>(src);
+      else if constexpr (RW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(src); b[0] = t2.x; b[1] = t2.y; }
+      else b[0] = *reinterpret_cast<const int*>(src);
+    }
+    char* dst = fbase + OUT::at_p(p) + OUT_CH0;
+#pragma unroll
+    for (int t = 0; t < TPJ; ++t) {
+      const int nt = chunk * TPJ + t;
+      if (nt < NTL) {                                         // uniform
+        const I4 k0 = uniform_int4(cp + nt * 4), k1 = uniform_int4(cp + nt * 4 + 1), k2 = uniform_int4(cp + nt * 4 + 2),
+                 k3 = uniform_int4(cp + nt * 4 + 3);
+        v4i acc = {k0.x, k1.x, k2.x, k3.x};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t], b, acc, 0, 0, 0);
+        if (q < TOT) {
+          const int y0 = requant(acc[0], k0.y, k0.z, k0.w), y1 = requant(acc[1], k1.y, k1.z, k1.w),
+                    y2 = requant(acc[2], k2.y, k2.z, k2.w), y3 = requant(acc[3], k3.y, k3.z, k3.w);
+          uint32_t v;
+          if constexpr (EPI == EPI_LUT)
+            v = (uint32_t)lut[clampi(y0, 0, 255)] | ((uint32_t)lut[clampi(y1, 0, 255)] << 8) |
+                ((uint32_t)lut[clampi(y2, 0, 255)] << 16) | ((uint32_t)lut[clampi(y3, 0, 255)] << 24);
+          else
+            v = pack4(clampi(y0, -128, 127), clampi(y1, -128, 127), clampi(y2, -128, 127), clampi(y3, -128, 127));
+          *reinterpret_cast<uint32_t*>(dst + nt * 4) = v;
+        }
+      }
     }
   }
 }
@@ -342,7 +419,8 @@ __device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, cons
       char* fbase = frames + f * FRAME_BYTES;
       // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, col ox*STRIDE+kx
       const char* src = fbase + IN::OFF + ((oy * STRIDE) * IN::RS + ox * STRIDE) * IN::S + 4 * cg;
-      int acc[4] = {cp[0].bias2, cp[1].bias2, cp[2].bias2, cp[3].bias2};
+      const I4 k0 = uniform_int4(cp), k1 = uniform_int4(cp + 1), k2 = uniform_int4(cp + 2), k3 = uniform_int4(cp + 3);
+      int acc[4] = {k0.x, k1.x, k2.x, k3.x};
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -350,14 +428,91 @@ __device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, cons
           const int tap = (int)lds_u32(src + (ky * IN::RS + kx) * IN::S);
           const int t = ky * 3 + kx;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_sdot4(tap, (int)wg[t * 4 + jj], acc[jj], false);
+          for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_sdot4(tap, (int)uniform_u32(wg + t * 4 + jj), acc[jj], false);
         }
-      int idx[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) idx[jj] = clampi(requant(acc[jj], cp[jj].mult, cp[jj].kc, cp[jj].rshift), 0, 255);
+      const int idx[4] = {clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
+                          clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255)};
       const uint32_t v = (uint32_t)lut[idx[0]] | ((uint32_t)lut[idx[1]] << 8) | ((uint32_t)lut[idx[2]] << 16) |
                          ((uint32_t)lut[idx[3]] << 24);
       *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + 4 * cg) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise on MFMA
+// One-hot tap packing: for a group of 4 channels the 9 taps x 4 channels of ONE pixel are 9 aligned dwords; they
+// fill k-slots 4*t + c' (36 of 64).  The A operand carries, in row r of a 4-row block, the weight w[t][r&3] at
+// byte (r&3) of tap t's dword and zeros elsewhere, so D[r][pixel] is exactly channel (r&3)'s 9-tap sum.  Four
+// MFMAs -- one per 16-pixel row tile, each with only ITS row block of A non-zero -- accumulate into one
+// accumulator: lane (g,c) ends up with the 4 channels of pixel (row oy0+g, column x0+c), all 64 lanes busy in the
+// epilogue.  A job = 4 output rows x 16 columns (x 2 frames side by side for the 7x7 grids); row/column blocks at
+// the border are shifted inwards (recomputing a few pixels) so that no tap address needs clamping.
+// Replaces 36 v_dot4 per lane-item by 4 MFMAs on the otherwise idle matrix pipe (A/B measured in DESIGN.md).
+template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
+__device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+                                              const yf_dw d, int wave, int lane) {
+  constexpr int W = OUT::W, H = OUT::H;
+  constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;       // frames side by side in the 16 lanes of a row tile
+  constexpr int NSEG = (W > 16) ? 2 : 1;                    // 16-column segments (28 -> x0 in {0, 12})
+  constexpr int NRB = (H + 3) / 4;                          // 4-row blocks (last one shifted up)
+  constexpr int NG = (C + 3) / 4;
+  constexpr int NFP = F / FL;
+  constexpr int JPG = NFP * NRB * NSEG;                     // jobs per channel group
+  constexpr int JOBS = NG * JPG;
+  constexpr int JPW = (JOBS + NW - 1) / NW;
+  constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
+  static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
+  static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
+  const uint8_t* lut = luts + LUT_ID * 256;
+  const int g = lane >> 4, c = lane & 15;
+  const int fl = (FL == 2) ? (c >> 3) : 0;
+  const int xl = (FL == 2) ? (c & 7) : c;
+  const bool lane_valid = (W >= 16) ? true : (xl < W);
+  const int lane_in = fl * FRAME_BYTES + xl * STRIDE * IN::S;
+  const int lane_out = fl * FRAME_BYTES + (g * W + xl) * OUT::S;
+  int tapoff[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) { const int t = min(4 * g + tt, 8); tapoff[tt] = ((t / 3) * IN::RS + (t % 3)) * IN::S; }
+  const int j1 = min(wave * JPW + JPW, JOBS);
+  int j = wave * JPW;
+  while (j < j1) {
+    const int cg = j / JPG;
+    const int jend = min(j1, (cg + 1) * JPG);
+    const uint32_t* wg = reinterpret_cast<const uint32_t*>(tab + d.g_off + cg * YF_DW_GROUP_BYTES);
+    const yf_chan* cp = reinterpret_cast<const yf_chan*>(wg + 36);
+    // A fragments: aw = this lane's 4 tap dwords (row r = c: channel c&3), active only in row block c>>2
+    v4i aw;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) aw[tt] = (4 * g + tt < 9) ? (int)wg[(4 * g + tt) * 4 + (c & 3)] : 0;
+    const v4i z = {0, 0, 0, 0};
+    const int blk = c >> 2;
+    const I4 k0 = uniform_int4(cp), k1 = uniform_int4(cp + 1), k2 = uniform_int4(cp + 2), k3 = uniform_int4(cp + 3);
+    for (; j < jend; ++j) {
+      int rem = j - cg * JPG;
+      const int fp = rem / (NRB * NSEG); rem -= fp * (NRB * NSEG);
+      const int rb = rem / NSEG, seg = rem - rb * NSEG;
+      const int oy0 = min(rb * 4, H - 4);
+      const int x0 = seg ? (W - 16) : 0;
+      char* fb = frames + fp * FL * FRAME_BYTES;
+      const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
+      const char* p0 = src + tapoff[0]; const char* p1 = src + tapoff[1];
+      const char* p2 = src + tapoff[2]; const char* p3 = src + tapoff[3];
+      v4i acc = {k0.x, k1.x, k2.x, k3.x};
+      v4i b;
+      b[0] = (int)lds_u32(p0); b[1] = (int)lds_u32(p1); b[2] = (int)lds_u32(p2); b[3] = (int)lds_u32(p3);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 0 ? aw : z, b, acc, 0, 0, 0);
+      b[0] = (int)lds_u32(p0 + DROW); b[1] = (int)lds_u32(p1 + DROW); b[2] = (int)lds_u32(p2 + DROW); b[3] = (int)lds_u32(p3 + DROW);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 1 ? aw : z, b, acc, 0, 0, 0);
+      b[0] = (int)lds_u32(p0 + 2 * DROW); b[1] = (int)lds_u32(p1 + 2 * DROW); b[2] = (int)lds_u32(p2 + 2 * DROW); b[3] = (int)lds_u32(p3 + 2 * DROW);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 2 ? aw : z, b, acc, 0, 0, 0);
+      b[0] = (int)lds_u32(p0 + 3 * DROW); b[1] = (int)lds_u32(p1 + 3 * DROW); b[2] = (int)lds_u32(p2 + 3 * DROW); b[3] = (int)lds_u32(p3 + 3 * DROW);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 3 ? aw : z, b, acc, 0, 0, 0);
+      if (lane_valid) {
+        const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
+                  i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
+        const uint32_t v = (uint32_t)lut[i0] | ((uint32_t)lut[i1] << 8) | ((uint32_t)lut[i2] << 16) | ((uint32_t)lut[i3] << 24);
+        *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) = v;
+      }
     }
   }
 }
@@ -445,8 +600,8 @@ struct NetParams {
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
-template <int F, int NW, bool DUMP>
-__global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm) {
+template <int F, int NW, bool DUMP, bool DWM>
+__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
@@ -466,7 +621,7 @@ __global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm)
   const AddCtx no_add = {};
   auto addctx = [&](int k) {
     const yf_add& a = ix.add[k];
-    return AddCtx{a.zp1, a.zp2, a.zpo, a.m1, a.s1, a.m2, a.s2, a.mo, a.so};
+    return AddCtx{a.mo, a.kco, a.rso};
   };
   constexpr long DS = DumpOffsets::TOTAL;
 #define YF_SYNC() __syncthreads()
@@ -486,37 +641,38 @@ __global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm)
     conv1_stage<F, NW>(frames, luts, tab, ix.dense[YF_D_CONV1], wave, lane);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
-    dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane);   // conv2d_3
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
-    dense_stage<F, NW, 4, B_T2, B_T3, 0, 4, 16, EPI_RAW, 0, B_T3>(frames, luts, out_all, tab, ix.dense[YF_D_C5], no_add, wave, lane);   // conv2d_5
+    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, ix.dense[YF_D_C5], wave, lane);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
     fill_halo<B_T4, false, F, NT>(frames, ix.halo_zp[YF_W_DW10], tid);
-    dense_stage<F, NW, 4, B_T3, B_T4, 0, 18, 16, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, luts, out_all, tab, ix.dense[YF_D_C6], no_add, wave, lane);   // conv2d_6
+    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, ix.dense[YF_D_C6], wave, lane);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     pool8_h<F, NT>(frames, tid);                                                                   // pool_8 (h)
     YF_SYNC();
     YF_STAGE_END()
     pool8_v<F, NT>(frames, luts, tid);                                                             // pool_8 (v) + QUANTIZE#21
-    dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane);   // conv2d_10
+    YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
     dense_stage<F, NW, 2, B_T6, B_T7, 0, 6, 32, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C12], no_add, wave, lane);  // conv2d_12
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
     fill_halo<B_T8, true, F, NT>(frames, ix.halo_zp[YF_W_DW15], tid);
-    dense_stage<F, NW, 4, B_T7, B_T8, 0, 36, 16, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, luts, out_all, tab, ix.dense[YF_D_C13], no_add, wave, lane);  // conv2d_13
+    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, ix.dense[YF_D_C13], wave, lane);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
-    dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane);   // conv2d_15
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T9, B_T11, 0, 6, 48, EPI_ADD, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C17], addctx(YF_A_ADD18), wave, lane);  // conv2d_17 + eltwise_18
+    dense_stage<F, NW, 1, B_T9, B_T11, 0, 6, 48, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C17], addctx(YF_A_ADD18), wave, lane);  // conv2d_17 + eltwise_18
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
-    dense_stage<F, NW, 4, B_T11, B_T14, YF_T14_CONV_BASE, 18, 16, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, luts, out_all, tab, ix.dense[YF_D_C19], no_add, wave, lane);  // conv2d_19 -> concat_22
+    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, ix.dense[YF_D_C19], wave, lane);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     fill_halo<B_T15, false, F, NT>(frames, ix.halo_zp[YF_W_DW27], tid);
@@ -524,40 +680,40 @@ __global__ void __launch_bounds__(NW * 64) yoloface56_fused(const NetParams prm)
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
     pool25<F, NT>(frames, luts, tid);                                                              // pool_25 + QUANTIZE#45
-    dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane);   // conv2d_27
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane);   // conv2d_27
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
     YF_STAGE_END()
     dense_stage<F, NW, 2, B_T17, B_T18, 0, 8, 32, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C29], no_add, wave, lane);  // conv2d_29
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW32], tid);
-    dense_stage<F, NW, 4, B_T18, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C30], no_add, wave, lane);  // conv2d_30
+    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, ix.dense[YF_D_C30], wave, lane);  // conv2d_30
     YF_SYNC(); YF_DUMP(B_T19, 40, T19)
     YF_STAGE_END()
-    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane);   // conv2d_32
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane);   // conv2d_32
     YF_SYNC(); YF_DUMP(B_T20, 40, T20)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T20, B_T22, 0, 8, 48, EPI_ADD, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C34], addctx(YF_A_ADD35), wave, lane);  // conv2d_34 + eltwise_35
+    dense_stage<F, NW, 1, B_T20, B_T22, 0, 8, 48, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C34], addctx(YF_A_ADD35), wave, lane);  // conv2d_34 + eltwise_35
     YF_SYNC(); YF_DUMP(B_T22, 8, T22)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW38], tid);
-    dense_stage<F, NW, 4, B_T22, B_T19, 0, 40, 16, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C36], no_add, wave, lane);  // conv2d_36
+    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, ix.dense[YF_D_C36], wave, lane);  // conv2d_36
     YF_SYNC(); YF_DUMP(B_T19, 40, T23)
     YF_STAGE_END()
-    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane);   // conv2d_38
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane);   // conv2d_38
     YF_SYNC(); YF_DUMP(B_T20, 40, T24)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T20, B_T26, 0, 8, 48, EPI_ADD, 0, B_T22>(frames, luts, out_all, tab, ix.dense[YF_D_C40], addctx(YF_A_ADD41), wave, lane);  // conv2d_40 + eltwise_41
+    dense_stage<F, NW, 1, B_T20, B_T26, 0, 8, 48, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, ix.dense[YF_D_C40], addctx(YF_A_ADD41), wave, lane);  // conv2d_40 + eltwise_41
     YF_SYNC(); YF_DUMP(B_T26, 8, T26)
     YF_STAGE_END()
-    dense_stage<F, NW, 4, B_T26, B_T30, 24, 24, 16, EPI_LUT, YF_L_L43Q44, B_T30>(frames, luts, out_all, tab, ix.dense[YF_D_C42], no_add, wave, lane);  // conv2d_42 -> concat_46
+    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, ix.dense[YF_D_C42], wave, lane);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP(B_T30, 48, T30)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW49], tid);
     dense_stage<F, NW, 1, B_T30, B_T19, 0, 40, 48, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C47], no_add, wave, lane);  // conv2d_47
     YF_SYNC(); YF_DUMP(B_T19, 40, T31)
     YF_STAGE_END()
-    dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane);   // conv2d_49
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane);   // conv2d_49
     YF_SYNC(); YF_DUMP(B_T20, 40, T32)
     YF_STAGE_END()
     dense_stage<F, NW, 1, B_T20, B_T33, 0, 32, 48, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C51], no_add, wave, lane);  // conv2d_51

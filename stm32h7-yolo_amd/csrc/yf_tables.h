@@ -47,7 +47,12 @@ typedef struct {
 typedef struct {
   int32_t zp1, zp2, zpo;
   int32_t m1, s1, m2, s2, mo, so;
+  int32_t kco, rso;    /* fused final requantisation of sa+sb: y = (s + kco + (s>>31)) >> rso, rso = -so >= 1 */
 } yf_add;
+/* Device form of an ADD: two 256-entry int32 tables, index q+128:
+ *   A[q1] = MBQM((q1 - zp1) << 20, m1, s1)   (the stored operand)     B[q2] = MBQM((q2 - zp2) << 20, m2, s2)
+ * laid out [YF_N_ADD][2][256] right behind the byte LUTs. */
+#define YF_ADDLUT_BYTES (YF_N_ADD * 2 * 256 * 4)
 
 enum {
   /* dense stages in execution order */
@@ -74,7 +79,7 @@ typedef struct {
   yf_dense dense[YF_N_DENSE];
   yf_dw    dw[YF_N_DW];
   yf_add   add[YF_N_ADD];
-  uint32_t lut_off;          /* YF_N_LUT * 256 bytes */
+  uint32_t lut_off;          /* YF_N_LUT * 256 bytes of byte LUTs followed by YF_ADDLUT_BYTES of add tables */
   uint32_t total_bytes;
   int32_t  in_zp;            /* input zero point (-128): halo fill of the staged frame */
   int32_t  halo_zp[YF_N_DW]; /* zero point of each depthwise INPUT buffer: its halo fill value */

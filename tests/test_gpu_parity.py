@@ -39,7 +39,7 @@ def test_native_library_is_loaded(network):
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 257])
 def test_ai_network_run_host_path_equals_oracle(network, oracle, n):
     """reference call: ai_network_run(network, &ai_input, &ai_output) with n_batches = n (yoloface.c:226-231)"""
-    network.configure(2, 4)
+    network.configure(2, 8)
     x = rnd(100 + n, n)
     assert np.array_equal(network.run(x), oracle.run(x, threads=8))
 
@@ -94,7 +94,7 @@ def test_kernel_variants_and_ragged_tails(network, oracle, torch_cuda, fw):
         got = d_out.cpu().numpy()
         assert np.array_equal(got[:n], oracle.run(x, threads=8))
         assert (got[n] == 77).all(), "wrote past the last frame"
-    network.configure(2, 4)
+    network.configure(2, 8)
 
 
 def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):

@@ -13,7 +13,7 @@ from conftest import ROOT
 PKG = os.path.join(ROOT, "stm32h7-yolo_amd")
 N_DENSE, N_DW, N_ADD, N_LUT = 17, 7, 3, 19
 DENSE_OPS = [1, 5, 6, 12, 13, 17, 19, 23, 29, 30, 34, 36, 40, 42, 47, 51, 53]
-DENSE_LUT = [1, 0, 1, 0, 1, 0, 1, 1, 0, 1, 0, 1, 0, 1, 1, 1, 0]
+DENSE_LUT = [1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0]   # conv2d_17/34/40 index the add table B
 DW_OPS = [3, 10, 15, 27, 32, 38, 49]
 LEAKY_LUT_IDS = {2: 0, 4: 1, 7: 2, 11: 4, 14: 5, 16: 6, 20: 7, 24: 8, 28: 10, 31: 11, 33: 12, 37: 13, 39: 14, 48: 16, 50: 17, 52: 18}
 
@@ -28,7 +28,7 @@ class Dw(ctypes.Structure):
 
 
 class Add(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("zp1", "zp2", "zpo", "m1", "s1", "m2", "s2", "mo", "so")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("zp1", "zp2", "zpo", "m1", "s1", "m2", "s2", "mo", "so", "kco", "rso")]
 
 
 class Index(ctypes.Structure):
@@ -85,7 +85,7 @@ def test_index_is_embedded_and_blocks_are_aligned(prep):
         assert d.w_off % 16 == 0 and d.c_off % 16 == 0 and d.krow % 16 == 0 and d.cout_pad4 % 4 == 0
     for d in ix.dw:
         assert d.g_off % 16 == 0
-    assert ix.lut_off % 16 == 0 and ix.total_bytes >= ix.lut_off + N_LUT * 256 + 16
+    assert ix.lut_off % 16 == 0 and ix.total_bytes >= ix.lut_off + N_LUT * 256 + 3 * 2 * 1024 + 16
     assert ix.in_zp == -128
     assert list(ix.halo_zp) == [-108, -99, -96, -94, -107, -102, -114]    # zero points of tflite tensors 52,57,64,73,80,86,95
 
@@ -220,6 +220,19 @@ def test_add_tables(prep, oracle, pack):
             m, sh = ctypes.c_int32(), ctypes.c_int()
             oracle.lib.yfo_quantize_multiplier(real, ctypes.byref(m), ctypes.byref(sh))
             assert (mm, ss) == (m.value, sh.value) and ss <= 0
+        assert a.rso == -a.so >= 1 and a.kco == (1 << (a.rso - 1)) + (a.zpo << a.rso)
+        # device tables: A[q1], B[q2] and the fused final requantisation reproduce TFLite's ADD for every (q1, q2) sampled
+        ix, tab = prep["ix"], prep["tab"]
+        al = np.frombuffer(tab, "<i4", 3 * 512, ix.lut_off + N_LUT * 256).reshape(3, 2, 256)
+        rng = np.random.default_rng(40 + s)
+        for q1, q2 in np.concatenate([rng.integers(-128, 128, (400, 2)), [[-128, -128], [127, 127], [-128, 127], [t1["zp"], t2["zp"]]]]):
+            q1, q2 = int(q1), int(q2)
+            sa = oracle.lib.yfo_mbqm((q1 - a.zp1) * (1 << 20), a.m1, a.s1)
+            sb = oracle.lib.yfo_mbqm((q2 - a.zp2) * (1 << 20), a.m2, a.s2)
+            assert (al[s, 0, q1 + 128], al[s, 1, q2 + 128]) == (sa, sb)
+            sm = oracle.lib.yfo_srdhm(sa + sb, a.mo)
+            fused = (sm + a.kco + (sm >> 31)) >> a.rso
+            assert fused == oracle.lib.yfo_mbqm(sa + sb, a.mo, a.so) + a.zpo
 
 
 def test_prepare_rejects_bad_arguments(prep):

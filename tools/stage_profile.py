@@ -11,6 +11,8 @@ NAMES = ["input staging", "conv2d_1", "conv2d_3 (dw)", "conv2d_5", "conv2d_6", "
 n = 4096
 x = np.random.default_rng(1).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
 net = yf.Network().init()
+if len(sys.argv) > 2: net.configure(int(sys.argv[1]), int(sys.argv[2]))
+print("profiling debug build of", net.kernel_name)
 d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
 net.time_stages(d_in.data_ptr(), d_out.data_ptr(), n, 3, 0)
 prev = 0.0
