@@ -112,7 +112,7 @@ struct Variant { int f, nw; bool dump; bool dwm; fused_fn fn; size_t lds; const 
 // DW=true: depthwise on the matrix pipe (one-hot tap packing); DW=false: v_dot4 path (kept for A/B measurements)
 const Variant k_variants[] = {
   YF_VARIANT(1, 4, false, true), YF_VARIANT(2, 4, false, true), YF_VARIANT(4, 4, false, true), YF_VARIANT(2, 8, false, true), YF_VARIANT(4, 8, false, true),
-  YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
+  YF_VARIANT(2, 6, false, true), YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
   YF_VARIANT(2, 4, true, true), YF_VARIANT(2, 8, true, true),
 };
 

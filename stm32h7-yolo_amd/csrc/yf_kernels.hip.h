@@ -88,10 +88,15 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 __device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
   return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
 }
-__device__ __forceinline__ uint32_t lut4(const uint8_t* lut, uint32_t d) {   // per byte: lut[q + 128]
+// Byte LUTs live at LDS offset LUT_ID*256 (the dynamic LDS segment starts at 0: the kernel has no static LDS and
+// checks it).  Absolute LDS addressing lets the table base ride in the ds_read immediate offset.
+typedef const __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
+template <int LUT_ID>
+__device__ __forceinline__ uint32_t lutb(int idx) { return *(lds_u8_ptr)(uint32_t)(LUT_ID * 256 + idx); }
+template <int LUT_ID>
+__device__ __forceinline__ uint32_t lut4(uint32_t d) {   // per byte: lut[q + 128]
   const uint32_t x = d ^ 0x80808080u;
-  return (uint32_t)lut[x & 255] | ((uint32_t)lut[(x >> 8) & 255] << 8) | ((uint32_t)lut[(x >> 16) & 255] << 16) |
-         ((uint32_t)lut[x >> 24] << 24);
+  return lutb<LUT_ID>(x & 255) | (lutb<LUT_ID>((x >> 8) & 255) << 8) | (lutb<LUT_ID>((x >> 16) & 255) << 16) | (lutb<LUT_ID>(x >> 24) << 24);
 }
 __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {          // v_pk_max_i16
   v2s x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
@@ -172,9 +177,8 @@ template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
 __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
                                                int p, int chq, const int (&y)[4], const AddCtx& ad) {
   if constexpr (EPI == EPI_LUT) {
-    const uint8_t* lut = luts + LUT_ID * 256;
-    const uint32_t v = (uint32_t)lut[clampi(y[0], 0, 255)] | ((uint32_t)lut[clampi(y[1], 0, 255)] << 8) |
-                       ((uint32_t)lut[clampi(y[2], 0, 255)] << 16) | ((uint32_t)lut[clampi(y[3], 0, 255)] << 24);
+    const uint32_t v = lutb<LUT_ID>(clampi(y[0], 0, 255)) | (lutb<LUT_ID>(clampi(y[1], 0, 255)) << 8) |
+                       (lutb<LUT_ID>(clampi(y[2], 0, 255)) << 16) | (lutb<LUT_ID>(clampi(y[3], 0, 255)) << 24);
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = v;
   } else if constexpr (EPI == EPI_RAW) {
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
@@ -182,14 +186,14 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, cons
   } else if constexpr (EPI == EPI_ADD) {
     // tflite ADD (LUT_ID = add index): in1 = stored tensor (ADDB) -> table A, in2 = this conv's output -> table B,
     // then one fused requantisation of the sum.
-    const int* la = reinterpret_cast<const int*>(luts + YF_N_LUT * 256) + LUT_ID * 512;
-    const int* lb = la + 256;
+    typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
+    constexpr uint32_t LA = YF_N_LUT * 256 + LUT_ID * 2048, LB = LA + 1024;
     const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq) ^ 0x80808080u;
     int r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int sa = la[(o >> (8 * j)) & 255];
-      const int sb = lb[clampi(y[j], 0, 255)];
+      const int sa = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255));
+      const int sb = *(lds_i32_ptr)(uint32_t)(LB + 4 * clampi(y[j], 0, 255));
       r[j] = clampi(requant(sa + sb, ad.mo, ad.kco, ad.rso), -128, 127);
     }
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = pack4(r[0], r[1], r[2], r[3]);
@@ -290,7 +294,6 @@ __device__ __forceinline__ void dense4_stage(char* frames, const uint8_t* luts, 
   const int g = lane >> 4, c = lane & 15;
   const int j0 = wave * JPW, j1 = min(j0 + JPW, JOBS);
   const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
-  const uint8_t* lut = luts + LUT_ID * 256;
   int cur_chunk = -1;
   v4i a[TPJ];
   for (int j = j0; j < j1; ++j) {
@@ -329,8 +332,8 @@ __device__ __forceinline__ void dense4_stage(char* frames, const uint8_t* luts, 
                     y2 = requant(acc[2], k2.y, k2.z, k2.w), y3 = requant(acc[3], k3.y, k3.z, k3.w);
           uint32_t v;
           if constexpr (EPI == EPI_LUT)
-            v = (uint32_t)lut[clampi(y0, 0, 255)] | ((uint32_t)lut[clampi(y1, 0, 255)] << 8) |
-                ((uint32_t)lut[clampi(y2, 0, 255)] << 16) | ((uint32_t)lut[clampi(y3, 0, 255)] << 24);
+            v = lutb<LUT_ID>(clampi(y0, 0, 255)) | (lutb<LUT_ID>(clampi(y1, 0, 255)) << 8) |
+                (lutb<LUT_ID>(clampi(y2, 0, 255)) << 16) | (lutb<LUT_ID>(clampi(y3, 0, 255)) << 24);
           else
             v = pack4(clampi(y0, -128, 127), clampi(y1, -128, 127), clampi(y2, -128, 127), clampi(y3, -128, 127));
           *reinterpret_cast<uint32_t*>(dst + nt * 4) = v;
@@ -403,7 +406,6 @@ __device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, cons
   constexpr int NB = (TOT + 63) / 64;                  // 64-pixel blocks per channel group
   constexpr int JOBS = NG * NB;
   constexpr int JPW = (JOBS + NW - 1) / NW;
-  const uint8_t* lut = luts + LUT_ID * 256;
   const int j1 = min(wave * JPW + JPW, JOBS);
   int j = wave * JPW;
   while (j < j1) {
@@ -432,8 +434,7 @@ __device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, cons
         }
       const int idx[4] = {clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
                           clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255)};
-      const uint32_t v = (uint32_t)lut[idx[0]] | ((uint32_t)lut[idx[1]] << 8) | ((uint32_t)lut[idx[2]] << 16) |
-                         ((uint32_t)lut[idx[3]] << 24);
+      const uint32_t v = lutb<LUT_ID>(idx[0]) | (lutb<LUT_ID>(idx[1]) << 8) | (lutb<LUT_ID>(idx[2]) << 16) | (lutb<LUT_ID>(idx[3]) << 24);
       *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + 4 * cg) = v;
     }
   }
@@ -463,7 +464,6 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
   constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
   static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
   static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
-  const uint8_t* lut = luts + LUT_ID * 256;
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
   const int xl = (FL == 2) ? (c & 7) : c;
@@ -510,7 +510,7 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
       if (lane_valid) {
         const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
                   i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
-        const uint32_t v = (uint32_t)lut[i0] | ((uint32_t)lut[i1] << 8) | ((uint32_t)lut[i2] << 16) | ((uint32_t)lut[i3] << 24);
+        const uint32_t v = lutb<LUT_ID>(i0) | (lutb<LUT_ID>(i1) << 8) | (lutb<LUT_ID>(i2) << 16) | (lutb<LUT_ID>(i3) << 24);
         *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) = v;
       }
     }
@@ -520,37 +520,71 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
 // ------------------------------------------------------------------------------------------------ max-pools
 // pool_8: 8x8 stride 2 pad 3 on T4 (28x28x18) -> separable; the vertical pass applies QUANTIZE#21 and writes the
 // pool half of concat_22.  Out-of-range taps are handled by clamping the coordinate (max is idempotent).
+// One item sweeps NO consecutive outputs along the pooled axis and shares the pair maxima P[j] = max(c[2j], c[2j+1]):
+//   out[o] = max(c[2o-3], P[o-1], P[o], P[o+1], c[2o+4])        (coordinates clamped into [0,27]: max is idempotent)
+// so 2*(NO+4) loads and ~6 packed maxima per output replace 8 loads and 16 maxima.  The last chunk is shifted
+// inwards (recomputing a few outputs) so every chunk has exactly NO outputs.
+struct SplitB {      // packed int8x4 as two int16x2 registers (odd bytes / even bytes lifted into the high byte)
+  uint32_t o, e;
+  __device__ __forceinline__ SplitB() : o(0x80008000u), e(0x80008000u) {}
+  __device__ __forceinline__ explicit SplitB(uint32_t d) : o(d & 0xFF00FF00u), e((d << 8) & 0xFF00FF00u) {}
+  __device__ __forceinline__ SplitB mx(const SplitB& b) const { SplitB r; r.o = pkmax(o, b.o); r.e = pkmax(e, b.e); return r; }
+  __device__ __forceinline__ uint32_t merge() const { return (o & 0xFF00FF00u) | ((e >> 8) & 0x00FF00FFu); }
+};
+// LOADC(k): packed dword at clamped coordinate k along the pooled axis; STORE(o, v): write output o.
+template <int NO, class LOADC, class STORE>
+__device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
+  constexpr int NP = NO + 4;                       // pairs o0-2 .. o0+NO+1
+  SplitB ev[NP], od[NP];
+#pragma unroll
+  for (int jj = 0; jj < NP; ++jj) {
+    const int j = o0 - 2 + jj;
+    ev[jj] = SplitB(loadc(clampi(2 * j, 0, 27)));
+    od[jj] = SplitB(loadc(clampi(2 * j + 1, 0, 27)));
+  }
+  SplitB pm[NP];
+#pragma unroll
+  for (int jj = 1; jj < NP - 1; ++jj) pm[jj] = ev[jj].mx(od[jj]);
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    const int jj = n + 2;
+    const SplitB r = od[jj - 2].mx(pm[jj - 1]).mx(pm[jj].mx(pm[jj + 1])).mx(ev[jj + 2]);
+    store(o0 + n, r.merge());
+  }
+}
 template <int F, int NT>
 __device__ __forceinline__ void pool8_h(char* frames, int tid) {
-  for (int i = tid; i < F * 28 * 14 * 5; i += NT) {
+  constexpr int NO = 4, NCH = 4;                   // output chunks at 0,4,8,10
+  for (int i = tid; i < F * 28 * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
-    const int ox = t % 14; t /= 14;
+    const int k = t % NCH; t /= NCH;
     const int y = t % 28; const int f = t / 28;
     char* fbase = frames + f * FRAME_BYTES;
-    ByteMax m;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m.add(lds_u32(fbase + B_T4::at(y, clampi(2 * ox - 3 + k, 0, 27)) + 4 * cg));
-    *reinterpret_cast<uint32_t*>(fbase + B_HB::OFF + (y * 14 + ox) * 20 + 4 * cg) = m.get();
+    const char* row = fbase + B_T4::at(y, 0) + 4 * cg;
+    char* dst = fbase + B_HB::OFF + (y * 14) * 20 + 4 * cg;
+    pool8_sweep<NO>(min(k * NO, 14 - NO),
+                    [&](int x) { return lds_u32(row + x * B_T4::S); },
+                    [&](int ox, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v; });
   }
 }
 template <int F, int NT>
 __device__ __forceinline__ void pool8_v(char* frames, const uint8_t* luts, int tid) {
-  const uint8_t* lut = luts + YF_L_Q21 * 256;
-  for (int i = tid; i < F * 14 * 14 * 5; i += NT) {
+  constexpr int NO = 2, NCH = 7;
+  for (int i = tid; i < F * 14 * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
-    const int ox = t % 14; t /= 14;
-    const int oy = t % 14; const int f = t / 14;
+    const int k = t % NCH; t /= NCH;
+    const int ox = t % 14; const int f = t / 14;
     char* fbase = frames + f * FRAME_BYTES;
-    ByteMax m;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m.add(lds_u32(fbase + B_HB::OFF + (clampi(2 * oy - 3 + k, 0, 27) * 14 + ox) * 20 + 4 * cg));
-    *reinterpret_cast<uint32_t*>(fbase + B_T14::at_p(oy * 14 + ox) + 4 * cg) = lut4(lut, m.get());
+    const char* col = fbase + B_HB::OFF + ox * 20 + 4 * cg;
+    char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
+    pool8_sweep<NO>(k * NO,
+                    [&](int r) { return lds_u32(col + r * (14 * 20)); },
+                    [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (14 * B_T14::S)) = lut4<YF_L_Q21>(v); });
   }
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
 template <int F, int NT>
 __device__ __forceinline__ void pool25(char* frames, const uint8_t* luts, int tid) {
-  const uint8_t* lut = luts + YF_L_Q45 * 256;
   for (int i = tid; i < F * 49 * 6; i += NT) {
     const int cg = i % 6; int t = i / 6;
     const int p = t % 49; const int f = t / 49;
@@ -562,7 +596,7 @@ __device__ __forceinline__ void pool25(char* frames, const uint8_t* luts, int ti
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
         m.add(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, 13), clampi(2 * ox - 1 + kx, 0, 13)) + 4 * cg));
-    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4(lut, m.get());
+    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4<YF_L_Q45>(m.get());
   }
 }
 
@@ -601,11 +635,12 @@ struct NetParams {
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
 template <int F, int NW, bool DUMP, bool DWM>
-__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) yoloface56_fused(const NetParams prm) {
+__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();   // LUTs are addressed absolutely
   char* out_all = smem + LUT_BYTES;
   char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
   const int tid = threadIdx.x;
