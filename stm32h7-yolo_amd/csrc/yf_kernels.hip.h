@@ -21,6 +21,14 @@
 
 namespace yf {
 
+// Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
+// more than they save: 12.9 vs 14.5 M frames/s).  -DYF_NOINLINE_STAGES makes them calls again.
+#ifndef YF_NOINLINE_STAGES
+#define YF_STAGE_FN __device__ __forceinline__
+#else
+#define YF_STAGE_FN __device__ __attribute__((noinline))
+#endif
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
@@ -124,7 +132,7 @@ __device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_p
 // ------------------------------------------------------------------------------------------------ halo fill
 // RING: 1-pixel border all round (SAME 3x3 stride 1); otherwise top row + left column (explicit PAD, stride 2)
 template <class B, bool RING, int F, int NT>
-__device__ __forceinline__ void fill_halo(char* frames, int zp, int tid) {
+YF_STAGE_FN void fill_halo(char* frames, int zp, int tid) {
   const uint32_t v = (uint32_t)(zp & 255) * 0x01010101u;
   constexpr int DW = B::S / 4;
   constexpr int HR = B::H + B::PT + (RING ? 1 : 0), WR = B::RS;        // halo'd rows / cols
@@ -146,7 +154,7 @@ __device__ __forceinline__ void fill_halo(char* frames, int zp, int tid) {
 // ------------------------------------------------------------------------------------------------ input staging
 // NHWC int8 frames (9408 B) -> RGBX dwords with halo.  Coalesced 12-byte loads (4 pixels per lane).
 template <int F, int NT>
-__device__ __forceinline__ void stage_input(char* frames, const int8_t* __restrict__ in, long first_frame, long n_frames,
+YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long first_frame, long n_frames,
                                             int zp, int tid) {
   const uint32_t hv = (uint32_t)(zp & 255) * 0x01010101u;
   // halo: row 0 (60 dwords) and dword column 3 of rows 1..56
@@ -211,7 +219,7 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, cons
 // ------------------------------------------------------------------------------------------------ dense 1x1 stage
 // BD pixel sets per MFMA (block-diagonal A): BD=1: <=16 channels x K<=64, BD=2: <=8 x K<=32, BD=4: <=4 x K<=16.
 template <int F, int NW, int BD, class IN, class OUT, int OUT_CH0, int COUT, int KROW, int EPI, int LUT_ID, class ADDB>
-__device__ __forceinline__ void dense_stage(char* frames, const uint8_t* luts, char* out_all,
+YF_STAGE_FN void dense_stage(char* frames, const uint8_t* luts, char* out_all,
                                             const uint8_t* __restrict__ tab, const yf_dense d, const AddCtx ad,
                                             int wave, int lane) {
   constexpr int NCHT = 16 / BD;
@@ -280,7 +288,7 @@ __device__ __forceinline__ void dense_stage(char* frames, const uint8_t* luts, c
 // output address are computed once per job and shared by its tiles; with BD = 4 every lane of the wave uses the SAME
 // four channels of a tile, so the requantisation constants are wave-uniform scalar loads instead of VGPRs.
 template <int F, int NW, int TPJ, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID>
-__device__ __forceinline__ void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
                                              const yf_dense d, int wave, int lane) {
   constexpr int NTL = (COUT + 3) / 4;
   constexpr int NCH = (NTL + TPJ - 1) / TPJ;                // channel-tile chunks
@@ -346,7 +354,7 @@ __device__ __forceinline__ void dense4_stage(char* frames, const uint8_t* luts, 
 // ------------------------------------------------------------------------------------------------ conv2d_1
 // 3x3 stride 2, Cin 3 (RGBX) -> 8: two k-steps, BD=2 (32 output pixels x 8 channels per MFMA pair).
 template <int F, int NW>
-__device__ __forceinline__ void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
                                             const yf_dense d, int wave, int lane) {
   constexpr int P = 784, TOT = F * P, PIX_T = 32;
   constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
@@ -399,7 +407,7 @@ __device__ __forceinline__ void conv1_stage(char* frames, const uint8_t* luts, c
 // IN has a halo holding its zero point; the zero point itself is folded into bias2.  Jobs = channel group x
 // pixel chunk; the group's 36 masked weight dwords and 4 yf_chan are wave-uniform (scalar loads).
 template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
-__device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+YF_STAGE_FN void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
                                          const yf_dw d, int wave, int lane) {
   constexpr int NG = (C + 3) / 4;
   constexpr int P = OUT::P, TOT = F * P;
@@ -441,17 +449,17 @@ __device__ __forceinline__ void dw_stage(char* frames, const uint8_t* luts, cons
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise on MFMA
-// One-hot tap packing: for a group of 4 channels the 9 taps x 4 channels of ONE pixel are 9 aligned dwords; they
-// fill k-slots 4*t + c' (36 of 64).  The A operand carries, in row r of a 4-row block, the weight w[t][r&3] at
-// byte (r&3) of tap t's dword and zeros elsewhere, so D[r][pixel] is exactly channel (r&3)'s 9-tap sum.  Four
-// MFMAs -- one per 16-pixel row tile, each with only ITS row block of A non-zero -- accumulate into one
-// accumulator: lane (g,c) ends up with the 4 channels of pixel (row oy0+g, column x0+c), all 64 lanes busy in the
-// epilogue.  A job = 4 output rows x 16 columns (x 2 frames side by side for the 7x7 grids); row/column blocks at
-// the border are shifted inwards (recomputing a few pixels) so that no tap address needs clamping.
-// Replaces 36 v_dot4 per lane-item by 4 MFMAs on the otherwise idle matrix pipe (A/B measured in DESIGN.md).
+// Lane-private one-hot packing.  The 64 k-slots of v_mfma_i32_16x16x64_i8 are supplied by four lane groups of 16
+// slots each; rows 4g..4g+3 of the A operand are non-zero only in group g's slots.  D[4g+j][c] is then a 16-long dot
+// product over data that lane (g,c) itself supplied -- 64 independent pixels per MFMA, each lane working on ITS OWN
+// pixel.  One k-step carries 4 taps x 4 channels (4 aligned dwords of the pixel's halo'd neighbourhood), so the
+// 9 taps of a 3x3 depthwise filter take 3 k-steps; A holds w[tap][channel j] at byte j of tap's dword in row 4g+j.
+// Per 64 pixels x 4 channels: 9 ds_read_b32 off one address register, 3 MFMAs, no VALU multiply at all
+// (the v_dot4 form needs 36).  A job = 4 output rows x 16 columns (2 frames side by side for the 7x7 grids);
+// border blocks are shifted inwards so every lane's neighbourhood address is in range.
 template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
-__device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
-                                              const yf_dw d, int wave, int lane) {
+YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
+                               const yf_dw d, int wave, int lane) {
   constexpr int W = OUT::W, H = OUT::H;
   constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;       // frames side by side in the 16 lanes of a row tile
   constexpr int NSEG = (W > 16) ? 2 : 1;                    // 16-column segments (28 -> x0 in {0, 12})
@@ -462,17 +470,16 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
   constexpr int JOBS = NG * JPG;
   constexpr int JPW = (JOBS + NW - 1) / NW;
   constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
+  constexpr int TS = IN::S, TR = IN::RS * IN::S;            // tap strides: +1 column, +1 row
   static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
   static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
   const int xl = (FL == 2) ? (c & 7) : c;
   const bool lane_valid = (W >= 16) ? true : (xl < W);
-  const int lane_in = fl * FRAME_BYTES + xl * STRIDE * IN::S;
+  const int lane_in = fl * FRAME_BYTES + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
   const int lane_out = fl * FRAME_BYTES + (g * W + xl) * OUT::S;
-  int tapoff[4];
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) { const int t = min(4 * g + tt, 8); tapoff[tt] = ((t / 3) * IN::RS + (t % 3)) * IN::S; }
+  const bool a_on = (c >> 2) == g;                          // A row r = c belongs to row block r>>2
   const int j1 = min(wave * JPW + JPW, JOBS);
   int j = wave * JPW;
   while (j < j1) {
@@ -480,12 +487,13 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
     const int jend = min(j1, (cg + 1) * JPG);
     const uint32_t* wg = reinterpret_cast<const uint32_t*>(tab + d.g_off + cg * YF_DW_GROUP_BYTES);
     const yf_chan* cp = reinterpret_cast<const yf_chan*>(wg + 36);
-    // A fragments: aw = this lane's 4 tap dwords (row r = c: channel c&3), active only in row block c>>2
-    v4i aw;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) aw[tt] = (4 * g + tt < 9) ? (int)wg[(4 * g + tt) * 4 + (c & 3)] : 0;
-    const v4i z = {0, 0, 0, 0};
-    const int blk = c >> 2;
+    v4i a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;                // k-steps: taps 0-3, 4-7, 8
+    if (a_on) {
+      const uint32_t* wl = wg + (c & 3);                    // masked weight dwords of channel c&3: wl[4*tap]
+      a0 = v4i{(int)wl[0], (int)wl[4], (int)wl[8], (int)wl[12]};
+      a1 = v4i{(int)wl[16], (int)wl[20], (int)wl[24], (int)wl[28]};
+      a2[0] = (int)wl[32];
+    }
     const I4 k0 = uniform_int4(cp), k1 = uniform_int4(cp + 1), k2 = uniform_int4(cp + 2), k3 = uniform_int4(cp + 3);
     for (; j < jend; ++j) {
       int rem = j - cg * JPG;
@@ -495,18 +503,14 @@ __device__ __forceinline__ void dw_mfma_stage(char* frames, const uint8_t* luts,
       const int x0 = seg ? (W - 16) : 0;
       char* fb = frames + fp * FL * FRAME_BYTES;
       const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
-      const char* p0 = src + tapoff[0]; const char* p1 = src + tapoff[1];
-      const char* p2 = src + tapoff[2]; const char* p3 = src + tapoff[3];
+      v4i b0, b1, b2 = {0, 0, 0, 0};
+      b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
+      b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
+      b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
       v4i acc = {k0.x, k1.x, k2.x, k3.x};
-      v4i b;
-      b[0] = (int)lds_u32(p0); b[1] = (int)lds_u32(p1); b[2] = (int)lds_u32(p2); b[3] = (int)lds_u32(p3);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 0 ? aw : z, b, acc, 0, 0, 0);
-      b[0] = (int)lds_u32(p0 + DROW); b[1] = (int)lds_u32(p1 + DROW); b[2] = (int)lds_u32(p2 + DROW); b[3] = (int)lds_u32(p3 + DROW);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 1 ? aw : z, b, acc, 0, 0, 0);
-      b[0] = (int)lds_u32(p0 + 2 * DROW); b[1] = (int)lds_u32(p1 + 2 * DROW); b[2] = (int)lds_u32(p2 + 2 * DROW); b[3] = (int)lds_u32(p3 + 2 * DROW);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 2 ? aw : z, b, acc, 0, 0, 0);
-      b[0] = (int)lds_u32(p0 + 3 * DROW); b[1] = (int)lds_u32(p1 + 3 * DROW); b[2] = (int)lds_u32(p2 + 3 * DROW); b[3] = (int)lds_u32(p3 + 3 * DROW);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(blk == 3 ? aw : z, b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
       if (lane_valid) {
         const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
                   i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
@@ -553,7 +557,7 @@ __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
   }
 }
 template <int F, int NT>
-__device__ __forceinline__ void pool8_h(char* frames, int tid) {
+YF_STAGE_FN void pool8_h(char* frames, int tid) {
   constexpr int NO = 4, NCH = 4;                   // output chunks at 0,4,8,10
   for (int i = tid; i < F * 28 * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
@@ -568,7 +572,7 @@ __device__ __forceinline__ void pool8_h(char* frames, int tid) {
   }
 }
 template <int F, int NT>
-__device__ __forceinline__ void pool8_v(char* frames, const uint8_t* luts, int tid) {
+YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
   constexpr int NO = 2, NCH = 7;
   for (int i = tid; i < F * 14 * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
@@ -584,7 +588,7 @@ __device__ __forceinline__ void pool8_v(char* frames, const uint8_t* luts, int t
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
 template <int F, int NT>
-__device__ __forceinline__ void pool25(char* frames, const uint8_t* luts, int tid) {
+YF_STAGE_FN void pool25(char* frames, const uint8_t* luts, int tid) {
   for (int i = tid; i < F * 49 * 6; i += NT) {
     const int cg = i % 6; int t = i / 6;
     const int p = t % 49; const int f = t / 49;
