@@ -6,7 +6,17 @@
 #include <string.h>
 #include <string>
 #include "yf_engine.h"
+#define YF_NS yf
+#define YF_EXP 0
 #include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_EXP
+#undef YF_STAGE_FN
+#define YF_NS yfx
+#define YF_EXP 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_EXP
 #include "gen/yf_decode_tables_gen.h"
 #include "../../include/yf_network.h"   // yf_det, YF_DECODE_*
 
@@ -105,15 +115,19 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 }
 
 typedef void (*fused_fn)(const yf::NetParams);
-struct Variant { int f, nw; bool dump; bool dwm; fused_fn fn; size_t lds; const char* name; };
+static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
+struct Variant { int f, nw; bool dump; bool dwm; bool exp; fused_fn fn; size_t lds; const char* name; };
 
-#define YF_VARIANT(F, NW, DUMP, DWM) { F, NW, DUMP, DWM, (fused_fn)yf::yoloface56_fused<F, NW, DUMP, DWM>, yf::lds_bytes<F, NW>(), \
+#define YF_VARIANT(F, NW, DUMP, DWM) { F, NW, DUMP, DWM, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP, DWM>, yf::lds_bytes<F, NW>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ",DW=" #DWM ">" }
+#define YF_VARIANT_X(F, NW) { F, NW, false, true, true, (fused_fn)yfx::yoloface56_fused<F, NW, false, true>, yfx::lds_bytes<F, NW>(), \
+                              "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
 // DW=true: depthwise on the matrix pipe (one-hot tap packing); DW=false: v_dot4 path (kept for A/B measurements)
 const Variant k_variants[] = {
   YF_VARIANT(1, 4, false, true), YF_VARIANT(2, 4, false, true), YF_VARIANT(4, 4, false, true), YF_VARIANT(2, 8, false, true), YF_VARIANT(4, 8, false, true),
   YF_VARIANT(2, 6, false, true), YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
   YF_VARIANT(2, 4, true, true), YF_VARIANT(2, 8, true, true),
+  YF_VARIANT_X(2, 8), YF_VARIANT_X(1, 4),
 };
 
 }  // namespace
@@ -134,8 +148,8 @@ struct yf_engine {
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
-static const Variant* find_variant(int f, int nw, bool dump, bool dwm = true) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.dwm == dwm) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool dwm = true, bool exp = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.dwm == dwm && v.exp == exp) return &v;
   return nullptr;
 }
 
@@ -187,10 +201,13 @@ void yf_engine_destroy(yf_engine* e) {
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
   /* frames_per_wg + 100 selects the v_dot4 depthwise build of the same shape (A/B measurements) */
+  /* frames_per_wg + 200 selects the experimental (YF_EXP) build of the same shape */
+  const bool exp = frames_per_wg >= 200;
+  if (exp) frames_per_wg -= 200;
   const bool dot4 = frames_per_wg >= 100;
   if (dot4) frames_per_wg -= 100;
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
-  const Variant* v = find_variant(f, nw, false, !dot4);
+  const Variant* v = find_variant(f, nw, false, !dot4, exp);
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
   if (const Variant* dv = find_variant(f, nw, true)) e->var_dump = dv;     /* debug build of the same shape, if compiled */

@@ -14,12 +14,14 @@
 //   max-pool              : separable, packed 2x int16 max on the byte lanes, clamped coordinates
 //   residual add          : TFLite int8 ADD arithmetic in the producing conv's epilogue
 //   concat                : producers write straight into the concat buffer (no copy)
-#pragma once
+// Included twice by yf_engine.hip (namespaces yf and yfx) so that an experimental variant (YF_EXP 1) can be A/B-timed
+// against the shipped code in ONE process on ONE device (cdna_hip_programming.md 5.4 rule 24).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "yf_tables.h"
 
-namespace yf {
+namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
 // more than they save: 12.9 vs 14.5 M frames/s).  -DYF_NOINLINE_STAGES makes them calls again.
@@ -128,6 +130,21 @@ typedef const __attribute__((address_space(4))) uint32_t* cu32_ptr;
 struct I4 { int x, y, z, w; };
 __device__ __forceinline__ I4 uniform_int4(const void* p) { const v4i v = *(cv4i_ptr)(uintptr_t)p; return I4{v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_ptr)(uintptr_t)p; }
+// stage descriptors out of the index at the head of the table blob, as scalar loads (offsets stay in SGPRs)
+__device__ __forceinline__ yf_dense load_dense(const uint8_t* tab, int i) {
+  const uint8_t* p = tab + offsetof(yf_table_index, dense) + i * sizeof(yf_dense);
+  yf_dense d = {};
+  d.w_off = uniform_u32(p); d.c_off = uniform_u32(p + 4);
+  return d;
+}
+__device__ __forceinline__ yf_dw load_dw(const uint8_t* tab, int i) {
+  yf_dw d = {};
+  d.g_off = uniform_u32(tab + offsetof(yf_table_index, dw) + i * sizeof(yf_dw));
+  return d;
+}
+__device__ __forceinline__ int load_halo_zp(const uint8_t* tab, int i) {
+  return (int)uniform_u32(tab + offsetof(yf_table_index, halo_zp) + 4 * i);
+}
 
 // ------------------------------------------------------------------------------------------------ halo fill
 // RING: 1-pixel border all round (SAME 3x3 stride 1); otherwise top row + left column (explicit PAD, stride 2)
@@ -216,72 +233,6 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, cons
   }
 }
 
-// ------------------------------------------------------------------------------------------------ dense 1x1 stage
-// BD pixel sets per MFMA (block-diagonal A): BD=1: <=16 channels x K<=64, BD=2: <=8 x K<=32, BD=4: <=4 x K<=16.
-template <int F, int NW, int BD, class IN, class OUT, int OUT_CH0, int COUT, int KROW, int EPI, int LUT_ID, class ADDB>
-YF_STAGE_FN void dense_stage(char* frames, const uint8_t* luts, char* out_all,
-                                            const uint8_t* __restrict__ tab, const yf_dense d, const AddCtx ad,
-                                            int wave, int lane) {
-  constexpr int NCHT = 16 / BD;
-  constexpr int COUT_PAD4 = (COUT + 3) & ~3;
-  constexpr int NTL = (COUT + NCHT - 1) / NCHT;
-  constexpr int PIX_T = 16 * BD;
-  constexpr int P = IN::P;
-  constexpr int TOT = F * P;
-  constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
-  constexpr int JOBS = NTL * MT;
-  constexpr int JPW = (JOBS + NW - 1) / NW;
-  constexpr int RW = IN::S >= 16 ? 16 : IN::S;          // bytes of the pixel vector one lane supplies
-  static_assert(OUT::P == P, "1x1 conv keeps the grid");
-  static_assert(KROW <= 64 / BD, "k does not fit the block");
-  const int g = lane >> 4, c = lane & 15;
-  const int set = g * BD / 4;
-  const int kg = g % (4 / BD);
-  const int koff = kg * 16;
-  const int j0 = wave * JPW;
-  const int j1 = min(j0 + JPW, JOBS);
-  int cur_nt = -1;
-  v4i afrag = {0, 0, 0, 0};
-  int bias[4] = {0, 0, 0, 0}, mult[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
-  int chq = 0;
-  for (int j = j0; j < j1; ++j) {
-    const int nt = j / MT, mt = j - nt * MT;
-    if (nt != cur_nt) {
-      cur_nt = nt;
-      const int ch = nt * NCHT + (c % NCHT);
-      const bool a_on = (c / NCHT == set) && (ch < COUT_PAD4) && (koff < KROW);
-      afrag = v4i{0, 0, 0, 0};
-      if (a_on) afrag = *reinterpret_cast<const v4i*>(tab + d.w_off + ch * KROW + koff);
-      chq = nt * NCHT + 4 * kg;
-      const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off) + min(chq, COUT_PAD4 - 4);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int4 t = *reinterpret_cast<const int4*>(cp + jj);
-        bias[jj] = t.x; mult[jj] = t.y; kc[jj] = t.z; rs[jj] = t.w;
-      }
-    }
-    const int q = mt * PIX_T + set * 16 + c;
-    const int qc = min(q, TOT - 1);
-    const int f = qc / P, p = qc - f * P;
-    char* fbase = frames + f * FRAME_BYTES;
-    v4i b = {0, 0, 0, 0};
-    if (koff < KROW && koff < IN::S) {
-      const char* src = fbase + IN::at_p(p) + koff;
-      if constexpr (RW == 16) b = *reinterpret_cast<const v4i*>(src);
-      else if constexpr (RW == 8) { const int2 t = *reinterpret_cast<const int2*>(src); b[0] = t.x; b[1] = t.y; }
-      else b[0] = *reinterpret_cast<const int*>(src);
-    }
-    v4i acc = {bias[0], bias[1], bias[2], bias[3]};
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag, b, acc, 0, 0, 0);
-    if (q < TOT && chq < COUT_PAD4) {
-      int y[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
-      epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, chq, y, ad);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ dense 1x1, BD = 4
 // The skinny-K layers (K <= 16: conv2d_5/6/13/19/30/36/42).  64 pixels per MFMA, 4 output channels per tile.
 // A job = one 64-pixel m-tile x TPJ consecutive 4-channel tiles: pixel index arithmetic, the B fragment and the
@@ -345,6 +296,73 @@ YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* 
           else
             v = pack4(clampi(y0, -128, 127), clampi(y1, -128, 127), clampi(y2, -128, 127), clampi(y3, -128, 127));
           *reinterpret_cast<uint32_t*>(dst + nt * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dense 1x1, lane-private
+// Generalisation of the BD = 4 form to any K: the lane's own pixel supplies KS fragments of 16 bytes (k-steps), the A
+// operand of k-step ks carries W[4*pass + (r&3)][16*ks ..] in row r's own slot group only, and KS MFMAs accumulate the
+// 4 channels of one pass for 64 pixels.  Every lane owns ONE pixel: no lane is wasted when Cout is not a multiple of
+// 16 (conv2d_17: 6, conv2d_34/40: 8, head: 18), the constants of a pass are wave-uniform scalars, and the pixel math
+// is shared by the TPJ passes of a job.  MFMA count grows (KS per 4 channels) but the matrix pipe is idle anyway.
+template <int F, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB>
+YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all, const uint8_t* __restrict__ tab,
+                                const yf_dense d, const AddCtx ad, int wave, int lane) {
+  constexpr int NP = (COUT + 3) / 4;                        // passes of 4 output channels
+  constexpr int NCH = (NP + TPJ - 1) / TPJ;
+  constexpr int P = IN::P, TOT = F * P;
+  constexpr int MT = (TOT + 63) / 64;
+  constexpr int JOBS = NCH * MT;
+  constexpr int JPW = (JOBS + NW - 1) / NW;
+  constexpr int KROW = 16 * KS;
+  static_assert(OUT::P == P || EPI == EPI_HEAD, "1x1 conv keeps the grid");
+  static_assert(IN::S >= KROW, "the pixel vector must cover all k-steps");
+  const int g = lane >> 4, c = lane & 15;
+  const int j0 = wave * JPW, j1 = min(j0 + JPW, JOBS);
+  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
+  const bool a_on = (c >> 2) == g;
+  int cur_chunk = -1;
+  v4i a[TPJ][KS];
+  for (int j = j0; j < j1; ++j) {
+    const int chunk = j / MT, mt = j - chunk * MT;
+    if (chunk != cur_chunk) {
+      cur_chunk = chunk;
+#pragma unroll
+      for (int t = 0; t < TPJ; ++t) {
+        const int ps = chunk * TPJ + t;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a[t][ks] = v4i{0, 0, 0, 0};
+          if (a_on && ps < NP) a[t][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks);
+        }
+      }
+    }
+    const int q = mt * 64 + lane;
+    const int qc = min(q, TOT - 1);
+    const int f = qc / P, p = qc - f * P;
+    char* fbase = frames + f * FRAME_BYTES;
+    v4i b[KS];
+    {
+      const char* src = fbase + IN::at_p(p);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
+    }
+#pragma unroll
+    for (int t = 0; t < TPJ; ++t) {
+      const int ps = chunk * TPJ + t;
+      if (ps < NP) {                                          // uniform
+        const I4 k0 = uniform_int4(cp + ps * 4), k1 = uniform_int4(cp + ps * 4 + 1), k2 = uniform_int4(cp + ps * 4 + 2),
+                 k3 = uniform_int4(cp + ps * 4 + 3);
+        v4i acc = {k0.x, k1.x, k2.x, k3.x};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
+        if (q < TOT) {
+          const int y[4] = {requant(acc[0], k0.y, k0.z, k0.w), requant(acc[1], k1.y, k1.z, k1.w),
+                            requant(acc[2], k2.y, k2.z, k2.w), requant(acc[3], k3.y, k3.z, k3.w)};
+          epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, ps * 4, y, ad);
         }
       }
     }
@@ -651,16 +669,15 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint8_t* __restrict__ tab = prm.tab;
-  const yf_table_index& ix = *reinterpret_cast<const yf_table_index*>(tab);   // uniform: scalar loads per stage
 
   for (int i = tid; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + ix.lut_off)[i];
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
 
   const long n_groups = (prm.n + F - 1) / F;
   const AddCtx no_add = {};
   auto addctx = [&](int k) {
-    const yf_add& a = ix.add[k];
-    return AddCtx{a.mo, a.kco, a.rso};
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddCtx{(int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   constexpr long DS = DumpOffsets::TOTAL;
 #define YF_SYNC() __syncthreads()
@@ -673,21 +690,21 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
     const long first = grp * F;
     YF_SYNC();                                                         // previous group's arena is dead
     stage_no = 0;
-    stage_input<F, NT>(frames, prm.in, first, prm.n, ix.in_zp, tid);
-    fill_halo<B_T1, true, F, NT>(frames, ix.halo_zp[YF_W_DW3], tid);
+    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid);
+    fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid);
     YF_SYNC();
     YF_STAGE_END()
-    conv1_stage<F, NW>(frames, luts, tab, ix.dense[YF_D_CONV1], wave, lane);                        // conv2d_1
+    conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), wave, lane);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, ix.dw[YF_W_DW3], wave, lane);   // conv2d_3
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
-    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, ix.dense[YF_D_C5], wave, lane);   // conv2d_5
+    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), wave, lane);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
-    fill_halo<B_T4, false, F, NT>(frames, ix.halo_zp[YF_W_DW10], tid);
-    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, ix.dense[YF_D_C6], wave, lane);   // conv2d_6
+    fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid);
+    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), wave, lane);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     pool8_h<F, NT>(frames, tid);                                                                   // pool_8 (h)
@@ -695,70 +712,70 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
     YF_STAGE_END()
     pool8_v<F, NT>(frames, luts, tid);                                                             // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, ix.dw[YF_W_DW10], wave, lane);   // conv2d_10
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
-    dense_stage<F, NW, 2, B_T6, B_T7, 0, 6, 32, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C12], no_add, wave, lane);  // conv2d_12
+    dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane);
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
-    fill_halo<B_T8, true, F, NT>(frames, ix.halo_zp[YF_W_DW15], tid);
-    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, ix.dense[YF_D_C13], wave, lane);  // conv2d_13
+    fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid);
+    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), wave, lane);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, ix.dw[YF_W_DW15], wave, lane);   // conv2d_15
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T9, B_T11, 0, 6, 48, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, ix.dense[YF_D_C17], addctx(YF_A_ADD18), wave, lane);  // conv2d_17 + eltwise_18
+    dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane);
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, ix.dense[YF_D_C19], wave, lane);  // conv2d_19 -> concat_22
+    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), wave, lane);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
-    fill_halo<B_T15, false, F, NT>(frames, ix.halo_zp[YF_W_DW27], tid);
-    dense_stage<F, NW, 1, B_T14, B_T15, 0, 24, 48, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, ix.dense[YF_D_C23], no_add, wave, lane);  // conv2d_23
+    fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid);
+    dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane);
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
     pool25<F, NT>(frames, luts, tid);                                                              // pool_25 + QUANTIZE#45
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, ix.dw[YF_W_DW27], wave, lane);   // conv2d_27
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane);   // conv2d_27
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
     YF_STAGE_END()
-    dense_stage<F, NW, 2, B_T17, B_T18, 0, 8, 32, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C29], no_add, wave, lane);  // conv2d_29
+    dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane);
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW32], tid);
-    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, ix.dense[YF_D_C30], wave, lane);  // conv2d_30
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
+    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), wave, lane);  // conv2d_30
     YF_SYNC(); YF_DUMP(B_T19, 40, T19)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, ix.dw[YF_W_DW32], wave, lane);   // conv2d_32
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane);   // conv2d_32
     YF_SYNC(); YF_DUMP(B_T20, 40, T20)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T20, B_T22, 0, 8, 48, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, ix.dense[YF_D_C34], addctx(YF_A_ADD35), wave, lane);  // conv2d_34 + eltwise_35
+    dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane);
     YF_SYNC(); YF_DUMP(B_T22, 8, T22)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW38], tid);
-    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, ix.dense[YF_D_C36], wave, lane);  // conv2d_36
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
+    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), wave, lane);  // conv2d_36
     YF_SYNC(); YF_DUMP(B_T19, 40, T23)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, ix.dw[YF_W_DW38], wave, lane);   // conv2d_38
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane);   // conv2d_38
     YF_SYNC(); YF_DUMP(B_T20, 40, T24)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T20, B_T26, 0, 8, 48, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, ix.dense[YF_D_C40], addctx(YF_A_ADD41), wave, lane);  // conv2d_40 + eltwise_41
+    dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane);
     YF_SYNC(); YF_DUMP(B_T26, 8, T26)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, ix.dense[YF_D_C42], wave, lane);  // conv2d_42 -> concat_46
+    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), wave, lane);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP(B_T30, 48, T30)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, ix.halo_zp[YF_W_DW49], tid);
-    dense_stage<F, NW, 1, B_T30, B_T19, 0, 40, 48, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, ix.dense[YF_D_C47], no_add, wave, lane);  // conv2d_47
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
+    dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane);
     YF_SYNC(); YF_DUMP(B_T19, 40, T31)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, ix.dw[YF_W_DW49], wave, lane);   // conv2d_49
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane);   // conv2d_49
     YF_SYNC(); YF_DUMP(B_T20, 40, T32)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T20, B_T33, 0, 32, 48, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C51], no_add, wave, lane);  // conv2d_51
+    dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane);
     YF_SYNC(); YF_DUMP(B_T33, 32, T33)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, B_T33, B_T33, 0, 18, 32, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, ix.dense[YF_D_C53], no_add, wave, lane);  // conv2d_53 (head)
+    dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane);
     YF_SYNC();
     {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
       const long valid = min((long)F, prm.n - first);
@@ -776,4 +793,4 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
 template <int F, int NW>
 constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
 
-}  // namespace yf
+}  // namespace YF_NS
