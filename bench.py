@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-wg", type=int, default=0)
     ap.add_argument("--waves-per-wg", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,15 +69,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     yf = importlib.import_module("stm32h7-yolo_amd")
     sharding = importlib.import_module("stm32h7-yolo_amd.sharding")
-    net = yf.Network(device=local_rank, frames_per_wg=args.frames_per_wg, waves_per_wg=args.waves_per_wg).init()
+    net = yf.Network(device=dev_index, frames_per_wg=args.frames_per_wg, waves_per_wg=args.waves_per_wg).init()
 
     n, n_total = FRAMES_PER_GPU, FRAMES_PER_GPU * world
     a, b = sharding.shard_range(n_total, rank, world)
@@ -93,16 +98,27 @@ def main():
     sp = stream.cuda_stream
 
     gathered = None
+    gathered_counts = gathered_dets = None
 
     def step(ev=None):
-        nonlocal gathered
+        nonlocal gathered, gathered_counts, gathered_dets
         if ev is not None:
             ev[0].record(stream)
         net.run_device(d_in.data_ptr(), d_heads.data_ptr(), n, sp)
         if ev is not None:
             ev[1].record(stream)
         net.decode_device(d_heads.data_ptr(), n, d_dets.data_ptr(), d_counts.data_ptr(), cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
-        gathered = sharding.all_gather_heads(d_heads, n_total) if world > 1 else d_heads
+        if world > 1:       # every rank ends up with all heads and all detection records (RCCL over xGMI)
+            if args.backend == "nccl":
+                gathered = sharding.all_gather_heads(d_heads, n_total)
+                gathered_counts = sharding.all_gather_rows(d_counts, n_total)
+                gathered_dets = sharding.all_gather_rows(d_dets, n_total)
+            else:           # rehearsal: same helper on host copies
+                gathered = sharding.all_gather_heads(d_heads.cpu(), n_total).to(dev)
+                gathered_counts = sharding.all_gather_rows(d_counts.cpu(), n_total).to(dev)
+                gathered_dets = sharding.all_gather_rows(d_dets.cpu(), n_total).to(dev)
+        else:
+            gathered = d_heads
 
     for _ in range(args.warmup):
         step()
@@ -118,7 +134,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
@@ -126,8 +142,9 @@ def main():
     heads = d_heads.cpu().numpy()
     ok_gather = True
     if world > 1:   # every rank must hold every rank's heads, in frame order
-        ok_gather = bool(torch.equal(gathered[a:b], d_heads))
-        flag = torch.tensor([int(ok_gather)], device=dev)
+        ok_gather = bool(torch.equal(gathered[a:b], d_heads)) and bool(torch.equal(gathered_counts[a:b], d_counts)) \
+            and bool(torch.equal(gathered_dets[a:b], d_dets))
+        flag = torch.tensor([int(ok_gather)], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_gather = bool(flag.item())
 
@@ -138,7 +155,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=4096 int8 YOLO-face 56x56x3 frames per GPU, fused LDS-resident "
-                                   "forward + GPU box decode" + (f" + RCCL all-gather of {n_total} heads" if world > 1 else ""),
+                                   "forward + GPU box decode" + (f" + RCCL all-gather of {n_total} heads and detection records" if world > 1 else ""),
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
                        "kernel": net.kernel_name, "parallelism": f"batch-shard x{world}, all-gather heads" if world > 1 else "single GPU"},
         }

@@ -162,6 +162,36 @@ YF_API ai_bool   ai_platform_bind_network_params(ai_handle network, ai_network_p
                                                  const ai_buffer_array* map_weights,
                                                  const ai_buffer_array* map_activations);
 
+/* ------------------------------------------------------------------ Part 1b: runtime-level boundary ------
+ * The symbols of ST's closed runtime that the reference's GENERATED network.c references (nm -u of network.c built
+ * for x86-64): with these exported, network.c itself compiles and links unchanged and only the ST runtime library is
+ * replaced (csrc/platform_abi.c).  `ai_network*` / `ai_context*` are opaque here (void*).
+ * Replaces ai_platform_interface.h:786-966; the forward_* / nl_func / ai_sum_* kernels (layers_conv2d.h:192,
+ * layers_pool.h:374, layers_generic.h:494,598, layers_nl.h:606, ai_math_helpers.h) are placeholders that are
+ * referenced as function pointers by network.c's layer tables and never called. */
+YF_API void*     ai_platform_context_acquire(const ai_handle handle);
+YF_API ai_error  ai_platform_network_create(ai_handle* network, const ai_buffer* network_config, void* net_ctx,
+                                            const ai_u8 tool_major, const ai_u8 tool_minor, const ai_u8 tool_micro);
+YF_API ai_handle ai_platform_network_destroy(ai_handle network);
+YF_API ai_error  ai_platform_network_get_error(ai_handle network);
+YF_API void*     ai_platform_network_init(ai_handle network, const ai_network_params* params);
+YF_API ai_bool   ai_platform_network_post_init(ai_handle network);
+YF_API ai_i32    ai_platform_network_process(ai_handle network, const ai_buffer* input, ai_buffer* output);
+YF_API ai_bool   ai_platform_get_weights_map(uint8_t** map, const uint32_t map_size, const ai_network_params* params);
+YF_API ai_bool   ai_platform_get_activations_map(uint8_t** map, const uint32_t map_size, const ai_network_params* params);
+YF_API ai_bool   ai_platform_api_get_network_report(ai_handle network, ai_network_report* r);
+YF_API const char* ai_platform_runtime_get_revision(void);
+YF_API ai_platform_version ai_platform_runtime_get_version(void);
+YF_API ai_platform_version ai_platform_api_get_version(void);
+YF_API ai_platform_version ai_platform_interface_api_get_version(void);
+YF_API void      forward_conv2d_integer_SSSA_ch(void* layer);
+YF_API void      forward_mp_integer_INT8(void* layer);
+YF_API void      forward_eltwise_integer_INT8(void* layer);
+YF_API void      forward_concat(void* layer);
+YF_API void      nl_func_array_integer(void);
+YF_API void      ai_sum_f32(void);
+YF_API void      ai_sum_buffer_INT8(void);
+
 /* ------------------------------------------------------------------ Part 2: extensions ------------------- */
 typedef struct yf_det_ {      /* one detection; mirrors the fields printed at yoloface.c:148 / drawn at tflite_prediction.py:63 */
   int32_t frame;

@@ -83,7 +83,15 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes",
            "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_last_error_text", "yf_network_kernel_name"]
+           "yf_network_time_stages", "yf_network_last_error_text", "yf_network_kernel_name",
+           # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
+           "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
+           "ai_platform_network_get_error", "ai_platform_network_init", "ai_platform_network_post_init",
+           "ai_platform_network_process", "ai_platform_get_weights_map", "ai_platform_get_activations_map",
+           "ai_platform_api_get_network_report", "ai_platform_runtime_get_revision", "ai_platform_runtime_get_version",
+           "ai_platform_api_get_version", "ai_platform_interface_api_get_version", "forward_conv2d_integer_SSSA_ch",
+           "forward_mp_integer_INT8", "forward_eltwise_integer_INT8", "forward_concat", "nl_func_array_integer",
+           "ai_sum_f32", "ai_sum_buffer_INT8"]
 
 
 def build(force=False):

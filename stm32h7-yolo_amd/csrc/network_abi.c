@@ -12,6 +12,7 @@
 #include "../../include/yf_network.h"
 #include "yf_engine.h"
 #include "yf_host_prep.h"
+#include "yf_impl.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,7 +42,7 @@ static void latch(yf_context* c, unsigned type, unsigned code, const char* text)
 static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = type; e.code = code; return e; }
 
 /* ------------------------------------------------------------------------------------------------ create / destroy */
-YF_API ai_error ai_network_create(ai_handle* network, const ai_buffer* network_config) {
+ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
   if (!network) return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_INVALID_PTR);
   if (network_config != NULL) { *network = AI_HANDLE_NULL; return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_NETWORK); }
   if (g_network.state == ST_READY && g_network.engine) { yf_engine_destroy(g_network.engine); }
@@ -54,7 +55,7 @@ YF_API ai_error ai_network_create(ai_handle* network, const ai_buffer* network_c
   return mk_error(AI_ERROR_NONE, AI_ERROR_CODE_NONE);
 }
 
-YF_API ai_handle ai_network_destroy(ai_handle network) {
+ai_handle yf_impl_destroy(ai_handle network) {
   yf_context* c = acquire(network);
   if (!c) return network;                       /* not destroyed: same handle comes back (network.h:155-157) */
   if (c->engine) yf_engine_destroy(c->engine);
@@ -62,7 +63,7 @@ YF_API ai_handle ai_network_destroy(ai_handle network) {
   return AI_HANDLE_NULL;
 }
 
-YF_API ai_error ai_network_get_error(ai_handle network) {
+ai_error yf_impl_get_error(ai_handle network) {
   yf_context* c = acquire(network);
   if (!c) return mk_error(AI_ERROR_INVALID_HANDLE, AI_ERROR_CODE_NETWORK);
   const ai_error e = c->first_error;
@@ -76,7 +77,7 @@ static size_t buffer_elems(const ai_buffer* b) { return (size_t)b->height * b->w
 /* The weights arrive either as the legacy {params, activations} pair whose params.data points at the
  * {AI_MAGIC_MARKER, blob, AI_MAGIC_MARKER} pointer map (network_data.c:395-401, used by yoloface.c:199-202), or as
  * the signed ai_buffer_array map produced by ai_network_data_params_get (network_data.c:412-432). */
-static const uint8_t* resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act) {
+const uint8_t* yf_impl_resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act) {
   if (p->map_signature == (ai_signature)AI_MAGIC_SIGNATURE) {
     if (p->map_weights.size < 1 || !p->map_weights.buffer) return NULL;
     const ai_buffer* wb = &p->map_weights.buffer[0];
@@ -96,13 +97,13 @@ static const uint8_t* resolve_weights(const ai_network_params* p, size_t* bytes,
   return (const uint8_t*)wb->data;                /* bare blob pointer */
 }
 
-YF_API ai_bool ai_network_init(ai_handle network, const ai_network_params* params) {
+ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
   yf_context* c = acquire(network);
   if (!c) return false;
   if (!params) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, "params is NULL"); return false; }
   size_t wbytes = 0;
   const ai_buffer* act = NULL;
-  const uint8_t* blob = resolve_weights(params, &wbytes, &act);
+  const uint8_t* blob = yf_impl_resolve_weights(params, &wbytes, &act);
   if (!blob) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, "weights buffer/map is invalid"); return false; }
   if (wbytes < AI_NETWORK_DATA_WEIGHTS_SIZE) { latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_INVALID_SIZE, "weights buffer smaller than 11304 bytes"); return false; }
   /* the activations arena is caller-owned scratch on the MCU; here activations live in LDS.  It is accepted and
@@ -161,19 +162,19 @@ static ai_i32 process(ai_handle network, const ai_buffer* input, ai_buffer* outp
   return (ai_i32)n;
 }
 
-YF_API ai_i32 ai_network_run(ai_handle network, const ai_buffer* input, ai_buffer* output) {
+ai_i32 yf_impl_run(ai_handle network, const ai_buffer* input, ai_buffer* output) {
   yf_context* c = acquire(network);
   if (c && !output) { latch(c, AI_ERROR_INVALID_OUTPUT, AI_ERROR_CODE_INVALID_PTR, "output is NULL"); return 0; }
   return process(network, input, output);
 }
 
-YF_API ai_i32 ai_network_forward(ai_handle network, const ai_buffer* input) { return process(network, input, NULL); }
+ai_i32 yf_impl_forward(ai_handle network, const ai_buffer* input) { return process(network, input, NULL); }
 
 /* ------------------------------------------------------------------------------------------------ report */
 static ai_buffer g_io_in = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_IN_1_HEIGHT, AI_NETWORK_IN_1_WIDTH, AI_NETWORK_IN_1_CHANNEL, NULL, NULL };
 static ai_buffer g_io_out = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_OUT_1_HEIGHT, AI_NETWORK_OUT_1_WIDTH, AI_NETWORK_OUT_1_CHANNEL, NULL, NULL };
 
-YF_API ai_bool ai_network_get_report(ai_handle network, ai_network_report* report) {
+ai_bool yf_impl_get_report(ai_handle network, ai_network_report* report) {
   yf_context* c = acquire(network);
   if (!c || !report) return false;
   memset(report, 0, sizeof *report);
@@ -200,7 +201,20 @@ YF_API ai_bool ai_network_get_report(ai_handle network, ai_network_report* repor
   return true;
 }
 
-YF_API ai_bool ai_network_get_info(ai_handle network, ai_network_report* report) { return ai_network_get_report(network, report); }
+
+
+/* ------------------------------------------------------------------------------------------------ public boundary
+ * Thin wrappers: the implementations above carry private names so that the runtime-level entry points
+ * (platform_abi.c) can reach them even when an application links the reference's own network.c, whose
+ * ai_network_* definitions then take precedence over the ones exported here. */
+YF_API ai_error  ai_network_create(ai_handle* network, const ai_buffer* network_config) { return yf_impl_create(network, network_config); }
+YF_API ai_handle ai_network_destroy(ai_handle network) { return yf_impl_destroy(network); }
+YF_API ai_error  ai_network_get_error(ai_handle network) { return yf_impl_get_error(network); }
+YF_API ai_bool   ai_network_init(ai_handle network, const ai_network_params* params) { return yf_impl_init(network, params); }
+YF_API ai_i32    ai_network_run(ai_handle network, const ai_buffer* input, ai_buffer* output) { return yf_impl_run(network, input, output); }
+YF_API ai_i32    ai_network_forward(ai_handle network, const ai_buffer* input) { return yf_impl_forward(network, input); }
+YF_API ai_bool   ai_network_get_report(ai_handle network, ai_network_report* report) { return yf_impl_get_report(network, report); }
+YF_API ai_bool   ai_network_get_info(ai_handle network, ai_network_report* report) { return yf_impl_get_report(network, report); }
 
 /* ------------------------------------------------------------------------------------------------ network_data */
 YF_API ai_handle ai_network_data_weights_get(void) {

@@ -1,0 +1,13 @@
+/* Private names of the boundary implementation (network_abi.c), shared with the runtime-level layer (platform_abi.c). */
+#ifndef YF_IMPL_H
+#define YF_IMPL_H
+#include "../../include/yf_network.h"
+ai_error  yf_impl_create(ai_handle* network, const ai_buffer* network_config);
+ai_handle yf_impl_destroy(ai_handle network);
+ai_error  yf_impl_get_error(ai_handle network);
+ai_bool   yf_impl_init(ai_handle network, const ai_network_params* params);
+ai_i32    yf_impl_run(ai_handle network, const ai_buffer* input, ai_buffer* output);
+ai_i32    yf_impl_forward(ai_handle network, const ai_buffer* input);
+ai_bool   yf_impl_get_report(ai_handle network, ai_network_report* report);
+const uint8_t* yf_impl_resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act);
+#endif

@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include "yf_tables.h"
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // absolute LDS addresses (device); the host pass only parses them
 namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
@@ -818,3 +820,4 @@ template <int F, int NW>
 constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
 
 }  // namespace YF_NS
+#pragma clang diagnostic pop

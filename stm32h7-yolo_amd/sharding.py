@@ -13,7 +13,8 @@ def shard_range(n, rank, world):
 
 
 def all_gather_heads(local_heads, n_total, group=None):
-    """local_heads: int8 tensor [n_local, 7, 7, 18] on this rank's device -> [n_total, 7, 7, 18] on every rank.
+    """local_heads: tensor [n_local, ...] on this rank's device (int8 heads [n,7,7,18], or any per-frame record
+    array such as detection records [n, cap, 28] / counts [n]) -> [n_total, ...] on every rank.
     Uneven shards are padded to the largest shard for the fixed-shape collective and trimmed afterwards."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
@@ -27,3 +28,6 @@ def all_gather_heads(local_heads, n_total, group=None):
     if all(b - a == cap for a, b in sizes):
         return out
     return torch.cat([out[r * cap: r * cap + (b - a)] for r, (a, b) in enumerate(sizes)], dim=0)
+
+
+all_gather_rows = all_gather_heads      # same collective for per-frame detection records and counts

@@ -69,6 +69,30 @@ def test_reference_network_data_links_against_library():
                       "ai_network_init", "ai_network_run", "ai_platform_bind_network_params"]
 
 
+@pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
+def test_reference_generated_network_c_links_against_library(yf):
+    """Runtime-level drop-in: the reference's GENERATED network.c, unchanged, resolves every
+    ST-runtime symbol it references (ai_platform_*, forward_*, nl_func_array_integer, ai_sum_*) from this library."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_ref_runtime_caller")
+    undefined = subprocess.check_output(["nm", "-u", exe]).decode()
+    needed = sorted(set(re.findall(r"U ((?:ai_|forward_|nl_func)\w+)", undefined)))
+    obj = subprocess.check_output(["bash", "-c", "gcc -std=gnu11 -c /root/reference/stm32/X-CUBE-AI/App/network.c "
+                                   "-I/root/reference/stm32/X-CUBE-AI/App -I/root/reference/stm32/Middlewares/ST/AI/Inc "
+                                   "-o /tmp/_yf_network_ref.o && nm -u /tmp/_yf_network_ref.o"]).decode()
+    wanted = sorted(set(re.findall(r"U ((?:ai_|forward_|nl_func)\w+)", obj)) | {"ai_platform_bind_network_params"})
+    assert needed == wanted and len(wanted) == 22
+    lib = yf.load()
+    for n in wanted:
+        assert hasattr(lib, n)
+    # without a GPU the binary fails the way the firmware would report it: init error type 0x30
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), "/tmp/_yf_heads.bin", "6"],
+                           capture_output=True, text=True)
+        assert r.returncode == 4 and "type=48" in r.stdout
+
+
 def _no_gpu():
     import torch
     return not torch.cuda.is_available()

@@ -278,12 +278,15 @@ def test_interpreter_mirror(oracle, golden, network):
     network.init()            # the mirror re-initialised the singleton; leave it ready for later tests
 
 
-def test_reference_header_caller_binary(golden, tmp_path):
-    """oracle/_ref/abi_ref_caller = reference network_data.c + a caller on the reference's headers, linked against
-    libyf_network.so in the build container (oracle/Makefile.ref).  Both initialisation forms."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "abi_ref_caller")
+@pytest.mark.parametrize("binary", ["abi_ref_caller", "abi_ref_runtime_caller"])
+def test_reference_header_caller_binary(golden, tmp_path, binary):
+    """oracle/_ref/abi_ref_caller = reference network_data.c + a caller on the reference's headers;
+    oracle/_ref/abi_ref_runtime_caller additionally compiles the reference's GENERATED network.c unchanged, so only
+    the ST runtime library is replaced.  Both linked against libyf_network.so in the build container
+    (oracle/Makefile.ref); both initialisation forms."""
+    exe = os.path.join(ROOT, "oracle", "_ref", binary)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/abi_ref_caller was not built (needs /root/reference at build time)")
+        pytest.skip(f"oracle/_ref/{binary} was not built (needs /root/reference at build time)")
     fin = os.path.join(ROOT, "tests", "golden", "golden_inputs.bin")
     for extra in ([], ["map"]):
         fout = str(tmp_path / "heads.bin")
