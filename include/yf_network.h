@@ -215,6 +215,10 @@ YF_API long yf_network_run_device(ai_handle network, const void* d_in, void* d_o
  * reference observer API, ai_platform_interface.h:684-731).  d_dump int8[n][yf_network_dump_bytes()]. */
 YF_API long yf_network_run_device_dump(ai_handle network, const void* d_in, void* d_out, void* d_dump, long n, void* stream);
 YF_API long yf_network_dump_bytes(void);
+/* The network is fully convolutional; the reference ABI fixes 56x56 (network.h:48-50).  This extension also runs
+ * 160x160 frames (BASELINE configs[4]): d_in int8[n][h][w][3] -> d_out int8[n][h/8][w/8][18].  56x56 takes the fused
+ * LDS-resident kernel, 160x160 runs the same stage code layer by layer over an HBM arena owned by the library. */
+YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, const void* d_in, void* d_out, long n, void* stream);
 /* Box decode on the GPU from device-resident heads: d_dets yf_det[n][cap], d_counts int32[n] (true count, may
  * exceed cap).  mode = YF_DECODE_PY or YF_DECODE_FW. */
 YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,

@@ -81,7 +81,7 @@ assert DET_DTYPE.itemsize == ctypes.sizeof(YfDet) == 28
 EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network_forward", "ai_network_get_error",
            "ai_network_destroy", "ai_network_get_info", "ai_network_get_report", "ai_network_data_weights_get",
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
-           "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes",
+           "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_last_error_text", "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
@@ -144,6 +144,8 @@ def load():
     lib.yf_network_run_device_dump.restype = cl
     lib.yf_network_run_device_dump.argtypes = [vp, vp, vp, vp, cl, vp]
     lib.yf_network_dump_bytes.restype = cl
+    lib.yf_network_run_device_hw.restype = cl
+    lib.yf_network_run_device_hw.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, cl, vp]
     lib.yf_network_decode_device.restype = cl
     lib.yf_network_decode_device.argtypes = [vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
@@ -228,6 +230,10 @@ class Network:
             rc = self.lib.yf_network_run_device_dump(self.handle, d_in, d_out, d_dump, n, stream)
         if rc != n:
             self._raise("yf_network_run_device")
+
+    def run_device_hw(self, h, w, d_in, d_out, n, stream=None):
+        if self.lib.yf_network_run_device_hw(self.handle, h, w, d_in, d_out, n, stream) != n:
+            self._raise("yf_network_run_device_hw")
 
     def decode_device(self, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
         if self.lib.yf_network_decode_device(self.handle, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:

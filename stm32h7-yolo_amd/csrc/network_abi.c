@@ -292,6 +292,15 @@ YF_API long yf_network_run_device_dump(ai_handle network, const void* d_in, void
 
 YF_API long yf_network_dump_bytes(void) { return yf_engine_dump_bytes(); }
 
+YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, const void* d_in, void* d_out, long n, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  if (height == 56 && width == 56) return finish(c, yf_engine_run_device(c->engine, d_in, d_out, NULL, n, stream), n);
+  if (height == 160 && width == 160) return finish(c, yf_engine_run_device_160(c->engine, d_in, d_out, n, stream), n);
+  latch(c, AI_ERROR_INVALID_INPUT, AI_ERROR_CODE_INVALID_SIZE, "supported input sizes: 56x56 (fused) and 160x160 (layer-by-layer)");
+  return 0;
+}
+
 YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                                      void* d_dets, void* d_counts, int cap, void* stream) {
   yf_context* c = ready(network);

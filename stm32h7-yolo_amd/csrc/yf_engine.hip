@@ -17,6 +17,18 @@
 #include "yf_kernels.hip.h"
 #undef YF_NS
 #undef YF_EXP
+#undef YF_STAGE_FN
+#undef YF_H0
+// 160x160 (BASELINE configs[4]): same stage code, layer by layer over an HBM arena
+#define YF_NS yf160
+#define YF_EXP 0
+#define YF_H0 160
+#define YF_GENERIC 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_EXP
+#undef YF_H0
+#undef YF_GENERIC
 #include "gen/yf_decode_tables_gen.h"
 #include "../../include/yf_network.h"   // yf_det, YF_DECODE_*
 
@@ -140,6 +152,7 @@ struct yf_engine {
   const Variant* var = nullptr;
   const Variant* var_dump = nullptr;
   void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
+  char* arena160 = nullptr; long arena160_frames = 0;
   hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -151,6 +164,18 @@ struct yf_engine {
 static const Variant* find_variant(int f, int nw, bool dump, bool dwm = true, bool exp = false) {
   for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.dwm == dwm && v.exp == exp) return &v;
   return nullptr;
+}
+
+// 160x160 variant: launches the 27 per-stage kernels in order
+template <int ST>
+static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned grid, hipStream_t s) {
+  if constexpr (ST < yf160::GEN_STAGES) {
+    hipLaunchKernelGGL((yf160::generic_stage_kernel<ST, 8>), dim3(grid), dim3(512), yf160::LUT_BYTES, s, prm);
+    { hipError_t rc_ = hipGetLastError(); if (rc_ != hipSuccess) { e->err = std::string("generic stage launch: ") + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } }
+    return launch160_from<ST + 1>(e, prm, grid, s);
+  } else {
+    return YF_ENG_OK;
+  }
 }
 
 extern "C" {
@@ -192,6 +217,7 @@ void yf_engine_destroy(yf_engine* e) {
   if (e->d_tab) (void)hipFree(e->d_tab);
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_out) (void)hipFree(e->d_out);
+  if (e->arena160) (void)hipFree(e->arena160);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -270,6 +296,31 @@ int yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, i
   float ms = 0.f;
   HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
   *ms_per_launch = ms / iters;
+  return YF_ENG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- 160x160 variant
+int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n, void* stream) {
+  if (!e || !d_in || !d_out || n < 0) return YF_ENG_ERR_ARG;
+  if (n == 0) return YF_ENG_OK;
+  if (((uintptr_t)d_in & 3) != 0 || ((uintptr_t)d_out & 1) != 0) { e->err = "input must be 4-byte, output 2-byte aligned"; return YF_ENG_ERR_ARG; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const long cap = n < 1024 ? n : 1024;                       // frames per chunk (~0.86 MB of arena each)
+  if (cap > e->arena160_frames) {
+    if (e->arena160) (void)hipFree(e->arena160);
+    e->arena160 = nullptr; e->arena160_frames = 0;
+    HIPCHK(e, hipMalloc((void**)&e->arena160, (size_t)cap * yf160::FRAME_BYTES));
+    e->arena160_frames = cap;
+  }
+  for (long done = 0; done < n; done += cap) {
+    const long m = (n - done) < cap ? (n - done) : cap;
+    yf160::GenParams prm;
+    prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
+    prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
+    prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
+    const int rc = launch160_from<0>(e, prm, (unsigned)m, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   return YF_ENG_OK;
 }
 

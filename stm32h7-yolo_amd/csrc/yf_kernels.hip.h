@@ -38,9 +38,11 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------ LDS plan
 // Per-frame arena (bytes).  Buffers alias by lifetime; see DESIGN.md "LDS plan" for the liveness table.
+#if !defined(YF_H0) || YF_H0 == 56
 constexpr int FRAME_BYTES = 34176;
+#endif
 constexpr int LUT_BYTES = YF_N_LUT * 256 + YF_ADDLUT_BYTES;    // byte LUTs, then the int32 add tables
-constexpr int OUT_FRAME_BYTES = 882;
+
 
 // Buf: OFF byte offset in the frame arena, logical W x H, S bytes per pixel, RS pixels per row (incl. halo),
 // PT/PL halo rows/cols in front of logical pixel (0,0).
@@ -55,6 +57,14 @@ struct Buf {
   }
 };
 
+#ifndef YF_H0
+#define YF_H0 56                               // input height = width; the network is fully convolutional
+#endif
+constexpr int G0 = YF_H0, G1 = G0 / 2, G2 = G0 / 4, G3 = G0 / 8;   // grids: input, after conv2d_1, after pool_8, after pool_25
+static_assert(G0 % 8 == 0 && G3 >= 4, "input size must be a multiple of 8 and at least 32");
+
+#if YF_H0 == 56
+// LDS-resident plan for 56x56 (hand-placed, buffers alias by lifetime)
 //                 OFF    W   H   S  RS PT PL
 typedef Buf<    0, 56, 56,  4, 60, 1, 4> B_IN;    // RGBX dwords, top halo row, halo column at dword 3
 typedef Buf<13696, 28, 28,  8, 30, 1, 1> B_T1;    // conv2d_1 out (+LeakyReLU), halo ring for dw3
@@ -77,6 +87,43 @@ typedef Buf<12976,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
 typedef Buf<15328,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
 typedef Buf<15720,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
 typedef Buf<16112,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
+#else
+// Any other size: the same buffers laid out one after another in a per-frame HBM arena (nothing aliases; 64 bytes
+// of slack behind each buffer absorb the depthwise stage's harmless over-reads on masked lanes).
+constexpr int arena_next(int off, int bytes) { return (off + bytes + 64 + 63) & ~63; }
+#define YF_SEQ(NAME, PREV_END, W_, H_, S_, RS_, PT_, PL_, ROWS_)                      \
+  constexpr int NAME##_OFF = PREV_END;                                                \
+  typedef Buf<NAME##_OFF, W_, H_, S_, RS_, PT_, PL_> NAME;                            \
+  constexpr int NAME##_END = arena_next(NAME##_OFF, (ROWS_) * (RS_) * (S_));
+YF_SEQ(B_IN,  0,         G0, G0,  4, G0 + 4, 1, 4, G0 + 1)
+YF_SEQ(B_T1,  B_IN_END,  G1, G1,  8, G1 + 2, 1, 1, G1 + 2)
+YF_SEQ(B_T2,  B_T1_END,  G1, G1,  8, G1,     0, 0, G1)
+YF_SEQ(B_T3,  B_T2_END,  G1, G1,  4, G1,     0, 0, G1)
+YF_SEQ(B_T4,  B_T3_END,  G1, G1, 20, G1 + 1, 1, 1, G1 + 1)
+YF_SEQ(B_HB,  B_T4_END,  G2, G1, 20, G2,     0, 0, G1)
+YF_SEQ(B_T14, B_HB_END,  G2, G2, 48, G2,     0, 0, G2)
+YF_SEQ(B_T6,  B_T14_END, G2, G2, 32, G2,     0, 0, G2)
+YF_SEQ(B_T7,  B_T6_END,  G2, G2,  8, G2,     0, 0, G2)
+YF_SEQ(B_T8,  B_T7_END,  G2, G2, 36, G2 + 2, 1, 1, G2 + 2)
+YF_SEQ(B_T9,  B_T8_END,  G2, G2, 48, G2,     0, 0, G2)
+YF_SEQ(B_T11, B_T9_END,  G2, G2,  8, G2,     0, 0, G2)
+YF_SEQ(B_T15, B_T11_END, G2, G2, 24, G2 + 1, 1, 1, G2 + 1)
+YF_SEQ(B_T30, B_T15_END, G3, G3, 48, G3,     0, 0, G3)
+YF_SEQ(B_T17, B_T30_END, G3, G3, 32, G3,     0, 0, G3)
+YF_SEQ(B_T18, B_T17_END, G3, G3,  8, G3,     0, 0, G3)
+YF_SEQ(B_T19, B_T18_END, G3, G3, 40, G3 + 2, 1, 1, G3 + 2)
+YF_SEQ(B_T20, B_T19_END, G3, G3, 48, G3,     0, 0, G3)
+YF_SEQ(B_T22, B_T20_END, G3, G3,  8, G3,     0, 0, G3)
+YF_SEQ(B_T26, B_T22_END, G3, G3,  8, G3,     0, 0, G3)
+YF_SEQ(B_T33, B_T26_END, G3, G3, 32, G3,     0, 0, G3)
+#undef YF_SEQ
+#endif
+
+#if YF_H0 != 56
+constexpr int FRAME_BYTES = B_T33_END;
+#endif
+constexpr int OUT_FRAME_BYTES = G3 * G3 * 18;
+constexpr int IN_FRAME_BYTES = G0 * G0 * 3;
 
 enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 
@@ -176,24 +223,25 @@ template <int F, int NT>
 YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long first_frame, long n_frames,
                                             int zp, int tid) {
   const uint32_t hv = (uint32_t)(zp & 255) * 0x01010101u;
-  // halo: row 0 (60 dwords) and dword column 3 of rows 1..56
-  for (int i = tid; i < F * (60 + 56); i += NT) {
-    const int f = i / 116, k = i - f * 116;
-    const int idx = k < 60 ? k : (k - 60 + 1) * 60 + 3;
+  constexpr int RSW = B_IN::RS, HH = B_IN::H, WQ = B_IN::W / 4;    // dwords per halo'd row, rows, 4-pixel items per row
+  // halo: row 0 (RSW dwords) and dword column 3 of rows 1..HH
+  for (int i = tid; i < F * (RSW + HH); i += NT) {
+    const int f = i / (RSW + HH), k = i - f * (RSW + HH);
+    const int idx = k < RSW ? k : (k - RSW + 1) * RSW + 3;
     *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B_IN::OFF + idx * 4) = hv;
   }
-  for (int i = tid; i < F * 784; i += NT) {
-    const int f = i / 784, r = i - f * 784;
+  for (int i = tid; i < F * HH * WQ; i += NT) {
+    const int f = i / (HH * WQ), r = i - f * (HH * WQ);
     long fi = first_frame + f; if (fi >= n_frames) fi = n_frames - 1;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + fi * 9408 + r * 12);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + fi * IN_FRAME_BYTES + r * 12);
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
     uint4 px;
     px.x = d0 & 0x00FFFFFFu;
     px.y = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
     px.z = (d1 >> 16) | ((d2 & 0xFFu) << 16);
     px.w = d2 >> 8;
-    const int y = r / 14, x4 = (r - y * 14) * 4;
-    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * 60 + x4 + 4) * 4) = px;
+    const int y = r / WQ, x4 = (r - y * WQ) * 4;
+    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * RSW + x4 + 4) * 4) = px;
   }
 }
 
@@ -400,7 +448,7 @@ YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all
 template <int F, int NW>
 YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
                                             const yf_dense d, int wave, int lane) {
-  constexpr int P = 784, TOT = F * P, PIX_T = 32;
+  constexpr int P = B_T1::P, W1 = B_T1::W, RSW = B_IN::RS, TOT = F * P, PIX_T = 32;
   constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
   constexpr int JPW = (MT + NW - 1) / NW;
   const int g = lane >> 4, c = lane & 15;
@@ -422,19 +470,19 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* _
     bias[jj] = t.x; mult[jj] = t.y; kc[jj] = t.z; rs[jj] = t.w;
   }
   // dword offsets of this lane's taps relative to IN[2oy][2ox+3]  (see yf_tables.h, conv2d_1 packing)
-  const int o0 = half ? 61 : 0, o1 = half ? 62 : 1, o2 = half ? 120 : 2, o3 = half ? 121 : 60;
+  const int o0 = half ? RSW + 1 : 0, o1 = half ? RSW + 2 : 1, o2 = half ? 2 * RSW : 2, o3 = half ? 2 * RSW + 1 : RSW;
   const int j0 = wave * JPW, j1 = min(j0 + JPW, MT);
   const AddCtx ad = {};
   for (int mt = j0; mt < j1; ++mt) {
     const int q = mt * PIX_T + set * 16 + c;
     const int qc = min(q, TOT - 1);
     const int f = qc / P, p = qc - f * P;
-    const int oy = p / 28, ox = p - oy * 28;
+    const int oy = p / W1, ox = p - oy * W1;
     char* fbase = frames + f * FRAME_BYTES;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * 60 + 2 * ox + 3);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
     v4i b0, b1 = {0, 0, 0, 0};
     b0[0] = (int)src[o0]; b0[1] = (int)src[o1]; b0[2] = (int)src[o2]; b0[3] = (int)src[o3];
-    b1[0] = (int)src[122];                        // (ky,kx) = (2,2); weight rows are zero for half 1 / other dwords
+    b1[0] = (int)src[2 * RSW + 2];                        // (ky,kx) = (2,2); weight rows are zero for half 1 / other dwords
     v4i acc = {bias[0], bias[1], bias[2], bias[3]};
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
@@ -506,7 +554,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
                                const yf_dw d, int wave, int lane) {
   constexpr int W = OUT::W, H = OUT::H;
   constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;       // frames side by side in the 16 lanes of a row tile
-  constexpr int NSEG = (W > 16) ? 2 : 1;                    // 16-column segments (28 -> x0 in {0, 12})
+  constexpr int NSEG = (W + 15) / 16;                       // 16-column segments, the last one shifted left (28 -> x0 in {0, 12})
   constexpr int NRB = (H + 3) / 4;                          // 4-row blocks (last one shifted up)
   constexpr int NG = (C + 3) / 4;
   constexpr int NFP = F / FL;
@@ -544,7 +592,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
       const int fp = rem / (NRB * NSEG); rem -= fp * (NRB * NSEG);
       const int rb = rem / NSEG, seg = rem - rb * NSEG;
       const int oy0 = min(rb * 4, H - 4);
-      const int x0 = seg ? (W - 16) : 0;
+      const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       char* fb = frames + fp * FL * FRAME_BYTES;
       const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
       v4i b0, b1, b2 = {0, 0, 0, 0};
@@ -580,15 +628,15 @@ struct SplitB {      // packed int8x4 as two int16x2 registers (odd bytes / even
   __device__ __forceinline__ uint32_t merge() const { return (o & 0xFF00FF00u) | ((e >> 8) & 0x00FF00FFu); }
 };
 // LOADC(k): packed dword at clamped coordinate k along the pooled axis; STORE(o, v): write output o.
-template <int NO, class LOADC, class STORE>
+template <int NO, int LIM, class LOADC, class STORE>
 __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
   constexpr int NP = NO + 4;                       // pairs o0-2 .. o0+NO+1
   SplitB ev[NP], od[NP];
 #pragma unroll
   for (int jj = 0; jj < NP; ++jj) {
     const int j = o0 - 2 + jj;
-    ev[jj] = SplitB(loadc(clampi(2 * j, 0, 27)));
-    od[jj] = SplitB(loadc(clampi(2 * j + 1, 0, 27)));
+    ev[jj] = SplitB(loadc(clampi(2 * j, 0, LIM)));
+    od[jj] = SplitB(loadc(clampi(2 * j + 1, 0, LIM)));
   }
   SplitB pm[NP];
 #pragma unroll
@@ -602,52 +650,55 @@ __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
 }
 template <int F, int NT>
 YF_STAGE_FN void pool8_h(char* frames, int tid) {
-  constexpr int NO = 4, NCH = 4;                   // output chunks at 0,4,8,10
-  for (int i = tid; i < F * 28 * NCH * 5; i += NT) {
+  constexpr int NO = 4, OW = B_HB::W, IH = B_T4::H, NCH = (OW + NO - 1) / NO;   // output chunks, the last shifted left
+  for (int i = tid; i < F * IH * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
-    const int y = t % 28; const int f = t / 28;
+    const int y = t % IH; const int f = t / IH;
     char* fbase = frames + f * FRAME_BYTES;
     const char* row = fbase + B_T4::at(y, 0) + 4 * cg;
-    char* dst = fbase + B_HB::OFF + (y * 14) * 20 + 4 * cg;
-    pool8_sweep<NO>(min(k * NO, 14 - NO),
-                    [&](int x) { return lds_u32(row + x * B_T4::S); },
-                    [&](int ox, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v; });
+    char* dst = fbase + B_HB::OFF + (y * OW) * 20 + 4 * cg;
+    pool8_sweep<NO, B_T4::W - 1>(min(k * NO, OW - NO),
+                                 [&](int x) { return lds_u32(row + x * B_T4::S); },
+                                 [&](int ox, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v; });
   }
 }
 template <int F, int NT>
 YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
-  constexpr int NO = 2, NCH = 7;
-  for (int i = tid; i < F * 14 * NCH * 5; i += NT) {
+  constexpr int NO = 2, OW = B_HB::W, OH = B_T14::H, NCH = OH / NO;
+  static_assert(OH % NO == 0, "even output height");
+  for (int i = tid; i < F * OW * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
-    const int ox = t % 14; const int f = t / 14;
+    const int ox = t % OW; const int f = t / OW;
     char* fbase = frames + f * FRAME_BYTES;
     const char* col = fbase + B_HB::OFF + ox * 20 + 4 * cg;
     char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
-    pool8_sweep<NO>(k * NO,
-                    [&](int r) { return lds_u32(col + r * (14 * 20)); },
-                    [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (14 * B_T14::S)) = lut4<YF_L_Q21>(v); });
+    pool8_sweep<NO, B_HB::H - 1>(k * NO,
+                                 [&](int r) { return lds_u32(col + r * (OW * 20)); },
+                                 [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4<YF_L_Q21>(v); });
   }
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
 template <int F, int NT>
 YF_STAGE_FN void pool25(char* frames, const uint8_t* luts, int tid) {
-  for (int i = tid; i < F * 49 * 6; i += NT) {
+  constexpr int PP = B_T30::P, OW = B_T30::W, LIM = B_T15::W - 1;
+  for (int i = tid; i < F * PP * 6; i += NT) {
     const int cg = i % 6; int t = i / 6;
-    const int p = t % 49; const int f = t / 49;
-    const int oy = p / 7, ox = p - oy * 7;
+    const int p = t % PP; const int f = t / PP;
+    const int oy = p / OW, ox = p - oy * OW;
     char* fbase = frames + f * FRAME_BYTES;
     ByteMax m;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
-        m.add(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, 13), clampi(2 * ox - 1 + kx, 0, 13)) + 4 * cg));
+        m.add(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg));
     *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4<YF_L_Q45>(m.get());
   }
 }
 
+#ifndef YF_GENERIC
 // ------------------------------------------------------------------------------------------------ debug dump
 // Observer-style per-stage dump (reference observer API, ai_platform_interface.h:684-731): logical NHWC bytes.
 template <class B, int C, int F, int NT>
@@ -818,6 +869,109 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
 
 template <int F, int NW>
 constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+
+#else   // YF_GENERIC
+// ------------------------------------------------------------------------------------------------ layer-by-layer form
+// For input sizes whose activations do not fit in LDS (160x160: conv2d_6's output alone is 131 KB) the SAME stage
+// functions run one kernel per fused stage over a per-frame arena in HBM (one workgroup per frame and stage, frames
+// grid-strided).  Results are bit-identical to the oracle at that size; HBM traffic is no longer the algorithmic
+// minimum -- fusing this variant with spatial tiles is later work.
+struct GenParams {
+  const int8_t* in;       // [n][G0][G0][3]
+  int8_t* out;            // [n][G3][G3][18]
+  long n;                 // frames in this launch (<= arena capacity)
+  const uint8_t* tab;
+  char* arena;            // n * FRAME_BYTES bytes of HBM scratch
+};
+constexpr int GEN_STAGES = 27;
+
+template <int ST, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenParams prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  for (int i = tid; i < LUT_BYTES / 16; i += NT)
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
+  __syncthreads();
+  const AddCtx no_add = {};
+  auto addctx = [&](int k) {
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddCtx{(int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso))};
+  };
+  for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
+    char* frames = prm.arena + fr * (long)FRAME_BYTES;
+    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
+    if constexpr (ST == 0) {
+      stage_input<F, NT>(frames, prm.in, fr, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid);
+      fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid);
+    } else if constexpr (ST == 1) {
+      conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), wave, lane);
+    } else if constexpr (ST == 2) {
+      dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane);
+    } else if constexpr (ST == 3) {
+      dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), wave, lane);
+    } else if constexpr (ST == 4) {
+      fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid);
+      dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), wave, lane);
+    } else if constexpr (ST == 5) {
+      pool8_h<F, NT>(frames, tid);
+    } else if constexpr (ST == 6) {
+      pool8_v<F, NT>(frames, luts, tid);
+    } else if constexpr (ST == 7) {
+      dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane);
+    } else if constexpr (ST == 8) {
+      dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane);
+    } else if constexpr (ST == 9) {
+      fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid);
+      dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), wave, lane);
+    } else if constexpr (ST == 10) {
+      dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane);
+    } else if constexpr (ST == 11) {
+      dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane);
+    } else if constexpr (ST == 12) {
+      dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), wave, lane);
+    } else if constexpr (ST == 13) {
+      fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid);
+      dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane);
+    } else if constexpr (ST == 14) {
+      pool25<F, NT>(frames, luts, tid);
+      dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane);
+    } else if constexpr (ST == 15) {
+      dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane);
+    } else if constexpr (ST == 16) {
+      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
+      dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), wave, lane);
+    } else if constexpr (ST == 17) {
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane);
+    } else if constexpr (ST == 18) {
+      dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane);
+    } else if constexpr (ST == 19) {
+      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
+      dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), wave, lane);
+    } else if constexpr (ST == 20) {
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane);
+    } else if constexpr (ST == 21) {
+      dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane);
+    } else if constexpr (ST == 22) {
+      dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), wave, lane);
+    } else if constexpr (ST == 23) {
+      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
+      dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane);
+    } else if constexpr (ST == 24) {
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane);
+    } else if constexpr (ST == 25) {
+      dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane);
+    } else {
+      static_assert(ST == 26, "stage index");
+      dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane);
+    }
+  }
+}
+#endif  // YF_GENERIC
 
 }  // namespace YF_NS
 #pragma clang diagnostic pop

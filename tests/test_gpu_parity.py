@@ -140,6 +140,39 @@ def test_full_size_32768_properties(network, oracle, torch_cuda):
         assert np.array_equal(got[k * 4096:(k + 1) * 4096], ref[p])
 
 
+def test_baseline_config5_160x160(network, oracle, torch_cuda):
+    """BASELINE.json configs[4]: 160x160 input, batch 1024 per GPU.  Same weights and quantisation (fully
+    convolutional); the oracle is the same C restatement at H=W=160 (head 20x20x18).  A 12-frame block (random,
+    constant and saturated frames) is compared bit for bit; the 1024-frame batch is shuffled copies of the block."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    block = rng.integers(-128, 128, (12, 160, 160, 3), dtype=np.int8)
+    block[1] = -128
+    block[2] = 127
+    block[3] = (block[3] // 32).astype(np.int8)
+    ref = oracle.run(block, threads=16)
+    assert ref.shape == (12, 20, 20, 18)
+    idx = rng.integers(0, 12, 1024)
+    idx[:12] = np.arange(12)
+    d_in = torch.from_numpy(block[idx]).cuda()
+    d_out = torch.full((1025, 20, 20, 18), 77, dtype=torch.int8, device="cuda")
+    network.run_device_hw(160, 160, d_in.data_ptr(), d_out.data_ptr(), 1024)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:1024], ref[idx])
+    assert (got[1024] == 77).all()
+    # the generic entry point also accepts 56x56 (fused kernel) and refuses other sizes with a latched error
+    x = rnd(77, 9)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((9, 7, 7, 18), dtype=torch.int8, device="cuda")
+    network.run_device_hw(56, 56, d_in.data_ptr(), d_out.data_ptr(), 9)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), oracle.run(x))
+    with pytest.raises(Exception) as ei:
+        network.run_device_hw(64, 64, d_in.data_ptr(), d_out.data_ptr(), 1)
+    assert (ei.value.type, ei.value.code) == (0x12, 0x18)
+
+
 def test_max_n_batches_65535_through_the_abi(network, oracle):
     """ai_buffer.n_batches is 16 bit (ai_platform.h:519): the largest single ai_network_run call."""
     lib = network.lib
