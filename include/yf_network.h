@@ -233,6 +233,12 @@ YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_
  * <= 0 or > 25 = whole network): the differences between successive stops give a per-stage time profile. */
 YF_API long yf_network_time_stages(ai_handle network, const void* d_in, void* d_out, long n, int iters, int stop_stage,
                                    void* stream, float* ms_per_launch);
+/* fp16 side configuration (BASELINE configs[3]): the reference's fp32 ONNX export (yoloface/pytorch/yoloface-50k.onnx)
+ * with fp16 weights/activations and fp32 accumulation, dense convs on v_mfma_f32_16x16x32_f16.  `yfw` is the weight
+ * pack written by tools/gen_fp16_model.py (stm32h7-yolo_amd/model/yoloface_fp32.yfw).  d_in_f16: fp16 [n][56][56][3]
+ * (pixel/255), d_out_f32: fp32 logits [n][7][7][18].  Independent of ai_network_init; needs only ai_network_create. */
+YF_API int  yf_network_fp16_init(ai_handle network, const void* yfw, size_t bytes);
+YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, void* d_out_f32, long n, void* stream);
 /* Text of the last HIP/runtime failure (empty string if none). */
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);

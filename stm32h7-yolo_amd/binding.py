@@ -83,7 +83,8 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_last_error_text", "yf_network_kernel_name",
+           "yf_network_time_stages", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
+           "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
            "ai_platform_network_get_error", "ai_platform_network_init", "ai_platform_network_post_init",
@@ -154,6 +155,9 @@ def load():
     lib.yf_network_time_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.yf_network_time_stages.restype = cl
     lib.yf_network_time_stages.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.yf_network_fp16_init.argtypes = [vp, vp, ctypes.c_size_t]
+    lib.yf_network_fp16_run_device.restype = cl
+    lib.yf_network_fp16_run_device.argtypes = [vp, vp, vp, cl, vp]
     lib.yf_network_last_error_text.restype = ctypes.c_char_p
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
@@ -234,6 +238,16 @@ class Network:
     def run_device_hw(self, h, w, d_in, d_out, n, stream=None):
         if self.lib.yf_network_run_device_hw(self.handle, h, w, d_in, d_out, n, stream) != n:
             self._raise("yf_network_run_device_hw")
+
+    def fp16_init(self, yfw_path=None):
+        path = yfw_path or os.path.join(_PKG, "model", "yoloface_fp32.yfw")
+        self._yfw = open(path, "rb").read()
+        if self.lib.yf_network_fp16_init(self.handle, self._yfw, len(self._yfw)) != 0:
+            self._raise("yf_network_fp16_init")
+
+    def fp16_run_device(self, d_in_f16, d_out_f32, n, stream=None):
+        if self.lib.yf_network_fp16_run_device(self.handle, d_in_f16, d_out_f32, n, stream) != n:
+            self._raise("yf_network_fp16_run_device")
 
     def decode_device(self, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
         if self.lib.yf_network_decode_device(self.handle, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:

@@ -13,6 +13,7 @@
 #include "yf_engine.h"
 #include "yf_host_prep.h"
 #include "yf_impl.h"
+#include "yf_fp16.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +26,7 @@ typedef struct {
   int state;
   ai_error first_error;
   yf_engine* engine;
+  yf_fp16* fp16;
   int device;
   int cfg_frames, cfg_waves;
   char err_text[512];
@@ -46,6 +48,7 @@ ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
   if (!network) return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_INVALID_PTR);
   if (network_config != NULL) { *network = AI_HANDLE_NULL; return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_NETWORK); }
   if (g_network.state == ST_READY && g_network.engine) { yf_engine_destroy(g_network.engine); }
+  if (g_network.state != ST_NONE && g_network.fp16) { yf_fp16_destroy(g_network.fp16); }
   const int dev = g_network.state != ST_NONE ? g_network.device : 0;
   const int cf = g_network.cfg_frames, cw = g_network.cfg_waves;
   memset(&g_network, 0, sizeof g_network);
@@ -59,6 +62,7 @@ ai_handle yf_impl_destroy(ai_handle network) {
   yf_context* c = acquire(network);
   if (!c) return network;                       /* not destroyed: same handle comes back (network.h:155-157) */
   if (c->engine) yf_engine_destroy(c->engine);
+  if (c->fp16) yf_fp16_destroy(c->fp16);
   memset(c, 0, sizeof *c);
   return AI_HANDLE_NULL;
 }
@@ -324,6 +328,28 @@ YF_API long yf_network_time_stages(ai_handle network, const void* d_in, void* d_
   yf_context* c = ready(network);
   if (!c) return 0;
   return finish(c, yf_engine_time_stages(c->engine, d_in, d_out, n, iters, stop_stage, stream, ms_per_launch), n);
+}
+
+/* fp16 side configuration: independent of ai_network_init (different weights: the fp32 ONNX export) */
+YF_API int yf_network_fp16_init(ai_handle network, const void* yfw, size_t bytes) {
+  yf_context* c = acquire(network);
+  if (!c) return -1;
+  if (c->fp16) { yf_fp16_destroy(c->fp16); c->fp16 = NULL; }
+  char etext[300] = "";
+  if (yf_fp16_create(c->device, yfw, bytes, &c->fp16, etext, sizeof etext) != 0) {
+    c->fp16 = NULL; latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, etext); return -1;
+  }
+  return 0;
+}
+
+YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, void* d_out_f32, long n, void* stream) {
+  yf_context* c = acquire(network);
+  if (!c) return 0;
+  if (!c->fp16) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_MISSED_INIT, "yf_network_fp16_init first"); return 0; }
+  if (yf_fp16_run_device(c->fp16, d_in_f16, d_out_f32, n, stream) != 0) {
+    latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_fp16_error(c->fp16)); return 0;
+  }
+  return n;
 }
 
 YF_API const char* yf_network_last_error_text(ai_handle network) {

@@ -173,6 +173,38 @@ def test_baseline_config5_160x160(network, oracle, torch_cuda):
     assert (ei.value.type, ei.value.code) == (0x12, 0x18)
 
 
+def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):
+    """BASELINE.json configs[3]: fp16 weights from the reference's ONNX export, 56x56, MFMA-f16 dense convs.
+    Checked against an fp32 numpy evaluation of the same graph (oracle/np_fp32.py; itself cross-checked against torch
+    CPU convs): head logits within atol 2e-2 / rtol 2e-2, and the same detection set wherever the fp32
+    confidence logit is not within the tolerance of the 0.7 threshold."""
+    torch = torch_cuda
+    from oracle.np_fp32 import load_yfw, run_fp32
+    convs = load_yfw(os.path.join(ROOT, "stm32h7-yolo_amd", "model", "yoloface_fp32.yfw"))
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (8, 56, 56, 3), dtype=np.uint8)
+    u8[:6] = (golden["inputs"].astype(np.int16) + 128).astype(np.uint8)           # includes the real image
+    x32 = u8.astype(np.float32) / 255
+    ref = np.stack([run_fp32(convs, f) for f in x32])
+    network.fp16_init()
+    n = 4096                                                                         # the config's batch: tiled copies
+    idx = np.arange(n) % 8
+    d_in = torch.from_numpy(x32.astype(np.float16)[idx]).cuda()
+    d_out = torch.zeros((n, 7, 7, 18), dtype=torch.float32, device="cuda")
+    network.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.array_equal(got[:8], got[8:16]) and np.array_equal(got[:8], got[-8:])   # deterministic across the batch
+    err = np.abs(got[:8] - ref)
+    assert np.all(err <= 2e-2 + 2e-2 * np.abs(ref)), f"max abs err {err.max():.4f}"
+    thr = np.log(0.7 / 0.3)                                                          # sigmoid(t) > 0.7  <=>  t > ln(7/3)
+    cref, cgot = ref.reshape(8, 49, 3, 6)[..., 4], got[:8].reshape(8, 49, 3, 6)[..., 4]
+    clear = np.abs(cref - thr) > 2e-2 + 2e-2 * np.abs(cref)
+    assert np.array_equal((cref > thr)[clear], (cgot > thr)[clear])
+    assert (cref[5] > thr).any()                                                     # the real image fires in fp32 too
+
+
 def test_max_n_batches_65535_through_the_abi(network, oracle):
     """ai_buffer.n_batches is 16 bit (ai_platform.h:519): the largest single ai_network_run call."""
     lib = network.lib
