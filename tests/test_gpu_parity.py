@@ -36,6 +36,18 @@ def test_native_library_is_loaded(network):
     assert "yoloface56_fused" in network.kernel_name
 
 
+@pytest.mark.gpu
+def test_reference_sample_images(network, oracle):
+    """The reference's 27 sample images (tests/golden/real_frames_56.bin): real activation statistics instead of
+    uniform noise -- head bit-exact against the oracle and against the committed sha256 of every head."""
+    import hashlib, json
+    frames = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "real_frames_56.json")))
+    got = network.run(frames)
+    assert np.array_equal(got, oracle.run(frames))
+    assert [hashlib.sha256(h.tobytes()).hexdigest() for h in got] == meta["head_sha256"]
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 257])
 def test_ai_network_run_host_path_equals_oracle(network, oracle, n):
     """reference call: ai_network_run(network, &ai_input, &ai_output) with n_batches = n (yoloface.c:226-231)"""

@@ -144,6 +144,29 @@ def test_int8_graph_tracks_float_graph(oracle, golden):
     assert err.mean() < 2.5 and err.max() < 25
 
 
+def test_int8_oracle_tracks_the_references_fp32_onnx_on_its_sample_images(oracle):
+    """Cross-artifact pin.  The reference ships TWO exports of the trained network: yoloface_int8.tflite (the int8 graph
+    the oracle restates) and yoloface-50k.onnx (fp32, reference yoloface/pytorch/).  On the reference's own 27 sample
+    images the dequantised int8 head must follow an independent fp32 numpy evaluation of the ONNX weights: Pearson
+    r > 0.95 per image and the most confident (cell, anchor) identical on most images.  A wrong padding side, concat
+    order, channel order or requantisation constant in the restatement destroys this agreement (PTQ noise alone gives
+    r ~ 0.97).  It does not prove bit-exactness with the TFLite interpreter (parity stays 'unpinned')."""
+    from oracle.np_fp32 import load_yfw, run_fp32
+    frames = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    assert frames.shape[0] == 27
+    convs = load_yfw(os.path.join(ROOT, "stm32h7-yolo_amd", "model", "yoloface_fp32.yfw"))
+    heads = oracle.run(frames)
+    same_top, rs = 0, []
+    for x, h in zip(frames, heads):
+        h8 = (h.astype(np.float64) + 15) * 0.14218327403068542
+        hf = run_fp32(convs, (x.astype(np.int16) + 128).astype(np.float32) / 255.0)
+        rs.append(np.corrcoef(h8.ravel(), hf.ravel())[0, 1])
+        c8, cf = h8.reshape(7, 7, 3, 6)[..., 4], hf.reshape(7, 7, 3, 6)[..., 4]
+        same_top += int(c8.argmax() == cf.argmax())
+    assert min(rs) > 0.95, rs
+    assert same_top >= 14, same_top                       # 18 of 27 when this test was written
+
+
 def test_decode_threshold_identity(oracle):
     """conf > 0.7 (py) and conf >= 0.7 (firmware) are both equivalent to q_conf >= -9."""
     sig = oracle.sig
