@@ -616,10 +616,11 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
 // ------------------------------------------------------------------------------------------------ max-pools
 // pool_8: 8x8 stride 2 pad 3 on T4 (28x28x18) -> separable; the vertical pass applies QUANTIZE#21 and writes the
 // pool half of concat_22.  Out-of-range taps are handled by clamping the coordinate (max is idempotent).
-// One item sweeps NO consecutive outputs along the pooled axis and shares the pair maxima P[j] = max(c[2j], c[2j+1]):
-//   out[o] = max(c[2o-3], P[o-1], P[o], P[o+1], c[2o+4])        (coordinates clamped into [0,27]: max is idempotent)
-// so 2*(NO+4) loads and ~6 packed maxima per output replace 8 loads and 16 maxima.  The last chunk is shifted
-// inwards (recomputing a few outputs) so every chunk has exactly NO outputs.
+// One item sweeps NO consecutive outputs along the pooled axis.  The 8-wide stride-2 window [2o-3, 2o+4] is exactly
+// four ODD pairs R[j] = max(c[2j+1], c[2j+2]), j = o-2 .. o+1, so with S[j] = max(R[j], R[j+1])
+//   out[o] = max(S[o-2], S[o])                     (coordinates clamped into [0,LIM]: max is idempotent)
+// -- 2*NO+6 loads and 3*NO+5 packed maxima per NO outputs (direct form: 8 loads, 7 maxima per output).  The last
+// chunk is shifted inwards (recomputing a few outputs) so every chunk has exactly NO outputs.
 struct SplitB {      // packed int8x4 as two int16x2 registers (odd bytes / even bytes lifted into the high byte)
   uint32_t o, e;
   __device__ __forceinline__ SplitB() : o(0x80008000u), e(0x80008000u) {}
@@ -630,27 +631,22 @@ struct SplitB {      // packed int8x4 as two int16x2 registers (odd bytes / even
 // LOADC(k): packed dword at clamped coordinate k along the pooled axis; STORE(o, v): write output o.
 template <int NO, int LIM, class LOADC, class STORE>
 __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
-  constexpr int NP = NO + 4;                       // pairs o0-2 .. o0+NO+1
-  SplitB ev[NP], od[NP];
+  constexpr int NR = NO + 3;                       // odd pairs o0-2 .. o0+NO
+  SplitB r[NR];
 #pragma unroll
-  for (int jj = 0; jj < NP; ++jj) {
+  for (int jj = 0; jj < NR; ++jj) {
     const int j = o0 - 2 + jj;
-    ev[jj] = SplitB(loadc(clampi(2 * j, 0, LIM)));
-    od[jj] = SplitB(loadc(clampi(2 * j + 1, 0, LIM)));
+    r[jj] = SplitB(loadc(clampi(2 * j + 1, 0, LIM))).mx(SplitB(loadc(clampi(2 * j + 2, 0, LIM))));
   }
-  SplitB pm[NP];
+  SplitB q[NR - 1];                                // q[jj] = S[o0-2+jj]
 #pragma unroll
-  for (int jj = 1; jj < NP - 1; ++jj) pm[jj] = ev[jj].mx(od[jj]);
+  for (int jj = 0; jj < NR - 1; ++jj) q[jj] = r[jj].mx(r[jj + 1]);
 #pragma unroll
-  for (int n = 0; n < NO; ++n) {
-    const int jj = n + 2;
-    const SplitB r = od[jj - 2].mx(pm[jj - 1]).mx(pm[jj].mx(pm[jj + 1])).mx(ev[jj + 2]);
-    store(o0 + n, r.merge());
-  }
+  for (int n = 0; n < NO; ++n) store(o0 + n, q[n].mx(q[n + 2]).merge());
 }
 template <int F, int NT>
 YF_STAGE_FN void pool8_h(char* frames, int tid) {
-  constexpr int NO = 4, OW = B_HB::W, IH = B_T4::H, NCH = (OW + NO - 1) / NO;   // output chunks, the last shifted left
+  constexpr int NO = 5, OW = B_HB::W, IH = B_T4::H, NCH = (OW + NO - 1) / NO;   // output chunks, the last shifted left
   for (int i = tid; i < F * IH * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
@@ -665,8 +661,8 @@ YF_STAGE_FN void pool8_h(char* frames, int tid) {
 }
 template <int F, int NT>
 YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
-  constexpr int NO = 2, OW = B_HB::W, OH = B_T14::H, NCH = OH / NO;
-  static_assert(OH % NO == 0, "even output height");
+  constexpr int NO = 5, OW = B_HB::W, OH = B_T14::H, NCH = (OH + NO - 1) / NO;   // the last chunk shifted up
+  static_assert(OH >= NO, "column shorter than one sweep");
   for (int i = tid; i < F * OW * NCH * 5; i += NT) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
@@ -674,7 +670,7 @@ YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
     char* fbase = frames + f * FRAME_BYTES;
     const char* col = fbase + B_HB::OFF + ox * 20 + 4 * cg;
     char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
-    pool8_sweep<NO, B_HB::H - 1>(k * NO,
+    pool8_sweep<NO, B_HB::H - 1>(min(k * NO, OH - NO),
                                  [&](int r) { return lds_u32(col + r * (OW * 20)); },
                                  [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4<YF_L_Q21>(v); });
   }
