@@ -360,7 +360,7 @@ YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* 
                  k3 = uniform_int4(cp + nt * 4 + 3);
         v4i acc = {k0.x, k1.x, k2.x, k3.x};
         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t], b, acc, 0, 0, 0);
-        if (q < TOT) {
+        {                                   // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
           const int y0 = requant(acc[0], k0.y, k0.z, k0.w), y1 = requant(acc[1], k1.y, k1.z, k1.w),
                     y2 = requant(acc[2], k2.y, k2.z, k2.w), y3 = requant(acc[3], k3.y, k3.z, k3.w);
           uint32_t v;
@@ -433,7 +433,7 @@ YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all
         v4i acc = {k0.x, k1.x, k2.x, k3.x};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
-        if (q < TOT) {
+        {                                   // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
           const int y[4] = {requant(acc[0], k0.y, k0.z, k0.w), requant(acc[1], k1.y, k1.z, k1.w),
                             requant(acc[2], k2.y, k2.z, k2.w), requant(acc[3], k3.y, k3.z, k3.w)};
           epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, ps * 4, y, ad);
@@ -486,7 +486,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* _
     v4i acc = {bias[0], bias[1], bias[2], bias[3]};
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-    if (q < TOT) {
+    {                                       // no exec mask (surplus lanes redo pixel TOT-1)
       int y[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
@@ -567,8 +567,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
   static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
-  const int xl = (FL == 2) ? (c & 7) : c;
-  const bool lane_valid = (W >= 16) ? true : (xl < W);
+  const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);      // surplus lanes duplicate the last column (idempotent)
   const int lane_in = fl * FRAME_BYTES + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
   const int lane_out = fl * FRAME_BYTES + (g * W + xl) * OUT::S;
   const bool a_on = (c >> 2) == g;                          // A row r = c belongs to row block r>>2
@@ -603,7 +602,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-      if (lane_valid) {
+      {
         const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
                   i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
         const uint32_t v = lutb<LUT_ID>(i0) | (lutb<LUT_ID>(i1) << 8) | (lutb<LUT_ID>(i2) << 16) | (lutb<LUT_ID>(i3) << 24);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-stage time profile of the fused kernel (debug build, F=2 NW=4): time(stop=k) - time(stop=k-1)."""
+"""Per-stage time profile of the fused kernel (debug build; YF_N=frames, e.g. 512 = one workgroup per CU): time(stop=k) - time(stop=k-1)."""
 import importlib, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ NAMES = ["input staging", "conv2d_1", "conv2d_3 (dw)", "conv2d_5", "conv2d_6", "
          "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23", "pool_25 + conv2d_27 (dw)", "conv2d_29",
          "conv2d_30", "conv2d_32 (dw)", "conv2d_34+add", "conv2d_36", "conv2d_38 (dw)", "conv2d_40+add", "conv2d_42", "conv2d_47",
          "conv2d_49 (dw)", "conv2d_51", "conv2d_53 + store"]
-n = 4096
+n = int(os.environ.get("YF_N", "4096"))
 x = np.random.default_rng(1).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
 net = yf.Network().init()
 if len(sys.argv) > 2: net.configure(int(sys.argv[1]), int(sys.argv[2]))
