@@ -14,7 +14,13 @@
 #undef YF_STAGE_FN
 #define YF_NS yfx
 #define YF_EXP 1
+#ifndef YF_LAUNDER_X
+#define YF_LAUNDER_X 7      /* experimental build: no hoisting of per-lane index arithmetic (83 VGPRs instead of 120) */
+#endif
+#undef YF_LAUNDER
+#define YF_LAUNDER YF_LAUNDER_X
 #include "yf_kernels.hip.h"
+#undef YF_LAUNDER
 #undef YF_NS
 #undef YF_EXP
 #undef YF_STAGE_FN
@@ -139,7 +145,7 @@ const Variant k_variants[] = {
   YF_VARIANT(1, 4, false, true), YF_VARIANT(2, 4, false, true), YF_VARIANT(4, 4, false, true), YF_VARIANT(2, 8, false, true), YF_VARIANT(4, 8, false, true),
   YF_VARIANT(2, 6, false, true), YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
   YF_VARIANT(2, 4, true, true), YF_VARIANT(2, 8, true, true),
-  YF_VARIANT_X(2, 8), YF_VARIANT_X(1, 4),
+  YF_VARIANT_X(2, 8), YF_VARIANT_X(1, 4), YF_VARIANT_X(2, 12),
 };
 
 }  // namespace

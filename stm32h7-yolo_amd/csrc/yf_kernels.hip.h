@@ -23,6 +23,9 @@
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // absolute LDS addresses (device); the host pass only parses them
+#ifndef YF_LAUNDER
+#define YF_LAUNDER 0
+#endif
 namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
@@ -729,7 +732,7 @@ struct NetParams {
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
 template <int F, int NW, bool DUMP, bool DWM>
-__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
+__global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
@@ -737,12 +740,10 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();   // LUTs are addressed absolutely
   char* out_all = smem + LUT_BYTES;
   char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab = prm.tab;
 
-  for (int i = tid; i < LUT_BYTES / 16; i += NT)
+  for (int i = tid0; i < LUT_BYTES / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
 
   const long n_groups = (prm.n + F - 1) / F;
@@ -760,94 +761,106 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yolo
 
   for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long first = grp * F;
+    // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
+    // results in VGPRs for the whole kernel.  YF_LAUNDER selects stage groups (1 front 28x28, 2 middle 14x14, 4 tail
+    // 7x7) whose thread index is laundered once per group, i.e. recomputed instead of parked.
+    int tid = tid0, tid_f = tid0, tid_m = tid0, tid_t = tid0;
+    if constexpr ((YF_LAUNDER & 1) != 0) asm volatile("" : "+v"(tid_f));
+    if constexpr ((YF_LAUNDER & 2) != 0) asm volatile("" : "+v"(tid_m));
+    if constexpr ((YF_LAUNDER & 4) != 0) asm volatile("" : "+v"(tid_t));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L_f = tid_f & 63, L_m = tid_m & 63, L_t = tid_t & 63;
+    const int W_f = __builtin_amdgcn_readfirstlane(tid_f >> 6), W_m = __builtin_amdgcn_readfirstlane(tid_m >> 6), W_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
+    (void)lane; (void)wave;
     YF_SYNC();                                                         // previous group's arena is dead
     stage_no = 0;
-    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid);
-    fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid);
+    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_f);
+    fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()
-    conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), wave, lane);                        // conv2d_1
+    conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), W_f, L_f);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane);   // conv2d_3
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), W_f, L_f); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), W_f, L_f);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
-    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), wave, lane);   // conv2d_5
+    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), W_f, L_f);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
-    fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid);
-    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), wave, lane);   // conv2d_6
+    fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid_f);
+    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), W_f, L_f);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
-    pool8_h<F, NT>(frames, tid);                                                                   // pool_8 (h)
+    pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
     YF_SYNC();
     YF_STAGE_END()
-    pool8_v<F, NT>(frames, luts, tid);                                                             // pool_8 (v) + QUANTIZE#21
+    pool8_v<F, NT>(frames, luts, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane);   // conv2d_10
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), W_m, L_m); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), W_m, L_m);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane);
+    dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, W_m, L_m);
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
-    fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid);
-    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), wave, lane);  // conv2d_13
+    fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid_m);
+    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), W_m, L_m);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane);   // conv2d_15
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), W_m, L_m); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), W_m, L_m);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane);
+    dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), W_m, L_m);
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), wave, lane);  // conv2d_19 -> concat_22
+    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), W_m, L_m);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
-    fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid);
-    dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane);
+    fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
+    dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m);
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
-    pool25<F, NT>(frames, luts, tid);                                                              // pool_25 + QUANTIZE#45
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane);   // conv2d_27
+    pool25<F, NT>(frames, luts, tid_t);                                                              // pool_25 + QUANTIZE#45
+    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), W_t, L_t); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), W_t, L_t);   // conv2d_27
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane);
+    dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t);
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
-    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), wave, lane);  // conv2d_30
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
+    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), W_t, L_t);  // conv2d_30
     YF_SYNC(); YF_DUMP(B_T19, 40, T19)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane);   // conv2d_32
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), W_t, L_t);   // conv2d_32
     YF_SYNC(); YF_DUMP(B_T20, 40, T20)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane);
+    dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t);
     YF_SYNC(); YF_DUMP(B_T22, 8, T22)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
-    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), wave, lane);  // conv2d_36
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
+    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), W_t, L_t);  // conv2d_36
     YF_SYNC(); YF_DUMP(B_T19, 40, T23)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane);   // conv2d_38
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), W_t, L_t);   // conv2d_38
     YF_SYNC(); YF_DUMP(B_T20, 40, T24)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane);
+    dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t);
     YF_SYNC(); YF_DUMP(B_T26, 8, T26)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), wave, lane);  // conv2d_42 -> concat_46
+    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), W_t, L_t);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP(B_T30, 48, T30)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
-    dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane);
+    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
+    dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t);
     YF_SYNC(); YF_DUMP(B_T19, 40, T31)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane);   // conv2d_49
+    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), W_t, L_t);   // conv2d_49
     YF_SYNC(); YF_DUMP(B_T20, 40, T32)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane);
+    dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t);
     YF_SYNC(); YF_DUMP(B_T33, 32, T33)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane);
+    dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t);
     YF_SYNC();
     {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
       const long valid = min((long)F, prm.n - first);
