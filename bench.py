@@ -55,8 +55,8 @@ def cpu_baseline(x, got_heads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (one step = one 4096-frame batch per GPU, ~0.23 ms)")
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps; the first ~50 steps after idle run ~6%% slower (clock ramp)")
     ap.add_argument("--frames-per-wg", type=int, default=0)
     ap.add_argument("--waves-per-wg", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")

@@ -7,8 +7,9 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/bench_line.json 2> $OUT/trace.err
+TRACE_ARGS="$*"                       # kernel trace: the default bench command (400 steps after 100 warm-up)
+ARGS="--steps 20 --warmup 5 $*"        # counter passes: per-launch counts do not depend on the clock state
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $TRACE_ARGS > $OUT/bench_line.json 2> $OUT/trace.err
 i=0
 for grp in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
