@@ -223,6 +223,11 @@ YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, c
  * exceed cap).  mode = YF_DECODE_PY or YF_DECODE_FW. */
 YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                                      void* d_dets, void* d_counts, int cap, void* stream);
+/* Network and box decode in ONE launch (the firmware's ai_network_run + post-processing, yoloface.c:98-152 /
+ * tflite_prediction.py:39-63, back to back): heads go to d_heads as in yf_network_run_device and every workgroup
+ * decodes its frames' heads while they are still on chip.  Same records as yf_network_decode_device. */
+YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                         void* d_dets, void* d_counts, int cap, void* stream);
 /* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
 /* `iters` back-to-back launches of the fused kernel on `stream`, bracketed by HIP events on that stream;

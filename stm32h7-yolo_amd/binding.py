@@ -82,7 +82,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_destroy", "ai_network_get_info", "ai_network_get_report", "ai_network_data_weights_get",
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
-           "yf_network_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
+           "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
@@ -149,6 +149,8 @@ def load():
     lib.yf_network_run_device_hw.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, cl, vp]
     lib.yf_network_decode_device.restype = cl
     lib.yf_network_decode_device.argtypes = [vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
+    lib.yf_network_run_decode_device.restype = cl
+    lib.yf_network_run_decode_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
     lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
     lib.yf_network_time_device.restype = cl
@@ -252,6 +254,11 @@ class Network:
     def decode_device(self, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
         if self.lib.yf_network_decode_device(self.handle, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
             self._raise("yf_network_decode_device")
+
+    def run_decode_device(self, d_in, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
+        """Network + box decode in one launch (heads are decoded while still in LDS)."""
+        if self.lib.yf_network_run_decode_device(self.handle, d_in, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
+            self._raise("yf_network_run_decode_device")
 
     def prepare_rgb565_device(self, d_rgb, d_out, n, stream=None):
         if self.lib.yf_network_prepare_rgb565_device(self.handle, d_rgb, d_out, n, stream) != n:

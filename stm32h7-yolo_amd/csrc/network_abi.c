@@ -312,6 +312,13 @@ YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, lon
   return finish(c, yf_engine_decode_device(c->engine, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream), n);
 }
 
+YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                         void* d_dets, void* d_counts, int cap, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_run_decode_device(c->engine, d_in, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream), n);
+}
+
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream) {
   yf_context* c = ready(network);
   if (!c) return 0;

@@ -28,6 +28,9 @@ int  yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, 
 int  yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch);
 int  yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                              void* d_dets, void* d_counts, int cap, void* stream);
+/* network + box decode in ONE launch: every workgroup decodes its frames' heads while they are still in LDS */
+int  yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,
+                                 void* d_dets, void* d_counts, int cap, void* stream);
 int  yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream);
 /* 160x160 frames (int8 [n][160][160][3] -> [n][20][20][18]): layer-by-layer over an engine-owned HBM arena */
 int  yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n, void* stream);

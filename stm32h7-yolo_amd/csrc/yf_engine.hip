@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include "yf_engine.h"
+#include "yf_decode.hip.h"
 #define YF_NS yf
 #define YF_EXP 0
 #include "yf_kernels.hip.h"
@@ -36,75 +37,20 @@
 #undef YF_H0
 #undef YF_GENERIC
 #include "gen/yf_decode_tables_gen.h"
-#include "../../include/yf_network.h"   // yf_det, YF_DECODE_*
 
 namespace {
 
-__device__ __constant__ uint32_t d_sig_bits[256];
-__device__ __constant__ uint32_t d_exp_bits[256];
-
-// float -> int32 with the x86 convention of the reference's hosts (cvttss2si): truncate, out of range -> INT32_MIN
-__device__ __forceinline__ int f2i_x86(float v) {
-  return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
-}
-__device__ __forceinline__ int dbl_wrap(int v) { return (int)((unsigned)v * 2u); }
+using yfdec::d_sig_bits;
+using yfdec::d_exp_bits;
 
 // ---------------------------------------------------------------------------------------------- box decode
-// One wave per frame; candidates are visited in the reference order and compacted with ballots so that the
-// record order equals the order the reference loops produce.
-//   YF_DECODE_PY: yoloface/tflite/tflite_prediction.py:42-63  (a, row, col), conf > 0.7
-//   YF_DECODE_FW: stm32/X-CUBE-AI/App/yoloface.c:98-152       (cell, a), conf >= 0.7, LCD axis swap, clamp, x2
-// All transcendental values come from the committed float32 tables; the remaining float32 operations are single
-// IEEE operations (this file is compiled with -ffp-contract=off).
+// Stand-alone form (heads already in HBM): one wave per frame, see yf_decode.hip.h.
 __global__ void __launch_bounds__(256) decode_kernel(const int8_t* __restrict__ heads, long n, int mode, float w_scale,
                                                      float h_scale, yf_det* __restrict__ dets, int* __restrict__ counts, int cap) {
   const int lane = threadIdx.x & 63;
   const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (frame >= n) return;
-  const int8_t* head = heads + frame * 882;
-  yf_det* out = dets + frame * cap;
-  const float anc_w[3] = {9.f, 12.f, 22.f}, anc_h[3] = {14.f, 17.f, 21.f};
-  int total = 0;
-  for (int base = 0; base < 147; base += 64) {
-    const int i = base + lane;
-    bool keep = false;
-    int a = 0, row = 0, col = 0;
-    const int8_t* p = head;
-    float conf = 0.f;
-    if (i < 147) {
-      if (mode == YF_DECODE_PY) { a = i / 49; const int cell = i - a * 49; row = cell / 7; col = cell - row * 7; }
-      else { const int cell = i / 3; a = i - cell * 3; row = cell / 7; col = cell - row * 7; }
-      p = head + (row * 7 + col) * 18 + a * 6;
-      conf = __uint_as_float(d_sig_bits[p[4] + 128]);
-      keep = (mode == YF_DECODE_PY) ? (conf > 0.7f) : ((double)conf >= 0.7);
-    }
-    const unsigned long long mask = __ballot(keep);
-    const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-    if (keep && pos < cap) {
-      const float sx = __uint_as_float(d_sig_bits[p[0] + 128]), sy = __uint_as_float(d_sig_bits[p[1] + 128]);
-      const float ew = __uint_as_float(d_exp_bits[p[2] + 128]), eh = __uint_as_float(d_exp_bits[p[3] + 128]);
-      yf_det d;
-      d.frame = (int32_t)frame; d.anchor = (uint8_t)a; d.row = (uint8_t)row; d.col = (uint8_t)col;
-      d.q_conf = p[4]; d.conf = conf;
-      const float cx = (sx + (float)col) * 8.f, cy = (sy + (float)row) * 8.f;
-      const float bw = ew * anc_w[a], bh = eh * anc_h[a];
-      if (mode == YF_DECODE_PY) {
-        float x1 = cx - bw / 2, y1 = cy - bh / 2, x2 = cx + bw / 2, y2 = cy + bh / 2;
-        x1 *= w_scale; x2 *= w_scale; y1 *= h_scale; y2 *= h_scale;
-        d.x1 = f2i_x86(x1); d.y1 = f2i_x86(y1); d.x2 = f2i_x86(x2); d.y2 = f2i_x86(y2);
-      } else {
-        int y2 = f2i_x86(cx - bw / 2), y1 = f2i_x86(cx + bw / 2), x1 = f2i_x86(cy - bh / 2), x2 = f2i_x86(cy + bh / 2);
-        if (x1 < 0) x1 = 0;
-        if (y1 < 0) y1 = 0;
-        if (x2 > 55) x2 = 55;
-        if (y2 > 55) y2 = 55;
-        d.x1 = dbl_wrap(x1); d.y1 = dbl_wrap(y1); d.x2 = dbl_wrap(x2); d.y2 = dbl_wrap(y2);
-      }
-      out[pos] = d;
-    }
-    total += __popcll(mask);
-  }
-  if (lane == 0) counts[frame] = total;
+  yfdec::decode_frame(heads + frame * 882, frame, lane, mode, w_scale, h_scale, dets, counts, cap);
 }
 
 // ---------------------------------------------------------------------------------------------- frame preparation
@@ -250,12 +196,17 @@ const char* yf_engine_error(const yf_engine* e) { return e ? e->err.c_str() : "n
 const char* yf_engine_kernel_name(const yf_engine* e) { return e && e->var ? e->var->name : ""; }
 long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
 
-static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s, int stop_stage = -1) {
+struct DecodeArgs { void* dets; void* counts; int cap, mode; float w_scale, h_scale; };
+
+static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s, int stop_stage = -1,
+                  const DecodeArgs* dec = nullptr) {
   if (n <= 0) return YF_ENG_OK;
   if (((uintptr_t)d_in & 3) != 0) { e->err = "input must be 4-byte aligned"; return YF_ENG_ERR_ARG; }
   if (((uintptr_t)d_out & 1) != 0) { e->err = "output must be 2-byte aligned"; return YF_ENG_ERR_ARG; }
   yf::NetParams prm;
   prm.in = (const int8_t*)d_in; prm.out = (int8_t*)d_out; prm.n = n; prm.tab = e->d_tab; prm.dump = (int8_t*)d_dump; prm.stop_stage = stop_stage;
+  prm.dets = nullptr; prm.counts = nullptr; prm.cap = 0; prm.mode = 0; prm.w_scale = prm.h_scale = 1.f;
+  if (dec) { prm.dets = (yf_det*)dec->dets; prm.counts = (int*)dec->counts; prm.cap = dec->cap; prm.mode = dec->mode; prm.w_scale = dec->w_scale; prm.h_scale = dec->h_scale; }
   const long groups = (n + v->f - 1) / v->f;
   const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
   long grid = (long)e->cus * per_cu;
@@ -269,6 +220,14 @@ int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_du
   if (!e || !d_in || !d_out || n < 0) return YF_ENG_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   return launch(e, d_dump ? e->var_dump : e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);
+}
+
+int yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,
+                                void* d_dets, void* d_counts, int cap, void* stream) {
+  if (!e || !d_in || !d_out || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW)) return YF_ENG_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
+  return launch(e, e->var, d_in, d_out, nullptr, n, (hipStream_t)stream, -1, &dec);
 }
 
 int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {

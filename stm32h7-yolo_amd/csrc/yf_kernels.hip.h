@@ -728,6 +728,11 @@ struct NetParams {
   const uint8_t* tab;     // device table blob (yf_host_prep.c)
   int8_t* dump;           // optional per-stage dump, [n][DumpOffsets::TOTAL]
   int stop_stage;         // debug kernel only: leave the group after this many stages (stage timing); <0 = run all
+  // optional fused box decode (heads are decoded while still in LDS): dets == nullptr -> heads only
+  yf_det* dets;           // [n][cap] detection records
+  int* counts;            // [n] candidates per frame (may exceed cap)
+  int cap, mode;          // YF_DECODE_PY / YF_DECODE_FW
+  float w_scale, h_scale;
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
@@ -759,6 +764,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   int stage_no = 0;
 #define YF_STAGE_END() if constexpr (DUMP) { if (++stage_no == prm.stop_stage) continue; }
 
+  // Fused box decode: the staged heads of group g stay in out_all until conv2d_53 of group g+1, so they are decoded by
+  // the last F waves DURING conv2d_29 of the next group (a 4-job stage: those waves are idle there), off the critical
+  // path; the workgroup's last group is decoded after the loop.
+  long prev_first = -1;
+  auto decode_prev = [&](int w, int ln) {
+    if (prm.dets != nullptr && prev_first >= 0 && w >= NW - F && prev_first + (w - (NW - F)) < prm.n) {
+      int dl = ln;
+      asm volatile("" : "+v"(dl));              // keep the decode's per-lane index arithmetic out of the kernel-wide hoisted set
+      yfdec::decode_frame(reinterpret_cast<const int8_t*>(out_all) + (w - (NW - F)) * OUT_FRAME_BYTES, prev_first + (w - (NW - F)), dl,
+                          prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap);
+    }
+  };
   for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long first = grp * F;
     // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
@@ -825,6 +842,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
     YF_STAGE_END()
     dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t);
+    decode_prev(W_t, L_t);                                                                         // previous group's boxes
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
@@ -868,7 +886,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       uint16_t* dst = reinterpret_cast<uint16_t*>(prm.out + first * OUT_FRAME_BYTES);
       const uint16_t* srcp = reinterpret_cast<const uint16_t*>(out_all);
       for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
+      prev_first = first;
     }
+  }
+  {   // boxes of this workgroup's last group
+    const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    decode_prev(wave, lane);
   }
 #undef YF_DUMP
 #undef YF_STAGE_END

@@ -320,6 +320,36 @@ def test_box_decode_on_gpu_equals_oracle(yf, network, oracle, golden, torch_cuda
     assert _dets(buf2, counts, 5)[6] == got[6][:5]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_network_and_decode_in_one_launch(yf, network, oracle, torch_cuda, mode):
+    """yf_network_run_decode_device: heads AND detection records from one launch (the heads are decoded while still
+    in LDS) equal the oracle's network followed by the oracle's decode; ragged batch (odd n) and a small capacity."""
+    torch = torch_cuda
+    real = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    x = np.concatenate([real, np.random.default_rng(33).integers(-128, 128, (174, 56, 56, 3), dtype=np.int8)])
+    n, cap = x.shape[0], 8
+    assert n % 2 == 1
+    ws, hs = (410 / 56.0, 362 / 56.0) if mode == 0 else (1.0, 1.0)
+    d_x = torch.from_numpy(x).cuda()
+    d_h = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+    d_d = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_c = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    network.run_decode_device(d_x.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap, mode, ws, hs)
+    torch.cuda.synchronize()
+    heads = d_h.cpu().numpy()
+    assert np.array_equal(heads, oracle.run(x))
+    buf = d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap)
+    counts = d_c.cpu().numpy()
+    got = _dets(buf, counts, cap)
+    n_det = 0
+    for f in range(n):
+        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f)
+        assert counts[f] == len(ref)
+        assert got[f] == [(d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9]) for d in ref][:cap], f"frame {f}"
+        n_det += len(ref)
+    assert n_det > 0
+
+
 def test_frame_preparation_on_gpu_equals_oracle(network, oracle, torch_cuda):
     """yoloface.c:26-93 (RGB565 112x112 -> int8 56x56x3), then the whole camera-format -> head pipeline."""
     torch = torch_cuda
