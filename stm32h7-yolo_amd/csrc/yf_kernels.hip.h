@@ -150,6 +150,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 __device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
   return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
 }
+// four zero-extended bytes -> one dword with three v_lshl_or_b32 (from a|b<<8|c<<16|d<<24 the compiler selects four ops)
+__device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+  uint32_t lo, hi, v;
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(lo) : "v"(b1), "v"(b0));
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(hi) : "v"(b3), "v"(b2));
+  asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(v) : "v"(hi), "v"(lo));
+  return v;
+}
 // Byte LUTs live at LDS offset LUT_ID*256 (the dynamic LDS segment starts at 0: the kernel has no static LDS and
 // checks it).  Absolute LDS addressing lets the table base ride in the ds_read immediate offset.
 typedef const __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
@@ -279,8 +287,8 @@ template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
 __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
                                                int p, int chq, const int (&y)[4], const AddCtx& ad) {
   if constexpr (EPI == EPI_LUT) {
-    const uint32_t v = lutb<LUT_ID>(clampi(y[0], 0, 255)) | (lutb<LUT_ID>(clampi(y[1], 0, 255)) << 8) |
-                       (lutb<LUT_ID>(clampi(y[2], 0, 255)) << 16) | (lutb<LUT_ID>(clampi(y[3], 0, 255)) << 24);
+    const uint32_t v = join4(lutb<LUT_ID>(clampi(y[0], 0, 255)), lutb<LUT_ID>(clampi(y[1], 0, 255)),
+                             lutb<LUT_ID>(clampi(y[2], 0, 255)), lutb<LUT_ID>(clampi(y[3], 0, 255)));
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = v;
   } else if constexpr (EPI == EPI_RAW) {
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
@@ -368,8 +376,8 @@ YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* 
                     y2 = requant(acc[2], k2.y, k2.z, k2.w), y3 = requant(acc[3], k3.y, k3.z, k3.w);
           uint32_t v;
           if constexpr (EPI == EPI_LUT)
-            v = lutb<LUT_ID>(clampi(y0, 0, 255)) | (lutb<LUT_ID>(clampi(y1, 0, 255)) << 8) |
-                (lutb<LUT_ID>(clampi(y2, 0, 255)) << 16) | (lutb<LUT_ID>(clampi(y3, 0, 255)) << 24);
+            v = join4(lutb<LUT_ID>(clampi(y0, 0, 255)), lutb<LUT_ID>(clampi(y1, 0, 255)), lutb<LUT_ID>(clampi(y2, 0, 255)),
+                      lutb<LUT_ID>(clampi(y3, 0, 255)));
           else
             v = pack4(clampi(y0, -128, 127), clampi(y1, -128, 127), clampi(y2, -128, 127), clampi(y3, -128, 127));
           *reinterpret_cast<uint32_t*>(dst + nt * 4) = v;
@@ -608,7 +616,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
       {
         const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
                   i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
-        const uint32_t v = lutb<LUT_ID>(i0) | (lutb<LUT_ID>(i1) << 8) | (lutb<LUT_ID>(i2) << 16) | (lutb<LUT_ID>(i3) << 24);
+        const uint32_t v = join4(lutb<LUT_ID>(i0), lutb<LUT_ID>(i1), lutb<LUT_ID>(i2), lutb<LUT_ID>(i3));
         *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) = v;
       }
     }
