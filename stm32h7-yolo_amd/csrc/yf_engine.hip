@@ -219,7 +219,11 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
 int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_dump, long n, void* stream) {
   if (!e || !d_in || !d_out || n < 0) return YF_ENG_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
+#ifdef YF_BARPROF
+  return launch(e, e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);      // profile build: the production variant fills d_dump with barrier waits
+#else
   return launch(e, d_dump ? e->var_dump : e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);
+#endif
 }
 
 int yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,

@@ -206,6 +206,16 @@ __device__ __forceinline__ int load_halo_zp(const uint8_t* tab, int i) {
   return (int)uniform_u32(tab + offsetof(yf_table_index, halo_zp) + 4 * i);
 }
 
+// Contiguous job range of a wave: JOBS / NW each, the first JOBS % NW waves take one more.  Waves w and w + 4 share
+// a SIMD, so the surplus jobs land on different SIMDs (ceil(JOBS / NW) blocks leave the last waves -- and their SIMDs --
+// idle: 49 jobs on 8 waves would be 7,7,7,7,7,7,7,0).
+template <int JOBS, int NW>
+__device__ __forceinline__ void job_range(int wave, int& j0, int& j1) {
+  constexpr int BASE = JOBS / NW, REM = JOBS % NW;
+  j0 = wave * BASE + min(wave, REM);
+  j1 = j0 + BASE + (wave < REM ? 1 : 0);
+}
+
 // ------------------------------------------------------------------------------------------------ halo fill
 // RING: 1-pixel border all round (SAME 3x3 stride 1); otherwise top row + left column (explicit PAD, stride 2)
 template <class B, bool RING, int F, int NT>
@@ -331,12 +341,12 @@ YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* 
   constexpr int P = IN::P, TOT = F * P;
   constexpr int MT = (TOT + 63) / 64;
   constexpr int JOBS = NCH * MT;
-  constexpr int JPW = (JOBS + NW - 1) / NW;
   constexpr int RW = IN::S >= 16 ? 16 : IN::S;
   static_assert(OUT::P == P, "1x1 conv keeps the grid");
   static_assert(EPI == EPI_LUT || EPI == EPI_RAW, "epilogue kind");
   const int g = lane >> 4, c = lane & 15;
-  const int j0 = wave * JPW, j1 = min(j0 + JPW, JOBS);
+  int j0, j1;
+  job_range<JOBS, NW>(wave, j0, j1);
   const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
   int cur_chunk = -1;
   v4i a[TPJ];
@@ -401,12 +411,12 @@ YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all
   constexpr int P = IN::P, TOT = F * P;
   constexpr int MT = (TOT + 63) / 64;
   constexpr int JOBS = NCH * MT;
-  constexpr int JPW = (JOBS + NW - 1) / NW;
   constexpr int KROW = 16 * KS;
   static_assert(OUT::P == P || EPI == EPI_HEAD, "1x1 conv keeps the grid");
   static_assert(IN::S >= KROW, "the pixel vector must cover all k-steps");
   const int g = lane >> 4, c = lane & 15;
-  const int j0 = wave * JPW, j1 = min(j0 + JPW, JOBS);
+  int j0, j1;
+  job_range<JOBS, NW>(wave, j0, j1);
   const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
   const bool a_on = (c >> 2) == g;
   int cur_chunk = -1;
@@ -461,7 +471,6 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* _
                                             const yf_dense d, int wave, int lane) {
   constexpr int P = B_T1::P, W1 = B_T1::W, RSW = B_IN::RS, TOT = F * P, PIX_T = 32;
   constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
-  constexpr int JPW = (MT + NW - 1) / NW;
   const int g = lane >> 4, c = lane & 15;
   const int set = g >> 1, half = g & 1;
   // A fragments: rows 0..7 <-> set 0, rows 8..15 <-> set 1; channel = c & 7
@@ -482,7 +491,8 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* _
   }
   // dword offsets of this lane's taps relative to IN[2oy][2ox+3]  (see yf_tables.h, conv2d_1 packing)
   const int o0 = half ? RSW + 1 : 0, o1 = half ? RSW + 2 : 1, o2 = half ? 2 * RSW : 2, o3 = half ? 2 * RSW + 1 : RSW;
-  const int j0 = wave * JPW, j1 = min(j0 + JPW, MT);
+  int j0, j1;
+  job_range<MT, NW>(wave, j0, j1);
   const AddCtx ad = {};
   for (int mt = j0; mt < j1; ++mt) {
     const int q = mt * PIX_T + set * 16 + c;
@@ -516,9 +526,8 @@ YF_STAGE_FN void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __re
   constexpr int P = OUT::P, TOT = F * P;
   constexpr int NB = (TOT + 63) / 64;                  // 64-pixel blocks per channel group
   constexpr int JOBS = NG * NB;
-  constexpr int JPW = (JOBS + NW - 1) / NW;
-  const int j1 = min(wave * JPW + JPW, JOBS);
-  int j = wave * JPW;
+  int j, j1;
+  job_range<JOBS, NW>(wave, j, j1);
   while (j < j1) {
     const int cg = j / NB;
     const int jend = min(j1, (cg + 1) * NB);
@@ -571,7 +580,6 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
   constexpr int NFP = F / FL;
   constexpr int JPG = NFP * NRB * NSEG;                     // jobs per channel group
   constexpr int JOBS = NG * JPG;
-  constexpr int JPW = (JOBS + NW - 1) / NW;
   constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
   constexpr int TS = IN::S, TR = IN::RS * IN::S;            // tap strides: +1 column, +1 row
   static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
@@ -582,8 +590,8 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
   const int lane_in = fl * FRAME_BYTES + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
   const int lane_out = fl * FRAME_BYTES + (g * W + xl) * OUT::S;
   const bool a_on = (c >> 2) == g;                          // A row r = c belongs to row block r>>2
-  const int j1 = min(wave * JPW + JPW, JOBS);
-  int j = wave * JPW;
+  int j, j1;
+  job_range<JOBS, NW>(wave, j, j1);
   while (j < j1) {
     const int cg = j / JPG;
     const int jend = min(j1, (cg + 1) * JPG);
@@ -766,7 +774,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     return AddCtx{(int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   constexpr long DS = DumpOffsets::TOTAL;
+#ifdef YF_BARPROF
+  // Barrier-wait profile (tools/barrier_profile.py): cycles each wave spends inside __syncthreads(), per barrier index.
+  long long bar_wait[40] = {};
+  long long t_loop0 = 0;
+  int bar_no = 0;
+#define YF_SYNC() do { const long long t0_ = __builtin_readcyclecounter(); __syncthreads(); bar_wait[bar_no < 39 ? bar_no : 39] += __builtin_readcyclecounter() - t0_; ++bar_no; } while (0)
+#else
 #define YF_SYNC() __syncthreads()
+#endif
 #define YF_DUMP(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
   int stage_no = 0;
@@ -786,6 +802,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   };
   for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const long first = grp * F;
+#ifdef YF_BARPROF
+    bar_no = 0;
+    if (grp == (long)blockIdx.x) t_loop0 = __builtin_readcyclecounter();
+#endif
     // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
     // results in VGPRs for the whole kernel.  YF_LAUNDER selects stage groups (1 front 28x28, 2 middle 14x14, 4 tail
     // 7x7) whose thread index is laundered once per group, i.e. recomputed instead of parked.
@@ -900,6 +920,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   {   // boxes of this workgroup's last group
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
+#ifdef YF_BARPROF
+    if (!DUMP && prm.dump != nullptr && lane == 0) {     // [wg][wave][41]: total cycles in the loop, then waits per barrier
+      long long* o = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + wave) * 41;
+      o[0] = __builtin_readcyclecounter() - t_loop0;
+      for (int i = 0; i < 40; ++i) o[1 + i] = bar_wait[i];
+    }
+#endif
   }
 #undef YF_DUMP
 #undef YF_STAGE_END
