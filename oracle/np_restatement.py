@@ -170,11 +170,16 @@ class NpModel:
         head = val[self.m["output"]]
         return (head, outs) if dump else head
 
-    def run_float(self, frame):
-        """float64 evaluation of the dequantised graph (structural sanity)."""
+    def run_float(self, frame, float_convs=None, observe=None):
+        """float64 evaluation of the dequantised graph (structural sanity).
+        float_convs: optional list of (weights in tflite layout, bias) replacing the dequantised int8 constants, in
+        conv order (PTQ calibration, tests/test_ptq.py); observe(tensor_index, value) sees every op output."""
         T, ops = self.m["tensors"], self.m["ops"]
         t0 = T[self.m["input"]]
         val = {self.m["input"]: (np.asarray(frame, np.float64) - t0["zp"]) * float(t0["scale"][0])}
+        if observe is not None:
+            observe(self.m["input"], val[self.m["input"]])
+        n_conv = 0
         for o in ops:
             x = val[o["ins"][0]]
             if o["op"] == PAD:
@@ -186,6 +191,10 @@ class NpModel:
                 ws = wt["scale"].astype(np.float64)
                 w = wq * (ws[:, None, None, None] if o["op"] == CONV else ws[None, None, None, :])
                 bias = T[o["ins"][2]]["data"].astype(np.float64) * float(ti["scale"][0]) * ws
+                if float_convs is not None:
+                    w = np.asarray(float_convs[n_conv][0], np.float64).reshape(wt["shape"])
+                    bias = np.asarray(float_convs[n_conv][1], np.float64)
+                n_conv += 1
                 kh, kw = wt["shape"][1], wt["shape"][2]
                 oh, ph = _same_valid(o["padding"], x.shape[0], kh, o["sh"])
                 ow, pw = _same_valid(o["padding"], x.shape[1], kw, o["sw"])
@@ -218,4 +227,6 @@ class NpModel:
             elif o["op"] == CONCAT:
                 y = np.concatenate([x, val[o["ins"][1]]], axis=2)
             val[o["out"]] = y
+            if observe is not None:
+                observe(o["out"], y)
         return val[self.m["output"]]
