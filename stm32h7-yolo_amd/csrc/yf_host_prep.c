@@ -91,7 +91,7 @@ static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_
   out->bias2 = bias - t_zp(d->t_in) * sum_w;
   out->mult = m;
   out->rshift = rs;
-  out->kc = ((int32_t)1 << (rs - 1)) + ((t_zp(d->t_out) + z_extra) << rs);
+  out->kc = ((int32_t)1 << (rs - 1)) + (t_zp(d->t_out) + z_extra) * ((int32_t)1 << rs);   /* the offset may be negative: multiply, do not shift */
   return 0;
 }
 
@@ -219,7 +219,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     if (a->s1 > 0 || a->s2 > 0 || a->so > -1 || a->so < -30 || a->mo <= (1 << 30)) rc = YF_PREP_ERR_SHIFT_RANGE;
     a->zp1 = t_zp(add_t[s][0]); a->zp2 = t_zp(add_t[s][1]); a->zpo = t_zp(add_t[s][2]);
     a->rso = -a->so;
-    a->kco = ((int32_t)1 << (a->rso - 1)) + (a->zpo << a->rso);
+    a->kco = ((int32_t)1 << (a->rso - 1)) + a->zpo * ((int32_t)1 << a->rso);
   }
 
   /* ---------------- LUTs ---------------- */

@@ -1,0 +1,78 @@
+/* AddressSanitizer + UndefinedBehaviorSanitizer run of the CPU-side C code (GPU sanitizers are not available on the
+ * pool): the oracle's restatement (oracle/yf_oracle.c) and the product's host table preparation (csrc/yf_host_prep.c).
+ * Built and run by tests/test_sanitizers.py:  prog <model.yfm> <golden_inputs.bin> <decode_tables_f32.bin>
+ * Prints "heads <fnv1a64>" of the heads of the golden frames; any sanitizer report aborts (-fno-sanitize-recover). */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../oracle/yf_oracle.h"
+#include "../../stm32h7-yolo_amd/csrc/yf_host_prep.h"
+
+extern const uint8_t yf_weights_blob[];
+
+static uint64_t fnv(const void* p, size_t n, uint64_t h) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  yfo_model* m = yfo_load(argv[1]);
+  if (!m) return 3;
+  FILE* f = fopen(argv[2], "rb");
+  if (!f) return 4;
+  enum { N = 6, IN = 56 * 56 * 3, OUT = 7 * 7 * 18 };
+  int8_t* x = malloc((size_t)N * IN);
+  if (fread(x, IN, N, f) != N) return 5;
+  fclose(f);
+  float tabs[512];
+  f = fopen(argv[3], "rb");
+  if (!f || fread(tabs, 4, 512, f) != 512) return 6;
+  fclose(f);
+
+  const long db = yfo_dump_bytes(m, 56, 56);
+  int8_t* heads = malloc((size_t)N * OUT);
+  int8_t* dump = malloc((size_t)N * db);
+  if (yfo_run(m, x, N, 56, 56, heads, dump, 2) != N) return 7;           /* two threads, every op output dumped */
+  int8_t* heads1 = malloc((size_t)N * OUT);
+  if (yfo_run(m, x, N, 56, 56, heads1, NULL, 1) != N || memcmp(heads, heads1, (size_t)N * OUT)) return 8;
+  /* another size: the network is fully convolutional */
+  int oh, ow, oc;
+  yfo_out_shape(m, 80, 72, &oh, &ow, &oc);
+  int8_t* big = calloc(80 * 72 * 3, 1);
+  int8_t* bigo = malloc((size_t)oh * ow * oc);
+  if (yfo_run(m, big, 1, 80, 72, bigo, NULL, 1) != 1) return 9;
+  /* decodes: a head where every candidate fires, and the golden heads */
+  yfo_det dets[147];
+  int8_t hot[OUT];
+  memset(hot, 127, sizeof hot);
+  if (yfo_decode_py(hot, 7, 7, 0, tabs, tabs + 256, 7.3f, 6.4f, dets, 147) != 147) return 10;
+  if (yfo_decode_c(hot, 0, tabs, tabs + 256, dets, 5) != 147) return 11;  /* capacity smaller than the count */
+  for (int i = 0; i < N; ++i) (void)yfo_decode_py(heads + i * OUT, 7, 7, i, tabs, tabs + 256, 1.f, 1.f, dets, 147);
+  int8_t lut[256];
+  for (int op = 0; op < yfo_num_ops(m); ++op) (void)yfo_leaky_lut(m, op, lut);
+  uint8_t* cam = malloc(112 * 112 * 2);
+  for (int i = 0; i < 112 * 112 * 2; ++i) cam[i] = (uint8_t)(i * 37 + 11);
+  int8_t prep[IN];
+  yfo_prepare_rgb565(cam, prep);
+
+  /* product host logic: table preparation from the 11304-byte blob, and its argument checks */
+  uint8_t* tab = NULL;
+  yf_table_index ix;
+  if (yf_prepare_tables(yf_weights_blob, 11304, &tab, &ix) != 0 || !tab) return 12;
+  const uint64_t th = fnv(tab, ix.total_bytes, 1469598103934665603ull);
+  free(tab);
+  tab = NULL;
+  if (yf_prepare_tables(yf_weights_blob, 11303, &tab, &ix) == 0) return 13;      /* short blob must be refused */
+  if (yf_prepare_tables(NULL, 11304, &tab, &ix) == 0) return 14;
+  int32_t mult; int shift;
+  yf_quantize_multiplier(0.000731, &mult, &shift);
+  (void)yf_mbqm(-123456, mult, shift);
+
+  printf("heads %016llx tables %016llx\n", (unsigned long long)fnv(heads, (size_t)N * OUT, 1469598103934665603ull), (unsigned long long)th);
+  free(x); free(heads); free(heads1); free(dump); free(big); free(bigo); free(cam);
+  yfo_free(m);
+  return 0;
+}

@@ -1,0 +1,34 @@
+"""ASan + UBSan over the CPU-side C code (oracle restatement and the product's host table preparation).  GPU
+sanitizers are not available on the pool, so this is where memory errors in the C sources would surface."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+def fnv(b):
+    h = 1469598103934665603
+    for v in b:
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_c_sources_are_clean_under_asan_and_ubsan(tmp_path):
+    exe = str(tmp_path / "sanitize_main")
+    csrc = os.path.join(ROOT, "stm32h7-yolo_amd", "csrc")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-Wall", "-Wextra", "-o", exe,
+                           os.path.join(ROOT, "tests", "csrc", "sanitize_main.c"), os.path.join(ROOT, "oracle", "yf_oracle.c"),
+                           os.path.join(csrc, "yf_host_prep.c"), os.path.join(csrc, "gen", "yf_weights_blob_gen.c"),
+                           "-lm", "-lpthread"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"), os.path.join(GOLDEN, "golden_inputs.bin"),
+                        os.path.join(GOLDEN, "decode_tables_f32.bin")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    heads = np.fromfile(os.path.join(GOLDEN, "golden_heads.bin"), np.uint8)
+    assert r.stdout.split()[1] == f"{fnv(heads.tobytes()):016x}"          # and the sanitized build reproduces the goldens
