@@ -137,15 +137,6 @@ __device__ __forceinline__ int requant(int acc, int mult, int kc, int rshift) {
   const int s = (int)(p >> 31);
   return (s + kc + (s >> 31)) >> rshift;
 }
-// generic MBQM with shift <= 0 (residual add path)
-__device__ __forceinline__ int mbqm_le0(int x, int mult, int shift) {
-  const long long p = (long long)x * (long long)mult + (1ll << 30);
-  const int s = (int)(p >> 31);
-  const int rs = -shift;
-  const int half = rs > 0 ? (1 << (rs - 1)) : 0;
-  const int sg = rs > 0 ? (s >> 31) : 0;
-  return (s + half + sg) >> rs;
-}
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
 __device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
   return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
@@ -268,30 +259,6 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
 
 // ------------------------------------------------------------------------------------------------ epilogue store
 struct AddCtx { int mo, kco, rso; };
-
-// packed int8x4 result of one 4-channel pass (no store): RAW / LUT / ADD forms
-template <int EPI, int LUT_ID, class ADDB>
-__device__ __forceinline__ uint32_t epilogue_value(const char* fbase, int p, int chq, const int (&y)[4], const AddCtx& ad) {
-  if constexpr (EPI == EPI_LUT) {
-    return lutb<LUT_ID>(clampi(y[0], 0, 255)) | (lutb<LUT_ID>(clampi(y[1], 0, 255)) << 8) |
-           (lutb<LUT_ID>(clampi(y[2], 0, 255)) << 16) | (lutb<LUT_ID>(clampi(y[3], 0, 255)) << 24);
-  } else if constexpr (EPI == EPI_RAW) {
-    return pack4(clampi(y[0], -128, 127), clampi(y[1], -128, 127), clampi(y[2], -128, 127), clampi(y[3], -128, 127));
-  } else {
-    static_assert(EPI == EPI_ADD, "value form");
-    typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
-    constexpr uint32_t LA = YF_N_LUT * 256 + LUT_ID * 2048, LB = LA + 1024;
-    const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq) ^ 0x80808080u;
-    int r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int sa = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255));
-      const int sb = *(lds_i32_ptr)(uint32_t)(LB + 4 * clampi(y[j], 0, 255));
-      r[j] = clampi(requant(sa + sb, ad.mo, ad.kco, ad.rso), -128, 127);
-    }
-    return pack4(r[0], r[1], r[2], r[3]);
-  }
-}
 
 template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
 __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
