@@ -94,7 +94,7 @@ def test_every_fused_stage_equals_the_matching_tflite_op(network, oracle, torch_
 
 
 @pytest.mark.parametrize("fw", VARIANTS)
-def test_kernel_variants_and_ragged_tails(network, oracle, torch_cuda, fw):
+def test_kernel_variants_and_ragged_tails(yf, network, oracle, torch_cuda, fw):
     torch = torch_cuda
     network.configure(*fw)
     for n in (1, 7, 130):
@@ -104,8 +104,25 @@ def test_kernel_variants_and_ragged_tails(network, oracle, torch_cuda, fw):
         network.run_device(d_in.data_ptr(), d_out.data_ptr(), n)
         torch.cuda.synchronize()
         got = d_out.cpu().numpy()
-        assert np.array_equal(got[:n], oracle.run(x, threads=8))
+        ref = oracle.run(x, threads=8)
+        assert np.array_equal(got[:n], ref)
         assert (got[n] == 77).all(), "wrote past the last frame"
+        # the same shape with the box decode fused into the launch (the decoding waves depend on F and NW)
+        cap = 4
+        d_d = torch.zeros((n + 1, cap, 28), dtype=torch.uint8, device="cuda")
+        d_c = torch.full((n + 1,), -7, dtype=torch.int32, device="cuda")
+        d_out.fill_(77)
+        network.run_decode_device(d_in.data_ptr(), d_out.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap, 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy()[:n], ref)
+        counts = d_c.cpu().numpy()
+        assert counts[n] == -7 and not d_d[n].any(), "decode wrote past the last frame"
+        buf = d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(n + 1, cap)
+        for f in range(n):
+            want = oracle.decode_c(ref[f], f)
+            assert counts[f] == len(want)
+            assert [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"]))
+                    for d in buf[f, :min(cap, counts[f])]] == [(d[1], d[2], d[3], d[6], d[7], d[8], d[9]) for d in want][:cap]
     network.configure(2, 8)
 
 
