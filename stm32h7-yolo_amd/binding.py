@@ -13,6 +13,8 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libyf_network.so")
+if os.environ.get("YF_LIB_PATH"):        # developer override: A/B of differently compiled libraries (tools/)
+    LIB_PATH = os.environ["YF_LIB_PATH"]
 
 AI_BUFFER_FORMAT_U8 = 0x00040440
 AI_BUFFER_FORMAT_S8 = 0x00840440
