@@ -2,7 +2,7 @@
 # VGPR / spill statistics of the fused kernels (shipped namespace yf, experimental yfx).  DEV TOOL, container only.
 #   usage: tools/kernel_regs.sh [extra hipcc flags, e.g. -DYF_LAUNDER_X=3]
 set -e
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -Os -std=c++17 -ffp-contract=off -fPIC -S --cuda-device-only -mllvm -amdgpu-sched-strategy=iterative-ilp "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -Os -std=c++17 -ffp-contract=off -fPIC -S --cuda-device-only -mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-lsr "$@" \
   -I/root/repo/stm32h7-yolo_amd/csrc /root/repo/stm32h7-yolo_amd/csrc/yf_engine.hip -o /tmp/yf_engine.s 2>/dev/null
 python3 - <<'PY'
 import re
