@@ -8,7 +8,7 @@ yf = importlib.import_module("stm32h7-yolo_amd")
 a = [int(v) for v in sys.argv[1:]]
 f, w = (a[0], a[1]) if len(a) >= 2 else (2, 8)
 fx, wx = (a[2], a[3]) if len(a) >= 4 else (f, w)
-n = 4096
+n = int(os.environ.get("YF_N", "4096"))
 x = np.random.default_rng(1).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
 net = yf.Network().init()
 d_in = torch.from_numpy(x).cuda(); d_a = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda"); d_b = torch.zeros_like(d_a)
