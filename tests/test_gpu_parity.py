@@ -276,6 +276,18 @@ def test_run_argument_errors_are_latched(network):
     assert lib.ai_network_get_error(network.handle).type == 0x13
     assert lib.ai_network_forward(network.handle, ctypes.byref(good_in)) == 2          # run without output
     assert lib.ai_network_run(network.handle, ctypes.byref(good_in), ctypes.byref(good_out)) == 2
+    # the device-pointer extensions use the same latch: null pointers, bad decode mode, zero capacity
+    import torch
+    d = torch.zeros((2 * 9408,), dtype=torch.int8, device="cuda")
+    for args in [(None, d.data_ptr(), 2, 0, 1.0, 1.0, d.data_ptr(), d.data_ptr(), 4, None),
+                 (d.data_ptr(), d.data_ptr(), 2, 7, 1.0, 1.0, d.data_ptr(), d.data_ptr(), 4, None),
+                 (d.data_ptr(), d.data_ptr(), 2, 0, 1.0, 1.0, d.data_ptr(), d.data_ptr(), 0, None),
+                 (d.data_ptr(), d.data_ptr(), 2, 0, 1.0, 1.0, None, d.data_ptr(), 4, None)]:
+        assert lib.yf_network_run_decode_device(network.handle, *args) <= 0
+        assert lib.ai_network_get_error(network.handle).type != 0
+        assert lib.ai_network_get_error(network.handle).type == 0
+    assert lib.yf_network_run_decode_device(network.handle, d.data_ptr(), d.data_ptr(), 0, 0, 1.0, 1.0, d.data_ptr(), d.data_ptr(), 4, None) == 0   # n = 0: nothing to do
+    assert lib.ai_network_get_error(network.handle).type == 0
 
 
 def test_weights_come_from_the_callers_blob(yf, network, oracle):
