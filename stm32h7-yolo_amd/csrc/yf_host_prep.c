@@ -88,10 +88,12 @@ static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_
   int32_t bias;
   memcpy(&bias, blob + d->b_off + 4 * (size_t)ch, 4);
   const int rs = -sh;
-  out->bias2 = bias - t_zp(d->t_in) * sum_w;
-  out->mult = m;
+  const int32_t bias2 = bias - t_zp(d->t_in) * sum_w;
+  const int32_t kc = ((int32_t)1 << (rs - 1)) + (t_zp(d->t_out) + z_extra) * ((int32_t)1 << rs);   /* the offset may be negative: multiply, do not shift */
+  out->bias_u = (int32_t)((uint32_t)bias2 ^ 0x80000000u);
+  out->mult2 = (uint32_t)m << 1;
+  out->khi = (int32_t)((uint32_t)kc - (uint32_t)m - 1u);
   out->rshift = rs;
-  out->kc = ((int32_t)1 << (rs - 1)) + (t_zp(d->t_out) + z_extra) * ((int32_t)1 << rs);   /* the offset may be negative: multiply, do not shift */
   return 0;
 }
 
@@ -190,7 +192,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
         const int ch = g * 4 + j;
         if (ch >= d->cout) {                 /* padding channel: harmless constants */
           for (int t = 0; t < 9; ++t) wd[t * 4 + j] = 0;
-          cc[j].bias2 = 0; cc[j].mult = (1 << 30) + 1; cc[j].rshift = 1; cc[j].kc = 1;
+          cc[j].bias_u = (int32_t)0x80000000u; cc[j].mult2 = ((1u << 30) + 1u) << 1; cc[j].rshift = 1; cc[j].khi = (int32_t)(1u - ((1u << 30) + 1u) - 1u);   /* padding channel: acc 0, M 2^30+1, kc 1 */
           continue;
         }
         int32_t sum_w = 0;

@@ -131,12 +131,17 @@ constexpr int IN_FRAME_BYTES = G0 * G0 * 3;
 enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 
 // ------------------------------------------------------------------------------------------------ arithmetic
-// TFLite MultiplyByQuantizedMultiplier for shift <= -1, fused with "+ zero point (+128)": see yf_tables.h.
-__device__ __forceinline__ int requant(int acc, int mult, int kc, int rshift) {
-  const long long p = (long long)acc * (long long)mult + (1ll << 30);     // v_mad_i64_i32
-  const int s = (int)(p >> 31);
-  return (s + kc + (s >> 31)) >> rshift;
+// TFLite MultiplyByQuantizedMultiplier for shift <= -1, fused with "+ zero point (+128)", on the sign-flipped accumulator
+// (yf_tables.h, yf_chan): one v_mad_u64_u32, v_lshrrev, v_add3, v_ashrrev.
+template <bool UNIFORM = true>
+__device__ __forceinline__ int requant(int acc_u, int mult2, int khi, int rshift) {
+  const unsigned long long d = (unsigned long long)(uint32_t)acc_u * (unsigned long long)(uint32_t)mult2 + 0x80000000ull;
+  const uint32_t t = (uint32_t)(d >> 32) + (uint32_t)khi + ((uint32_t)acc_u >> 31);
+  return (int)t >> rshift;
 }
+// the residual adds keep the plain constants (yf_add: mo, kco, rso): converted once per stage, scalar
+struct AddCtx { int mo2, khio, rso; };
+__device__ __forceinline__ AddCtx make_addctx(int mo, int kco, int rso) { return AddCtx{(int)((uint32_t)mo << 1), kco - mo - 1, rso}; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
 __device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
   return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
@@ -258,7 +263,6 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue store
-struct AddCtx { int mo, kco, rso; };
 
 template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
 __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
@@ -281,7 +285,7 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, cons
     for (int j = 0; j < 4; ++j) {
       const int sa = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255));
       const int sb = *(lds_i32_ptr)(uint32_t)(LB + 4 * clampi(y[j], 0, 255));
-      r[j] = clampi(requant(sa + sb, ad.mo, ad.kco, ad.rso), -128, 127);
+      r[j] = clampi(requant((sa + sb) ^ (int)0x80000000, ad.mo2, ad.khio, ad.rso), -128, 127);
     }
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = pack4(r[0], r[1], r[2], r[3]);
   } else {  // EPI_HEAD: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
@@ -484,7 +488,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* _
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
-// IN has a halo holding its zero point; the zero point itself is folded into bias2.  Jobs = channel group x
+// IN has a halo holding its zero point; the zero point itself is folded into the bias constant.  Jobs = channel group x
 // pixel chunk; the group's 36 masked weight dwords and 4 yf_chan are wave-uniform (scalar loads).
 template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
 YF_STAGE_FN void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
@@ -742,7 +746,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   const AddCtx no_add = {};
   auto addctx = [&](int k) {
     const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddCtx{(int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso))};
+    return make_addctx((int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso)));
   };
   constexpr long DS = DumpOffsets::TOTAL;
 #ifdef YF_BARPROF
@@ -937,7 +941,7 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
   const AddCtx no_add = {};
   auto addctx = [&](int k) {
     const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddCtx{(int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso))};
+    return make_addctx((int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso)));
   };
   for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
     char* frames = prm.arena + fr * (long)FRAME_BYTES;

@@ -15,15 +15,18 @@ extern "C" {
 #endif
 
 /* ---- per output channel requantisation constants (16 B) --------------------------------------------------
- * acc  = bias2 + sum w*x_raw                      (bias2 = bias - zp_in * sum(w): input zero point folded)
- * s    = SRDHM(acc, mult)                         (== floor((acc*mult + 2^30) / 2^31))
- * y    = (s + kc + (s >> 31)) >> rshift           (== RoundingDivideByPOT(s, rshift) + Z, needs rshift >= 1)
- *        kc = 2^(rshift-1) + (Z << rshift);  Z = zp_out + 128 when the value indexes a LUT, zp_out otherwise
- * The identity is exact for rshift >= 1; the host refuses to initialise a model with a channel outside it. */
+ * TFLite:  acc = bias - zp_in*sum(w) + sum w*x_raw;  s = SRDHM(acc, M) = floor((acc*M + 2^30) / 2^31);
+ *          y = RoundingDivideByPOT(s, rshift) + Z = (s + kc + (s >> 31)) >> rshift,  kc = 2^(rshift-1) + (Z << rshift),
+ *          Z = zp_out + 128 when the value indexes a LUT, zp_out otherwise (exact for rshift >= 1).
+ * Device form -- the accumulator carries acc + 2^31 (sign bit flipped: a valid UNSIGNED multiplicand whose top bit says
+ * "acc >= 0"), and with N = 2*acc*M + 2^31 + (kc + sg) * 2^32, sg = -(acc < 0), y = N >> (32 + rshift):
+ *          N >> 32 = hi32(acc_u * mult2 + 2^31) + khi + (acc_u >> 31)
+ * i.e. one v_mad_u64_u32, one shift, one three-operand add, one shift (the signed form needs v_alignbit as well).
+ * The host refuses a model with a channel outside 1 <= rshift <= 30 or M <= 2^30. */
 typedef struct {
-  int32_t bias2;
-  int32_t mult;
-  int32_t kc;
+  int32_t bias_u;      /* (bias - zp_in*sum(w)) ^ 0x80000000: MFMA accumulator initial value */
+  uint32_t mult2;      /* 2 * M */
+  int32_t khi;         /* kc - M - 1 (mod 2^32) */
   int32_t rshift;
 } yf_chan;
 

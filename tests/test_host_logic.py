@@ -111,11 +111,29 @@ def test_leaky_and_requant_luts_equal_oracle(prep, oracle, pack):
 
 
 def _chan(tab, off, i):
-    return struct.unpack_from("<4i", tab, off + 16 * i)
+    """yf_chan (yf_tables.h) holds the DEVICE form {bias ^ 2^31, 2*M, kc - M - 1, rshift}; returned here in the plain
+    form (bias2, mult, kc, rshift) the TFLite identity is stated in, together with the raw device words."""
+    bias_u, mult2, khi, rs = struct.unpack_from("<iIii", tab, off + 16 * i)
+    assert mult2 % 2 == 0
+    mult = mult2 >> 1
+    bias2 = ((bias_u & 0xFFFFFFFF) ^ 0x80000000)
+    bias2 = bias2 - (1 << 32) if bias2 >= (1 << 31) else bias2
+    kc = (khi + mult + 1 + (1 << 31)) % (1 << 32) - (1 << 31)
+    return bias2, mult, kc, rs
+
+
+def _device_requant(acc, bias2, mult, kc, rs):
+    """the kernel's arithmetic on 32/64-bit unsigned words: hi32(acc_u * 2M + 2^31) + (kc - M - 1) + (acc_u >> 31), >> rs"""
+    acc_u = (acc + (1 << 31)) & 0xFFFFFFFF
+    d = acc_u * ((2 * mult) & 0xFFFFFFFF) + (1 << 31)
+    t = ((d >> 32) + ((kc - mult - 1) & 0xFFFFFFFF) + (acc_u >> 31)) & 0xFFFFFFFF
+    t = t - (1 << 32) if t >= (1 << 31) else t
+    return t >> rs
 
 
 def _check_requant_identity(oracle, bias2, mult, kc, rs, zp_out, z_extra, rng):
-    """(s + kc + (s>>31)) >> rs == MBQM(acc, mult, -rs) + zp_out + z_extra on random and tie-prone accumulators."""
+    """(s + kc + (s>>31)) >> rs == MBQM(acc, mult, -rs) + zp_out + z_extra on random and tie-prone accumulators, and the
+    sign-flipped unsigned form the kernel evaluates gives the same."""
     accs = np.concatenate([rng.integers(-2**21, 2**21, 200), [0, 1, -1, bias2, -bias2]])
     # accumulators whose SRDHM lands exactly on a rounding tie of the second shift (both signs)
     half = 1 << (rs - 1)
@@ -129,6 +147,7 @@ def _check_requant_identity(oracle, bias2, mult, kc, rs, zp_out, z_extra, rng):
         fused = (s + kc + (s >> 31)) >> rs
         ref = oracle.lib.yfo_mbqm(acc, mult, -rs) + zp_out + z_extra
         assert fused == ref, (acc, mult, rs)
+        assert _device_requant(acc, bias2, mult, kc, rs) == ref, (acc, mult, rs)      # the form the kernel evaluates
 
 
 def test_dense_tables(prep, oracle, pack):
