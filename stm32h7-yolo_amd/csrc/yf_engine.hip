@@ -16,7 +16,7 @@
 #define YF_NS yfx
 #define YF_EXP 1
 #ifndef YF_LAUNDER_X
-#define YF_LAUNDER_X 7      /* experimental build: no hoisting of per-lane index arithmetic (83 VGPRs instead of 120) */
+#define YF_LAUNDER_X 0      /* 7: no hoisting of per-lane index arithmetic in the experimental build */
 #endif
 #undef YF_LAUNDER
 #define YF_LAUNDER YF_LAUNDER_X
@@ -80,18 +80,17 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 
 typedef void (*fused_fn)(const yf::NetParams);
 static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
-struct Variant { int f, nw; bool dump; bool dwm; bool exp; fused_fn fn; size_t lds; const char* name; };
+struct Variant { int f, nw; bool dump; bool exp; fused_fn fn; size_t lds; const char* name; };
 
-#define YF_VARIANT(F, NW, DUMP, DWM) { F, NW, DUMP, DWM, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP, DWM>, yf::lds_bytes<F, NW>(), \
-                                  "yoloface56_fused<F=" #F ",NW=" #NW ",DW=" #DWM ">" }
-#define YF_VARIANT_X(F, NW) { F, NW, false, true, true, (fused_fn)yfx::yoloface56_fused<F, NW, false, true>, yfx::lds_bytes<F, NW>(), \
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW>(), \
+                                  "yoloface56_fused<F=" #F ",NW=" #NW ">" }
+#define YF_VARIANT_X(F, NW) { F, NW, false, true, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW>(), \
                               "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
-// DW=true: depthwise on the matrix pipe (one-hot tap packing); DW=false: v_dot4 path (kept for A/B measurements)
+// production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
 const Variant k_variants[] = {
-  YF_VARIANT(1, 4, false, true), YF_VARIANT(2, 4, false, true), YF_VARIANT(4, 4, false, true), YF_VARIANT(2, 8, false, true), YF_VARIANT(4, 8, false, true),
-  YF_VARIANT(2, 6, false, true), YF_VARIANT(2, 4, false, false), YF_VARIANT(4, 8, false, false),
-  YF_VARIANT(2, 4, true, true), YF_VARIANT(2, 8, true, true),
-  YF_VARIANT_X(2, 8), YF_VARIANT_X(1, 4), YF_VARIANT_X(2, 12),
+  YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
+  YF_VARIANT(2, 4, true), YF_VARIANT(2, 8, true),
+  YF_VARIANT_X(2, 8),
 };
 
 }  // namespace
@@ -113,8 +112,8 @@ struct yf_engine {
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
-static const Variant* find_variant(int f, int nw, bool dump, bool dwm = true, bool exp = false) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.dwm == dwm && v.exp == exp) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool exp = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.exp == exp) return &v;
   return nullptr;
 }
 
@@ -152,9 +151,20 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
   if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_sig_bits), yf_sigmoid_bits, sizeof yf_sigmoid_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(sigmoid)");
   if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_exp_bits), yf_exp_bits, sizeof yf_exp_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(exp)");
-  for (const Variant& v : k_variants)
+  for (const Variant& v : k_variants) {
+    // The byte LUTs are addressed absolutely (LDS offset LUT_ID*256): the dynamic segment must start at LDS address 0,
+    // i.e. the kernel must not have picked up any static LDS.
+    hipFuncAttributes at;
+    if ((rc = hipFuncGetAttributes(&at, (const void*)v.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
+    if (at.sharedSizeBytes != 0) { delete e; return fail(std::string(v.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP); }
     if ((rc = hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds)) != hipSuccess)
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
+  }
+  {
+    hipFuncAttributes at;
+    if ((rc = hipFuncGetAttributes(&at, (const void*)yf160::generic_stage_kernel<1, 8>)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
+    if (at.sharedSizeBytes != 0) { delete e; return fail("generic stage kernel has static LDS", YF_ENG_ERR_HIP); }
+  }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
   e->var = find_variant(2, 8, false);
@@ -178,17 +188,15 @@ void yf_engine_destroy(yf_engine* e) {
 
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
-  /* frames_per_wg + 100 selects the v_dot4 depthwise build of the same shape (A/B measurements) */
   /* frames_per_wg + 200 selects the experimental (YF_EXP) build of the same shape */
   const bool exp = frames_per_wg >= 200;
   if (exp) frames_per_wg -= 200;
-  const bool dot4 = frames_per_wg >= 100;
-  if (dot4) frames_per_wg -= 100;
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
-  const Variant* v = find_variant(f, nw, false, !dot4, exp);
+  const Variant* v = find_variant(f, nw, false, exp);
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
-  if (const Variant* dv = find_variant(f, nw, true)) e->var_dump = dv;     /* debug build of the same shape, if compiled */
+  e->var_dump = exp ? nullptr : find_variant(f, nw, true);   /* debug build of the SAME shape, or none: the dump / stage-timing
+                                                                 entry points refuse instead of running another shape */
   return YF_ENG_OK;
 }
 
@@ -222,6 +230,7 @@ int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_du
 #ifdef YF_BARPROF
   return launch(e, e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);      // profile build: the production variant fills d_dump with barrier waits
 #else
+  if (d_dump && !e->var_dump) { e->err = "no debug (dump) build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
   return launch(e, d_dump ? e->var_dump : e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);
 #endif
 }
@@ -295,6 +304,7 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
 
 int yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch) {
   if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;
+  if (!e->var_dump) { e->err = "no debug (stage-timing) build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
   HIPCHK(e, hipSetDevice(e->device));
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(e, hipEventRecord(e->ev0, s));

@@ -76,25 +76,38 @@ static void build_requant_lut(int t_in, int t_out, uint8_t* lut) {
     lut[q + 128] = (uint8_t)sat8(yf_mbqm(q - t_zp(t_in), m, sh) + t_zp(t_out));
 }
 
-/* ---- per-channel requantisation constants ----------------------------------------------------------------- */
-/* z_extra = 128 when the result indexes a LUT, 0 when it is the final int8 value. Returns 0 or an error code. */
-static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int z_extra, yf_chan* out) {
+/* ---- per-channel requantisation constants (device form: yf_tables.h, yf_pass) -------------------------------- */
+/* 64-bit constant of the fused requantisation: (off)*2M + 2^31 + (2^(rs-1) - 1)*2^32 (mod 2^64), off = bias' - O. */
+static void build_c64(long long off, int32_t m, int rs, uint32_t out[2]) {
+  const unsigned long long c = (unsigned long long)off * (2ull * (unsigned long long)(uint32_t)m)   /* wraps mod 2^64 as intended */
+                             + (1ull << 31) + ((((unsigned long long)1 << (rs - 1)) - 1ull) << 32);
+  out[0] = (uint32_t)c; out[1] = (uint32_t)(c >> 32);
+}
+
+/* Channel j of pass p.  abs_w = sum |w| (bounds the accumulator).  Returns 0 or an error code. */
+static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int32_t abs_w, yf_pass* p, int j) {
   const float s_in = t_scale(d->t_in), s_out = t_scale(d->t_out);
   const float s_w = f32_from_bits(d->wscale_bits[ch]);
   int32_t m; int sh;
   yf_quantize_multiplier((double)s_in * (double)s_w / (double)s_out, &m, &sh);
-  if (sh > -1 || sh < -30) return YF_PREP_ERR_SHIFT_RANGE;      /* fused epilogue needs 1 <= rshift <= 30 */
+  if (sh > -1 || sh < -20) return YF_PREP_ERR_SHIFT_RANGE;      /* fused epilogue needs 1 <= rshift <= 20 */
   if (m <= (1 << 30)) return YF_PREP_ERR_SHIFT_RANGE;           /* normalised multiplier (frexp) is > 2^30 unless exact pow2 */
   int32_t bias;
   memcpy(&bias, blob + d->b_off + 4 * (size_t)ch, 4);
   const int rs = -sh;
-  const int32_t bias2 = bias - t_zp(d->t_in) * sum_w;
-  const int32_t kc = ((int32_t)1 << (rs - 1)) + (t_zp(d->t_out) + z_extra) * ((int32_t)1 << rs);   /* the offset may be negative: multiply, do not shift */
-  out->bias_u = (int32_t)((uint32_t)bias2 ^ 0x80000000u);
-  out->mult2 = (uint32_t)m << 1;
-  out->khi = (int32_t)((uint32_t)kc - (uint32_t)m - 1u);
-  out->rshift = rs;
+  const long long bias2 = (long long)bias - (long long)t_zp(d->t_in) * sum_w;
+  /* O + sum w*x_raw must stay a positive 32-bit multiplicand and the true accumulator below 2^29 in magnitude */
+  if ((bias2 < 0 ? -bias2 : bias2) + 255ll * abs_w >= (1ll << 29)) return YF_PREP_ERR_SHIFT_RANGE;
+  p->mult2[j] = (uint32_t)m << 1;
+  p->zr[j] = (uint32_t)(t_zp(d->t_out) + 128) << rs;
+  build_c64(bias2 - (long long)YF_ACC_OFFSET, m, rs, p->c64[j]);
+  p->rshift[j] = rs;
   return 0;
+}
+/* padding channel of a pass (cout not a multiple of 4): harmless constants, the byte it produces is never read */
+static void pad_chan(yf_pass* p, int j) {
+  p->mult2[j] = ((1u << 30) + 1u) << 1; p->zr[j] = 128u << 1; p->rshift[j] = 1;
+  build_c64(-(long long)YF_ACC_OFFSET, (1 << 30) + 1, 1, p->c64[j]);
 }
 
 static const yf_conv_desc* find_conv(int tfl_op) {
@@ -116,19 +129,19 @@ static size_t blob_alloc(blob_t* b, size_t n) {
   return off;
 }
 
-/* stage descriptors: tflite conv op, whether its output indexes a LUT (z_extra) ------------------------------ */
-typedef struct { int id; int tfl_op; int lut; } dense_plan;
+/* stage descriptors: the tflite conv op each dense stage evaluates --------------------------------------------- */
+typedef struct { int id; int tfl_op; } dense_plan;
 static const dense_plan k_dense[YF_N_DENSE] = {
-  {YF_D_CONV1, 1, 1}, {YF_D_C5, 5, 0}, {YF_D_C6, 6, 1}, {YF_D_C12, 12, 0}, {YF_D_C13, 13, 1}, {YF_D_C17, 17, 1},
-  {YF_D_C19, 19, 1}, {YF_D_C23, 23, 1}, {YF_D_C29, 29, 0}, {YF_D_C30, 30, 1}, {YF_D_C34, 34, 1}, {YF_D_C36, 36, 1},
-  {YF_D_C40, 40, 1}, {YF_D_C42, 42, 1}, {YF_D_C47, 47, 1}, {YF_D_C51, 51, 1}, {YF_D_C53, 53, 0},
+  {YF_D_CONV1, 1}, {YF_D_C5, 5}, {YF_D_C6, 6}, {YF_D_C12, 12}, {YF_D_C13, 13}, {YF_D_C17, 17},
+  {YF_D_C19, 19}, {YF_D_C23, 23}, {YF_D_C29, 29}, {YF_D_C30, 30}, {YF_D_C34, 34}, {YF_D_C36, 36},
+  {YF_D_C40, 40}, {YF_D_C42, 42}, {YF_D_C47, 47}, {YF_D_C51, 51}, {YF_D_C53, 53},
 };
 static const int k_dw_ops[YF_N_DW] = {3, 10, 15, 27, 32, 38, 49};
 
 /* conv2d_1 tap -> (k-step, byte slot) map: RGBX pixels, see yf_tables.h */
 static void conv1_slot(int ky, int kx, int c, int* step, int* slot) {
   const int pix = ky * 3 + kx;              /* 0..8 */
-  if (pix < 8) { *step = 0; *slot = pix * 4 + c; } else { *step = 1; *slot = c; }
+  *step = pix / 4; *slot = (pix % 4) * 4 + c;
 }
 
 int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** out_blob, yf_table_index* ix) {
@@ -154,15 +167,16 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
       o->krow = (uint16_t)((kk + 15) & ~15);
     }
     o->w_off = (uint32_t)blob_alloc(&b, (size_t)o->cout_pad4 * o->krow);
-    o->c_off = (uint32_t)blob_alloc(&b, (size_t)o->cout_pad4 * sizeof(yf_chan));
+    o->c_off = (uint32_t)blob_alloc(&b, (size_t)(o->cout_pad4 / 4) * sizeof(yf_pass));
+    for (int ch = d->cout; ch < o->cout_pad4; ++ch) pad_chan((yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3);
     for (int ch = 0; ch < d->cout; ++ch) {
       int8_t* row = (int8_t*)b.p + o->w_off + (size_t)ch * o->krow;
-      int32_t sum_w = 0;
-      for (int k = 0; k < kk; ++k) sum_w += w[(size_t)ch * kk + k];
+      int32_t sum_w = 0, abs_w = 0;
+      for (int k = 0; k < kk; ++k) { const int wv = w[(size_t)ch * kk + k]; sum_w += wv; abs_w += wv < 0 ? -wv : wv; }
       if (s == YF_D_CONV1) {
         for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) for (int c = 0; c < 3; ++c) {
           int step, slot; conv1_slot(ky, kx, c, &step, &slot);
-          row[step * 32 + slot] = w[(size_t)ch * 27 + (ky * 3 + kx) * 3 + c];
+          row[step * 16 + slot] = w[(size_t)ch * 27 + (ky * 3 + kx) * 3 + c];
         }
       } else if (s == YF_D_C23) {
         for (int k = 0; k < 18; ++k) row[k] = w[(size_t)ch * 36 + k];                       /* pool branch */
@@ -170,8 +184,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
       } else {
         memcpy(row, w + (size_t)ch * kk, (size_t)kk);
       }
-      yf_chan* c = (yf_chan*)(b.p + o->c_off) + ch;
-      rc = build_chan(d, weights_blob, ch, sum_w, k_dense[s].lut ? 128 : 0, c);
+      rc = build_chan(d, weights_blob, ch, sum_w, abs_w, (yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3);
       if (rc) break;
     }
   }
@@ -187,21 +200,21 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     const int8_t* w = (const int8_t*)weights_blob + d->w_off;                      /* 1HWC */
     for (int g = 0; g < o->ngroups; ++g) {
       uint32_t* wd = (uint32_t*)(b.p + o->g_off + (size_t)g * YF_DW_GROUP_BYTES);  /* [9 taps][4 lanes] */
-      yf_chan* cc = (yf_chan*)(wd + 36);
+      yf_pass* cc = (yf_pass*)(wd + 36);
       for (int j = 0; j < 4; ++j) {
         const int ch = g * 4 + j;
         if (ch >= d->cout) {                 /* padding channel: harmless constants */
           for (int t = 0; t < 9; ++t) wd[t * 4 + j] = 0;
-          cc[j].bias_u = (int32_t)0x80000000u; cc[j].mult2 = ((1u << 30) + 1u) << 1; cc[j].rshift = 1; cc[j].khi = (int32_t)(1u - ((1u << 30) + 1u) - 1u);   /* padding channel: acc 0, M 2^30+1, kc 1 */
+          pad_chan(cc, j);
           continue;
         }
-        int32_t sum_w = 0;
+        int32_t sum_w = 0, abs_w = 0;
         for (int t = 0; t < 9; ++t) {
           const int8_t wv = w[(size_t)t * d->cout + ch];
-          sum_w += wv;
-          wd[t * 4 + j] = ((uint32_t)(uint8_t)wv) << (8 * j);      /* byte j selects channel j in v_dot4 */
+          sum_w += wv; abs_w += wv < 0 ? -wv : wv;
+          wd[t * 4 + j] = ((uint32_t)(uint8_t)wv) << (8 * j);      /* byte j of the tap's dword carries channel j */
         }
-        rc = build_chan(d, weights_blob, ch, sum_w, 128, &cc[j]);  /* every depthwise conv feeds a LeakyReLU LUT */
+        rc = build_chan(d, weights_blob, ch, sum_w, abs_w, cc, j);
         if (rc) break;
       }
       if (rc) break;
@@ -222,6 +235,10 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     a->zp1 = t_zp(add_t[s][0]); a->zp2 = t_zp(add_t[s][1]); a->zpo = t_zp(add_t[s][2]);
     a->rso = -a->so;
     a->kco = ((int32_t)1 << (a->rso - 1)) + a->zpo * ((int32_t)1 << a->rso);
+    if (!rc && a->rso > 20) rc = YF_PREP_ERR_SHIFT_RANGE;
+    a->mo2 = (uint32_t)a->mo << 1;
+    a->zro = (uint32_t)(a->zpo + 128) << a->rso;
+    if (!rc) build_c64(-(long long)YF_ACC_OFFSET, a->mo, a->rso, a->c64o);
   }
 
   /* ---------------- LUTs ---------------- */
@@ -233,7 +250,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
       const yf_add* a = &ix->add[s];
       for (int q = -128; q < 128; ++q) {
         AL[(s * 2 + 0) * 256 + q + 128] = yf_mbqm((q - a->zp1) * (1 << 20), a->m1, a->s1);
-        AL[(s * 2 + 1) * 256 + q + 128] = yf_mbqm((q - a->zp2) * (1 << 20), a->m2, a->s2);
+        AL[(s * 2 + 1) * 256 + q + 128] = yf_mbqm((q - a->zp2) * (1 << 20), a->m2, a->s2) + YF_ACC_OFFSET;   /* |sa + sb| < 2^29 */
       }
     }
     static const int leaky[][3] = {       /* lut id, tensor in, tensor out (tflite LEAKY_RELU ops) */

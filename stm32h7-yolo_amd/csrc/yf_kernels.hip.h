@@ -7,9 +7,10 @@
 //   dense 3x3 / 1x1 conv  : v_mfma_i32_16x16x64_i8, weights as the A operand (rows = output channels), pixels as
 //                           the B operand (columns), block-diagonal packing (BD pixel sets per MFMA) for the skinny
 //                           layers, so every lane ends up owning 4 consecutive output channels of ONE pixel
-//   depthwise 3x3         : v_dot4_i32_i8 against byte-masked weight dwords held in SGPRs
-//   bias+requantize       : TFLite MultiplyByQuantizedMultiplier, fused:  s = (acc*M + 2^30) >> 31 ;
-//                           y = (s + kc + (s>>31)) >> rshift   (exact for rshift >= 1, checked on the host)
+//   depthwise 3x3         : the same MFMA with one-hot tap packing (lane-private: every lane owns one pixel)
+//   bias+requantize       : TFLite MultiplyByQuantizedMultiplier + zero point in four VALU instructions per output:
+//                           v_mad_u64_u32 (bias and both rounding constants in its 64-bit addend, its carry-out stands in
+//                           for TFLite's sign term), v_addc_co_u32, v_ashrrev, v_med3  (yf_tables.h, yf_pass)
 //   LeakyReLU / QUANTIZE  : 256-entry LDS byte LUTs built on the host with TFLite's fixed-point arithmetic
 //   max-pool              : separable, packed 2x int16 max on the byte lanes, clamped coordinates
 //   residual add          : TFLite int8 ADD arithmetic in the producing conv's epilogue
@@ -131,21 +132,46 @@ constexpr int IN_FRAME_BYTES = G0 * G0 * 3;
 enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 
 // ------------------------------------------------------------------------------------------------ arithmetic
-// TFLite MultiplyByQuantizedMultiplier for shift <= -1, fused with "+ zero point (+128)", on the sign-flipped accumulator
-// (yf_tables.h, yf_chan): one v_mad_u64_u32, v_lshrrev, v_add3, v_ashrrev.
-template <bool UNIFORM = true>
-__device__ __forceinline__ int requant(int acc_u, int mult2, int khi, int rshift) {
-  const unsigned long long d = (unsigned long long)(uint32_t)acc_u * (unsigned long long)(uint32_t)mult2 + 0x80000000ull;
-  const uint32_t t = (uint32_t)(d >> 32) + (uint32_t)khi + ((uint32_t)acc_u >> 31);
-  return (int)t >> rshift;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned long v4ul __attribute__((ext_vector_type(4)));
+// TFLite MultiplyByQuantizedMultiplier (shift <= -1) fused with "+ zero point + 128" for the four channels of a pass
+// (derivation: yf_tables.h, yf_pass).  acc = O + sum w*x_raw straight out of the MFMA (C operand = inline constant 2.0).
+//   {carry, d} = acc * 2M + C64      v_mad_u64_u32: multiplier in a VGPR, 64-bit addend in an SGPR pair, carry to an SGPR pair
+//   t = hi32(d) + ZR + carry         v_addc_co_u32
+// and the caller finishes with  idx = med3(t >> rshift, 0, 255).  Inline assembly because the carry-out of the multiply-add
+// has no C++ spelling; hipcc does not pad hazards for an asm statement (cdna_hip_programming.md 5.7), so the block that
+// consumes MFMA results opens with the wait states an MFMA result needs before a VALU read (the compiler emits 8 here).
+template <bool AFTER_MFMA>
+__device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, int (&t)[4]) {
+  v2u d0, d1, d2, d3;
+  unsigned long cy0, cy1, cy2, cy3;
+#define YF_RQ4_MADS "v_mad_u64_u32 %0, %4, %8, %12, %16\n\tv_mad_u64_u32 %1, %5, %9, %13, %17\n\t" \
+                    "v_mad_u64_u32 %2, %6, %10, %14, %18\n\tv_mad_u64_u32 %3, %7, %11, %15, %19"
+#define YF_RQ4_OPS : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(cy0), "=&s"(cy1), "=&s"(cy2), "=&s"(cy3) \
+                   : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(m2[0]), "v"(m2[1]), "v"(m2[2]), "v"(m2[3]), \
+                     "s"(c64[0]), "s"(c64[1]), "s"(c64[2]), "s"(c64[3])
+  if constexpr (AFTER_MFMA) asm("s_nop 7\n\ts_nop 1\n\t" YF_RQ4_MADS YF_RQ4_OPS);
+  else asm(YF_RQ4_MADS YF_RQ4_OPS);
+#undef YF_RQ4_MADS
+#undef YF_RQ4_OPS
+  asm("v_addc_co_u32_e64 %0, vcc, %4, %8, %12\n\tv_addc_co_u32_e64 %1, vcc, %5, %9, %13\n\t"
+      "v_addc_co_u32_e64 %2, vcc, %6, %10, %14\n\tv_addc_co_u32_e64 %3, vcc, %7, %11, %15"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+      : "v"(zr[0]), "v"(zr[1]), "v"(zr[2]), "v"(zr[3]), "v"(d0[1]), "v"(d1[1]), "v"(d2[1]), "v"(d3[1]),
+        "s"(cy0), "s"(cy1), "s"(cy2), "s"(cy3)
+      : "vcc");
 }
-// the residual adds keep the plain constants (yf_add: mo, kco, rso): converted once per stage, scalar
-struct AddCtx { int mo2, khio, rso; };
-__device__ __forceinline__ AddCtx make_addctx(int mo, int kco, int rso) { return AddCtx{(int)((uint32_t)mo << 1), kco - mo - 1, rso}; }
+// the four requantised channels of a pass as LUT indices / unsigned bytes (q + 128)
+template <bool AFTER_MFMA>
+__device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[4]) {
+  int t[4];
+  rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = min(max(t[j] >> rs[j], 0), 255);     // v_ashrrev, v_med3_i32
+}
+constexpr int ACC0 = YF_ACC_OFFSET;            // MFMA C operand: the inline constant 2.0 (no v_mov)
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
-__device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3) {
-  return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)b3 << 24);
-}
 // four zero-extended bytes -> one dword with three v_lshl_or_b32 (from a|b<<8|c<<16|d<<24 the compiler selects four ops)
 __device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
   uint32_t lo, hi, v;
@@ -154,7 +180,7 @@ __device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2,
   asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(v) : "v"(hi), "v"(lo));
   return v;
 }
-// Byte LUTs live at LDS offset LUT_ID*256 (the dynamic LDS segment starts at 0: the kernel has no static LDS and
+// Byte LUTs live at LDS offset LUT_ID*256 (the dynamic LDS segment starts at 0: the kernel has no static LDS; the host
 // checks it).  Absolute LDS addressing lets the table base ride in the ds_read immediate offset.
 typedef const __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
 template <int LUT_ID>
@@ -183,9 +209,21 @@ __device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret
 // wave-uniform table reads: the constant address space makes the compiler use scalar loads (SGPR results)
 typedef const __attribute__((address_space(4))) v4i* cv4i_ptr;
 typedef const __attribute__((address_space(4))) uint32_t* cu32_ptr;
+typedef const __attribute__((address_space(4))) v4ul* cv4ul_ptr;
 struct I4 { int x, y, z, w; };
 __device__ __forceinline__ I4 uniform_int4(const void* p) { const v4i v = *(cv4i_ptr)(uintptr_t)p; return I4{v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_ptr)(uintptr_t)p; }
+// yf_pass (80 B): mult2[4] and zr[4] go to VGPRs (vz is a zero the compiler cannot see through, which keeps the load a
+// vector load), c64[4] and rshift[4] to SGPRs
+struct PassV { v4u m2, zr; };
+__device__ __forceinline__ PassV load_pass_v(const uint8_t* pass, int vz) {
+  const v4u* p = reinterpret_cast<const v4u*>(pass + vz);
+  return PassV{p[0], p[1]};
+}
+struct PassS { v4ul c64; v4i rs; };
+__device__ __forceinline__ PassS load_pass_s(const uint8_t* pass) {
+  return PassS{*(cv4ul_ptr)(uintptr_t)(pass + 32), *(cv4i_ptr)(uintptr_t)(pass + 64)};
+}
 // stage descriptors out of the index at the head of the table blob, as scalar loads (offsets stay in SGPRs)
 __device__ __forceinline__ yf_dense load_dense(const uint8_t* tab, int i) {
   const uint8_t* p = tab + offsetof(yf_table_index, dense) + i * sizeof(yf_dense);
@@ -263,120 +301,49 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue store
+// residual add (tflite ADD): the final requantisation's constants are the same for every channel (yf_add, device form)
+struct AddK { uint32_t mo2, zro; unsigned long c64o; int rso; };
 
+// idx[4]: the pass's four requantised channels as unsigned bytes q + 128 (= LUT indices) of pixel p of frame f
 template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
-__device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, const uint8_t* luts, char* out_all, int f,
-                                               int p, int chq, const int (&y)[4], const AddCtx& ad) {
+__device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, char* out_all, int f, int p, int chq,
+                                               const int (&idx)[4], const AddK& ad) {
   if constexpr (EPI == EPI_LUT) {
-    const uint32_t v = join4(lutb<LUT_ID>(clampi(y[0], 0, 255)), lutb<LUT_ID>(clampi(y[1], 0, 255)),
-                             lutb<LUT_ID>(clampi(y[2], 0, 255)), lutb<LUT_ID>(clampi(y[3], 0, 255)));
-    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = v;
-  } else if constexpr (EPI == EPI_RAW) {
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
-        pack4(clampi(y[0], -128, 127), clampi(y[1], -128, 127), clampi(y[2], -128, 127), clampi(y[3], -128, 127));
+        join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+  } else if constexpr (EPI == EPI_RAW) {
+    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
   } else if constexpr (EPI == EPI_ADD) {
-    // tflite ADD (LUT_ID = add index): in1 = stored tensor (ADDB) -> table A, in2 = this conv's output -> table B,
-    // then one fused requantisation of the sum.
+    // tflite ADD (LUT_ID = add index): in1 = stored tensor (ADDB) -> table A, in2 = this conv's output -> table B (which
+    // carries the accumulator offset), then one fused requantisation of the sum.
     typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
     constexpr uint32_t LA = YF_N_LUT * 256 + LUT_ID * 2048, LB = LA + 1024;
     const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq) ^ 0x80808080u;
+    v4i sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      sum[j] = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255)) + *(lds_i32_ptr)(uint32_t)(LB + 4 * idx[j]);
     int r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int sa = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255));
-      const int sb = *(lds_i32_ptr)(uint32_t)(LB + 4 * clampi(y[j], 0, 255));
-      r[j] = clampi(requant((sa + sb) ^ (int)0x80000000, ad.mo2, ad.khio, ad.rso), -128, 127);
-    }
-    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = pack4(r[0], r[1], r[2], r[3]);
+    requant4<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro},
+                    v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
+    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
   } else {  // EPI_HEAD: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
-    const int v0 = clampi(y[0], -128, 127), v1 = clampi(y[1], -128, 127);
+    const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
     uint16_t* dst = reinterpret_cast<uint16_t*>(out_all + f * OUT_FRAME_BYTES + p * 18 + chq);
-    dst[0] = (uint16_t)((v0 & 255) | ((v1 & 255) << 8));
-    if (chq + 2 < 18) {
-      const int v2 = clampi(y[2], -128, 127), v3 = clampi(y[3], -128, 127);
-      dst[1] = (uint16_t)((v2 & 255) | ((v3 & 255) << 8));
-    }
+    dst[0] = (uint16_t)v;
+    if (chq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
   }
 }
 
-// ------------------------------------------------------------------------------------------------ dense 1x1, BD = 4
-// The skinny-K layers (K <= 16: conv2d_5/6/13/19/30/36/42).  64 pixels per MFMA, 4 output channels per tile.
-// A job = one 64-pixel m-tile x TPJ consecutive 4-channel tiles: pixel index arithmetic, the B fragment and the
-// output address are computed once per job and shared by its tiles; with BD = 4 every lane of the wave uses the SAME
-// four channels of a tile, so the requantisation constants are wave-uniform scalar loads instead of VGPRs.
-template <int F, int NW, int TPJ, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID>
-YF_STAGE_FN void dense4_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
-                                             const yf_dense d, int wave, int lane) {
-  constexpr int NTL = (COUT + 3) / 4;
-  constexpr int NCH = (NTL + TPJ - 1) / TPJ;                // channel-tile chunks
-  constexpr int P = IN::P, TOT = F * P;
-  constexpr int MT = (TOT + 63) / 64;
-  constexpr int JOBS = NCH * MT;
-  constexpr int RW = IN::S >= 16 ? 16 : IN::S;
-  static_assert(OUT::P == P, "1x1 conv keeps the grid");
-  static_assert(EPI == EPI_LUT || EPI == EPI_RAW, "epilogue kind");
-  const int g = lane >> 4, c = lane & 15;
-  int j0, j1;
-  job_range<JOBS, NW>(wave, j0, j1);
-  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
-  int cur_chunk = -1;
-  v4i a[TPJ];
-  for (int j = j0; j < j1; ++j) {
-    const int chunk = j / MT, mt = j - chunk * MT;
-    if (chunk != cur_chunk) {
-      cur_chunk = chunk;
-#pragma unroll
-      for (int t = 0; t < TPJ; ++t) {
-        const int nt = chunk * TPJ + t;
-        a[t] = v4i{0, 0, 0, 0};
-        if ((c >> 2) == g && nt < NTL) a[t] = *reinterpret_cast<const v4i*>(tab + d.w_off + (nt * 4 + (c & 3)) * 16);
-      }
-    }
-    const int q = mt * 64 + lane;                             // pixel set g, column c
-    const int qc = min(q, TOT - 1);
-    const int f = qc / P, p = qc - f * P;
-    char* fbase = frames + f * FRAME_BYTES;
-    v4i b = {0, 0, 0, 0};
-    {
-      const char* src = fbase + IN::at_p(p);
-      if constexpr (RW == 16) b = *reinterpret_cast<const v4i*>(src);
-      else if constexpr (RW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(src); b[0] = t2.x; b[1] = t2.y; }
-      else b[0] = *reinterpret_cast<const int*>(src);
-    }
-    char* dst = fbase + OUT::at_p(p) + OUT_CH0;
-#pragma unroll
-    for (int t = 0; t < TPJ; ++t) {
-      const int nt = chunk * TPJ + t;
-      if (nt < NTL) {                                         // uniform
-        const I4 k0 = uniform_int4(cp + nt * 4), k1 = uniform_int4(cp + nt * 4 + 1), k2 = uniform_int4(cp + nt * 4 + 2),
-                 k3 = uniform_int4(cp + nt * 4 + 3);
-        v4i acc = {k0.x, k1.x, k2.x, k3.x};
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t], b, acc, 0, 0, 0);
-        {                                   // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
-          const int y0 = requant(acc[0], k0.y, k0.z, k0.w), y1 = requant(acc[1], k1.y, k1.z, k1.w),
-                    y2 = requant(acc[2], k2.y, k2.z, k2.w), y3 = requant(acc[3], k3.y, k3.z, k3.w);
-          uint32_t v;
-          if constexpr (EPI == EPI_LUT)
-            v = join4(lutb<LUT_ID>(clampi(y0, 0, 255)), lutb<LUT_ID>(clampi(y1, 0, 255)), lutb<LUT_ID>(clampi(y2, 0, 255)),
-                      lutb<LUT_ID>(clampi(y3, 0, 255)));
-          else
-            v = pack4(clampi(y0, -128, 127), clampi(y1, -128, 127), clampi(y2, -128, 127), clampi(y3, -128, 127));
-          *reinterpret_cast<uint32_t*>(dst + nt * 4) = v;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ dense 1x1, lane-private
-// Generalisation of the BD = 4 form to any K: the lane's own pixel supplies KS fragments of 16 bytes (k-steps), the A
-// operand of k-step ks carries W[4*pass + (r&3)][16*ks ..] in row r's own slot group only, and KS MFMAs accumulate the
-// 4 channels of one pass for 64 pixels.  Every lane owns ONE pixel: no lane is wasted when Cout is not a multiple of
-// 16 (conv2d_17: 6, conv2d_34/40: 8, head: 18), the constants of a pass are wave-uniform scalars, and the pixel math
-// is shared by the TPJ passes of a job.  MFMA count grows (KS per 4 channels) but the matrix pipe is idle anyway.
-template <int F, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB>
-YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all, const uint8_t* __restrict__ tab,
-                                const yf_dense d, const AddCtx ad, int wave, int lane) {
+// ------------------------------------------------------------------------------------------------ dense 1x1
+// Lane-private MFMA: the lane's own pixel supplies KS fragments of 16 bytes (k-steps; the last one BW = 4, 8 or 16 bytes
+// wide), the A operand of k-step ks carries W[4*pass + (r&3)][16*ks ..] in row r's own slot group only, and KS MFMAs
+// accumulate the 4 channels of one pass for 64 pixels.  Every lane owns ONE pixel: no lane is wasted when Cout is not a
+// multiple of 16 (6, 8, 18, 24, 40), the constants of a pass are wave-uniform, and the pixel math is shared by the TPJ
+// passes of a job.  MFMA count grows (KS per 4 channels) but the matrix pipe is idle anyway.
+template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB>
+YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const yf_dense d, const AddK ad,
+                             int wave, int lane, int vz) {
   constexpr int NP = (COUT + 3) / 4;                        // passes of 4 output channels
   constexpr int NCH = (NP + TPJ - 1) / TPJ;
   constexpr int P = IN::P, TOT = F * P;
@@ -384,25 +351,27 @@ YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all
   constexpr int JOBS = NCH * MT;
   constexpr int KROW = 16 * KS;
   static_assert(OUT::P == P || EPI == EPI_HEAD, "1x1 conv keeps the grid");
-  static_assert(IN::S >= KROW, "the pixel vector must cover all k-steps");
+  static_assert(IN::S >= 16 * (KS - 1) + BW && (BW == 4 || BW == 8 || BW == 16), "the pixel vector must cover all k-steps");
   const int g = lane >> 4, c = lane & 15;
   int j0, j1;
   job_range<JOBS, NW>(wave, j0, j1);
-  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off);
+  const uint8_t* pp = tab + d.c_off;
   const bool a_on = (c >> 2) == g;
   int cur_chunk = -1;
   v4i a[TPJ][KS];
+  PassV pv[TPJ];
   for (int j = j0; j < j1; ++j) {
     const int chunk = j / MT, mt = j - chunk * MT;
     if (chunk != cur_chunk) {
       cur_chunk = chunk;
 #pragma unroll
       for (int t = 0; t < TPJ; ++t) {
-        const int ps = chunk * TPJ + t;
+        const int ps = min(chunk * TPJ + t, NP - 1);
+        pv[t] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           a[t][ks] = v4i{0, 0, 0, 0};
-          if (a_on && ps < NP) a[t][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks);
+          if (a_on) a[t][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks);
         }
       }
     }
@@ -414,119 +383,73 @@ YF_STAGE_FN void dense_lp_stage(char* frames, const uint8_t* luts, char* out_all
     {
       const char* src = fbase + IN::at_p(p);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
+      for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
+      const char* last = src + 16 * (KS - 1);
+      if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
+      else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, 0, 0}; }
+      else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), 0, 0, 0};
     }
 #pragma unroll
     for (int t = 0; t < TPJ; ++t) {
       const int ps = chunk * TPJ + t;
       if (ps < NP) {                                          // uniform
-        const I4 k0 = uniform_int4(cp + ps * 4), k1 = uniform_int4(cp + ps * 4 + 1), k2 = uniform_int4(cp + ps * 4 + 2),
-                 k3 = uniform_int4(cp + ps * 4 + 3);
-        v4i acc = {k0.x, k1.x, k2.x, k3.x};
+        const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
+        v4i acc = {ACC0, ACC0, ACC0, ACC0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
-        {                                   // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
-          const int y[4] = {requant(acc[0], k0.y, k0.z, k0.w), requant(acc[1], k1.y, k1.z, k1.w),
-                            requant(acc[2], k2.y, k2.z, k2.w), requant(acc[3], k3.y, k3.z, k3.w)};
-          epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, luts, out_all, f, p, ps * 4, y, ad);
-        }
+        int idx[4];                         // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
+        requant4<true>(acc, pv[t].m2, pv[t].zr, k.c64, k.rs, idx);
+        epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, out_all, f, p, ps * 4, idx, ad);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ conv2d_1
-// 3x3 stride 2, Cin 3 (RGBX) -> 8: two k-steps, BD=2 (32 output pixels x 8 channels per MFMA pair).
+// 3x3 stride 2, Cin 3 -> 8 on RGBX dwords, lane-private like the 1x1 stages: the lane's pixel gathers its nine taps
+// (nine aligned dwords of the staged frame) into three k-steps, both 4-channel passes share them.
 template <int F, int NW>
-YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
-                                            const yf_dense d, int wave, int lane) {
-  constexpr int P = B_T1::P, W1 = B_T1::W, RSW = B_IN::RS, TOT = F * P, PIX_T = 32;
-  constexpr int MT = (TOT + PIX_T - 1) / PIX_T;
+YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, const yf_dense d, int wave, int lane, int vz) {
+  constexpr int P = B_T1::P, W1 = B_T1::W, RSW = B_IN::RS, TOT = F * P;
+  constexpr int MT = (TOT + 63) / 64;
   const int g = lane >> 4, c = lane & 15;
-  const int set = g >> 1, half = g & 1;
-  // A fragments: rows 0..7 <-> set 0, rows 8..15 <-> set 1; channel = c & 7
-  const bool a_on = ((c >> 3) == set);
-  v4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-  if (a_on) {
-    const uint8_t* row = tab + d.w_off + (c & 7) * YF_CONV1_KROW;
-    a0 = *reinterpret_cast<const v4i*>(row + 16 * half);
-    a1 = *reinterpret_cast<const v4i*>(row + 32 + 16 * half);
-  }
-  const int chq = 4 * half;
-  const yf_chan* cp = reinterpret_cast<const yf_chan*>(tab + d.c_off) + chq;
-  int bias[4], mult[4], kc[4], rs[4];
+  const bool a_on = (c >> 2) == g;
+  const uint8_t* pp = tab + d.c_off;
+  v4i a[2][3];
+  PassV pv[2];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int4 t = *reinterpret_cast<const int4*>(cp + jj);
-    bias[jj] = t.x; mult[jj] = t.y; kc[jj] = t.z; rs[jj] = t.w;
+  for (int ps = 0; ps < 2; ++ps) {
+    pv[ps] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      a[ps][ks] = v4i{0, 0, 0, 0};
+      if (a_on) a[ps][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * YF_CONV1_KROW + 16 * ks);
+    }
   }
-  // dword offsets of this lane's taps relative to IN[2oy][2ox+3]  (see yf_tables.h, conv2d_1 packing)
-  const int o0 = half ? RSW + 1 : 0, o1 = half ? RSW + 2 : 1, o2 = half ? 2 * RSW : 2, o3 = half ? 2 * RSW + 1 : RSW;
   int j0, j1;
   job_range<MT, NW>(wave, j0, j1);
-  const AddCtx ad = {};
+  const AddK ad = {};
   for (int mt = j0; mt < j1; ++mt) {
-    const int q = mt * PIX_T + set * 16 + c;
+    const int q = mt * 64 + lane;
     const int qc = min(q, TOT - 1);
     const int f = qc / P, p = qc - f * P;
     const int oy = p / W1, ox = p - oy * W1;
     char* fbase = frames + f * FRAME_BYTES;
+    // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
-    v4i b0, b1 = {0, 0, 0, 0};
-    b0[0] = (int)src[o0]; b0[1] = (int)src[o1]; b0[2] = (int)src[o2]; b0[3] = (int)src[o3];
-    b1[0] = (int)src[2 * RSW + 2];                        // (ky,kx) = (2,2); weight rows are zero for half 1 / other dwords
-    v4i acc = {bias[0], bias[1], bias[2], bias[3]};
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-    {                                       // no exec mask (surplus lanes redo pixel TOT-1)
-      int y[4];
+    const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
+    const v4i b1 = {(int)src[RSW + 1], (int)src[RSW + 2], (int)src[2 * RSW], (int)src[2 * RSW + 1]};
+    const v4i b2 = {(int)src[2 * RSW + 2], 0, 0, 0};
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) y[jj] = requant(acc[jj], mult[jj], kc[jj], rs[jj]);
-      epilogue_store<EPI_LUT, YF_L_LEAKY2, B_T1, 0, B_T1>(fbase, luts, nullptr, f, p, chq, y, ad);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ depthwise 3x3
-// IN has a halo holding its zero point; the zero point itself is folded into the bias constant.  Jobs = channel group x
-// pixel chunk; the group's 36 masked weight dwords and 4 yf_chan are wave-uniform (scalar loads).
-template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
-YF_STAGE_FN void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
-                                         const yf_dw d, int wave, int lane) {
-  constexpr int NG = (C + 3) / 4;
-  constexpr int P = OUT::P, TOT = F * P;
-  constexpr int NB = (TOT + 63) / 64;                  // 64-pixel blocks per channel group
-  constexpr int JOBS = NG * NB;
-  int j, j1;
-  job_range<JOBS, NW>(wave, j, j1);
-  while (j < j1) {
-    const int cg = j / NB;
-    const int jend = min(j1, (cg + 1) * NB);
-    const uint32_t* wg = reinterpret_cast<const uint32_t*>(tab + d.g_off + cg * YF_DW_GROUP_BYTES);
-    const yf_chan* cp = reinterpret_cast<const yf_chan*>(wg + 36);
-    for (; j < jend; ++j) {
-      const int q = (j - cg * NB) * 64 + lane;
-      if (q >= TOT) continue;
-      const int f = q / P, p = q - f * P;
-      const int oy = p / OUT::W, ox = p - oy * OUT::W;
-      char* fbase = frames + f * FRAME_BYTES;
-      // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, col ox*STRIDE+kx
-      const char* src = fbase + IN::OFF + ((oy * STRIDE) * IN::RS + ox * STRIDE) * IN::S + 4 * cg;
-      const I4 k0 = uniform_int4(cp), k1 = uniform_int4(cp + 1), k2 = uniform_int4(cp + 2), k3 = uniform_int4(cp + 3);
-      int acc[4] = {k0.x, k1.x, k2.x, k3.x};
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tap = (int)lds_u32(src + (ky * IN::RS + kx) * IN::S);
-          const int t = ky * 3 + kx;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_sdot4(tap, (int)uniform_u32(wg + t * 4 + jj), acc[jj], false);
-        }
-      const int idx[4] = {clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
-                          clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255)};
-      const uint32_t v = lutb<LUT_ID>(idx[0]) | (lutb<LUT_ID>(idx[1]) << 8) | (lutb<LUT_ID>(idx[2]) << 16) | (lutb<LUT_ID>(idx[3]) << 24);
-      *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + 4 * cg) = v;
+    for (int ps = 0; ps < 2; ++ps) {
+      const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
+      v4i acc = {ACC0, ACC0, ACC0, ACC0};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][1], b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
+      int idx[4];                           // no exec mask (surplus lanes redo pixel TOT-1)
+      requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
+      epilogue_store<EPI_LUT, YF_L_LEAKY2, B_T1, 0, B_T1>(fbase, nullptr, f, p, 4 * ps, idx, ad);
     }
   }
 }
@@ -537,12 +460,12 @@ YF_STAGE_FN void dw_stage(char* frames, const uint8_t* luts, const uint8_t* __re
 // product over data that lane (g,c) itself supplied -- 64 independent pixels per MFMA, each lane working on ITS OWN
 // pixel.  One k-step carries 4 taps x 4 channels (4 aligned dwords of the pixel's halo'd neighbourhood), so the
 // 9 taps of a 3x3 depthwise filter take 3 k-steps; A holds w[tap][channel j] at byte j of tap's dword in row 4g+j.
-// Per 64 pixels x 4 channels: 9 ds_read_b32 off one address register, 3 MFMAs, no VALU multiply at all
-// (the v_dot4 form needs 36).  A job = 4 output rows x 16 columns (2 frames side by side for the 7x7 grids);
-// border blocks are shifted inwards so every lane's neighbourhood address is in range.
+// Per 64 pixels x 4 channels: 9 ds_read_b32 off one address register, 3 MFMAs, no VALU multiply at all.
+// IN has a halo holding its zero point; the zero point itself is folded into the requantisation constant.
+// A job = 4 output rows x 16 columns (2 frames side by side for the 7x7 grids); border blocks are shifted inwards so
+// every lane's neighbourhood address is in range.
 template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
-YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t* __restrict__ tab,
-                               const yf_dw d, int wave, int lane) {
+YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, const yf_dw d, int wave, int lane, int vz) {
   constexpr int W = OUT::W, H = OUT::H;
   constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;       // frames side by side in the 16 lanes of a row tile
   constexpr int NSEG = (W + 15) / 16;                       // 16-column segments, the last one shifted left (28 -> x0 in {0, 12})
@@ -566,8 +489,8 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
   while (j < j1) {
     const int cg = j / JPG;
     const int jend = min(j1, (cg + 1) * JPG);
-    const uint32_t* wg = reinterpret_cast<const uint32_t*>(tab + d.g_off + cg * YF_DW_GROUP_BYTES);
-    const yf_chan* cp = reinterpret_cast<const yf_chan*>(wg + 36);
+    const uint8_t* grp = tab + d.g_off + cg * YF_DW_GROUP_BYTES;
+    const uint32_t* wg = reinterpret_cast<const uint32_t*>(grp);
     v4i a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;                // k-steps: taps 0-3, 4-7, 8
     if (a_on) {
       const uint32_t* wl = wg + (c & 3);                    // masked weight dwords of channel c&3: wl[4*tap]
@@ -575,7 +498,8 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
       a1 = v4i{(int)wl[16], (int)wl[20], (int)wl[24], (int)wl[28]};
       a2[0] = (int)wl[32];
     }
-    const I4 k0 = uniform_int4(cp), k1 = uniform_int4(cp + 1), k2 = uniform_int4(cp + 2), k3 = uniform_int4(cp + 3);
+    const PassV pv = load_pass_v(grp + 144, vz);
+    const PassS k = load_pass_s(grp + 144);
     for (; j < jend; ++j) {
       int rem = j - cg * JPG;
       const int fp = rem / (NRB * NSEG); rem -= fp * (NRB * NSEG);
@@ -588,16 +512,14 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* luts, const uint8_t*
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
       b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
-      v4i acc = {k0.x, k1.x, k2.x, k3.x};
+      v4i acc = {ACC0, ACC0, ACC0, ACC0};
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-      {
-        const int i0 = clampi(requant(acc[0], k0.y, k0.z, k0.w), 0, 255), i1 = clampi(requant(acc[1], k1.y, k1.z, k1.w), 0, 255),
-                  i2 = clampi(requant(acc[2], k2.y, k2.z, k2.w), 0, 255), i3 = clampi(requant(acc[3], k3.y, k3.z, k3.w), 0, 255);
-        const uint32_t v = join4(lutb<LUT_ID>(i0), lutb<LUT_ID>(i1), lutb<LUT_ID>(i2), lutb<LUT_ID>(i3));
-        *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) = v;
-      }
+      int idx[4];
+      requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
+      *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) =
+          join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
     }
   }
 }
@@ -649,7 +571,7 @@ YF_STAGE_FN void pool8_h(char* frames, int tid) {
   }
 }
 template <int F, int NT>
-YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
+YF_STAGE_FN void pool8_v(char* frames, int tid) {
   constexpr int NO = 5, OW = B_HB::W, OH = B_T14::H, NCH = (OH + NO - 1) / NO;   // the last chunk shifted up
   static_assert(OH >= NO, "column shorter than one sweep");
   for (int i = tid; i < F * OW * NCH * 5; i += NT) {
@@ -666,7 +588,7 @@ YF_STAGE_FN void pool8_v(char* frames, const uint8_t* luts, int tid) {
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
 template <int F, int NT>
-YF_STAGE_FN void pool25(char* frames, const uint8_t* luts, int tid) {
+YF_STAGE_FN void pool25(char* frames, int tid) {
   constexpr int PP = B_T30::P, OW = B_T30::W, LIM = B_T15::W - 1;
   for (int i = tid; i < F * PP * 6; i += NT) {
     const int cg = i % 6; int t = i / 6;
@@ -723,17 +645,18 @@ struct NetParams {
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
-template <int F, int NW, bool DUMP, bool DWM>
+template <int F, int NW, bool DUMP>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
-  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);
-  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();   // LUTs are addressed absolutely
+  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
   char* out_all = smem + LUT_BYTES;
   char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
   const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
   // Static issue priority for the first-dispatched half of the workgroup (waves w and w + NW/2 share a SIMD): one wave of
   // every SIMD pair runs ahead instead of both stalling on the same stage phases.  In-run A/B: -1.9 % kernel time; the
   // opposite assignment (younger half) costs +3.5 %, per-workgroup priorities do nothing.
@@ -743,10 +666,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
 
   const long n_groups = (prm.n + F - 1) / F;
-  const AddCtx no_add = {};
+  const AddK no_add = {};
   auto addctx = [&](int k) {
     const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return make_addctx((int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso)));
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   constexpr long DS = DumpOffsets::TOTAL;
 #ifdef YF_BARPROF
@@ -799,89 +724,89 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()
-    conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), W_f, L_f);                        // conv2d_1
+    conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), W_f, L_f, vz);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), W_f, L_f); else dw_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), W_f, L_f);   // conv2d_3
+    dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), W_f, L_f, vz);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
-    dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), W_f, L_f);   // conv2d_5
+    dense_stage<F, NW, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3>(frames, out_all, tab, load_dense(tab, YF_D_C5), no_add, W_f, L_f, vz);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
     fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid_f);
-    dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), W_f, L_f);   // conv2d_6
+    dense_stage<F, NW, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, out_all, tab, load_dense(tab, YF_D_C6), no_add, W_f, L_f, vz);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
     YF_SYNC();
     YF_STAGE_END()
-    pool8_v<F, NT>(frames, luts, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
+    pool8_v<F, NT>(frames, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), W_m, L_m); else dw_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), W_m, L_m);   // conv2d_10
+    dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), W_m, L_m, vz);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, W_m, L_m);
+    dense_stage<F, NW, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C12), no_add, W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
     fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid_m);
-    dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), W_m, L_m);  // conv2d_13
+    dense_stage<F, NW, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, out_all, tab, load_dense(tab, YF_D_C13), no_add, W_m, L_m, vz);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), W_m, L_m); else dw_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), W_m, L_m);   // conv2d_15
+    dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), W_m, L_m, vz);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), W_m, L_m);
+    dense_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), W_m, L_m);  // conv2d_19 -> concat_22
+    dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, W_m, L_m, vz);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
-    dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m);
+    dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
-    pool25<F, NT>(frames, luts, tid_t);                                                              // pool_25 + QUANTIZE#45
-    if constexpr (DWM) dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), W_t, L_t); else dw_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), W_t, L_t);   // conv2d_27
+    pool25<F, NT>(frames, tid_t);                                                              // pool_25 + QUANTIZE#45
+    dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), W_t, L_t, vz);   // conv2d_27
     YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t);
+    dense_stage<F, NW, 1, 2, 16, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t, vz);
     decode_prev(W_t, L_t);                                                                         // previous group's boxes
     YF_SYNC(); YF_DUMP(B_T18, 8, T18)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
-    dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), W_t, L_t);  // conv2d_30
+    dense_stage<F, NW, 3, 1, 8, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, W_t, L_t, vz);  // conv2d_30
     YF_SYNC(); YF_DUMP(B_T19, 40, T19)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), W_t, L_t);   // conv2d_32
+    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), W_t, L_t, vz);   // conv2d_32
     YF_SYNC(); YF_DUMP(B_T20, 40, T20)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t);
+    dense_stage<F, NW, 1, 3, 16, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t, vz);
     YF_SYNC(); YF_DUMP(B_T22, 8, T22)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
-    dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), W_t, L_t);  // conv2d_36
+    dense_stage<F, NW, 3, 1, 8, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, W_t, L_t, vz);  // conv2d_36
     YF_SYNC(); YF_DUMP(B_T19, 40, T23)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), W_t, L_t);   // conv2d_38
+    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), W_t, L_t, vz);   // conv2d_38
     YF_SYNC(); YF_DUMP(B_T20, 40, T24)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t);
+    dense_stage<F, NW, 1, 3, 16, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t, vz);
     YF_SYNC(); YF_DUMP(B_T26, 8, T26)
     YF_STAGE_END()
-    dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), W_t, L_t);  // conv2d_42 -> concat_46
+    dense_stage<F, NW, 2, 1, 8, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44, B_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, W_t, L_t, vz);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP(B_T30, 48, T30)
     YF_STAGE_END()
     fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
-    dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t);
+    dense_stage<F, NW, 2, 3, 16, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t, vz);
     YF_SYNC(); YF_DUMP(B_T19, 40, T31)
     YF_STAGE_END()
-    if constexpr (DWM) dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), W_t, L_t); else dw_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), W_t, L_t);   // conv2d_49
+    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), W_t, L_t, vz);   // conv2d_49
     YF_SYNC(); YF_DUMP(B_T20, 40, T32)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t);
+    dense_stage<F, NW, 2, 3, 16, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t, vz);
     YF_SYNC(); YF_DUMP(B_T33, 32, T33)
     YF_STAGE_END()
-    dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t);
+    dense_stage<F, NW, 1, 2, 16, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
     YF_SYNC();
     {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
       const long valid = min((long)F, prm.n - first);
@@ -930,85 +855,89 @@ template <int ST, int NW>
 __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64, F = 1;
-  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);
-  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // addressed absolutely (host-checked: no static LDS)
+  char* out_all = nullptr;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint8_t* __restrict__ tab = prm.tab;
   for (int i = tid; i < LUT_BYTES / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
   __syncthreads();
-  const AddCtx no_add = {};
+  const AddK no_add = {};
   auto addctx = [&](int k) {
     const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return make_addctx((int)uniform_u32(a + offsetof(yf_add, mo)), (int)uniform_u32(a + offsetof(yf_add, kco)), (int)uniform_u32(a + offsetof(yf_add, rso)));
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
     char* frames = prm.arena + fr * (long)FRAME_BYTES;
-    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
+    out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
     if constexpr (ST == 0) {
       stage_input<F, NT>(frames, prm.in, fr, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid);
       fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid);
     } else if constexpr (ST == 1) {
-      conv1_stage<F, NW>(frames, luts, tab, load_dense(tab, YF_D_CONV1), wave, lane);
+      conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
     } else if constexpr (ST == 2) {
-      dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, luts, tab, load_dw(tab, YF_W_DW3), wave, lane);
+      dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
     } else if constexpr (ST == 3) {
-      dense4_stage<F, NW, 1, B_T2, B_T3, 0, 4, EPI_RAW, 0>(frames, luts, tab, load_dense(tab, YF_D_C5), wave, lane);
+      dense_stage<F, NW, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3>(frames, out_all, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
     } else if constexpr (ST == 4) {
       fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid);
-      dense4_stage<F, NW, 3, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7>(frames, luts, tab, load_dense(tab, YF_D_C6), wave, lane);
+      dense_stage<F, NW, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, out_all, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
     } else if constexpr (ST == 5) {
       pool8_h<F, NT>(frames, tid);
     } else if constexpr (ST == 6) {
-      pool8_v<F, NT>(frames, luts, tid);
+      pool8_v<F, NT>(frames, tid);
     } else if constexpr (ST == 7) {
-      dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, luts, tab, load_dw(tab, YF_W_DW10), wave, lane);
+      dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
     } else if constexpr (ST == 8) {
-      dense_lp_stage<F, NW, 1, 2, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane);
+      dense_stage<F, NW, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
     } else if constexpr (ST == 9) {
       fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid);
-      dense4_stage<F, NW, 3, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14>(frames, luts, tab, load_dense(tab, YF_D_C13), wave, lane);
+      dense_stage<F, NW, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, out_all, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
     } else if constexpr (ST == 10) {
-      dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, luts, tab, load_dw(tab, YF_W_DW15), wave, lane);
+      dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
     } else if constexpr (ST == 11) {
-      dense_lp_stage<F, NW, 1, 3, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, luts, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane);
+      dense_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
     } else if constexpr (ST == 12) {
-      dense4_stage<F, NW, 2, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20>(frames, luts, tab, load_dense(tab, YF_D_C19), wave, lane);
+      dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
     } else if constexpr (ST == 13) {
       fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid);
-      dense_lp_stage<F, NW, 2, 3, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, luts, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane);
+      dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
     } else if constexpr (ST == 14) {
-      pool25<F, NT>(frames, luts, tid);
-      dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, luts, tab, load_dw(tab, YF_W_DW27), wave, lane);
+      pool25<F, NT>(frames, tid);
+      dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
     } else if constexpr (ST == 15) {
-      dense_lp_stage<F, NW, 1, 2, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane);
+      dense_stage<F, NW, 1, 2, 16, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
     } else if constexpr (ST == 16) {
       fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
-      dense4_stage<F, NW, 3, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31>(frames, luts, tab, load_dense(tab, YF_D_C30), wave, lane);
+      dense_stage<F, NW, 3, 1, 8, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, wave, lane, vz);
     } else if constexpr (ST == 17) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, luts, tab, load_dw(tab, YF_W_DW32), wave, lane);
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
     } else if constexpr (ST == 18) {
-      dense_lp_stage<F, NW, 1, 3, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, luts, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane);
+      dense_stage<F, NW, 1, 3, 16, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
     } else if constexpr (ST == 19) {
       fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
-      dense4_stage<F, NW, 3, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37>(frames, luts, tab, load_dense(tab, YF_D_C36), wave, lane);
+      dense_stage<F, NW, 3, 1, 8, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, wave, lane, vz);
     } else if constexpr (ST == 20) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, luts, tab, load_dw(tab, YF_W_DW38), wave, lane);
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), wave, lane, vz);
     } else if constexpr (ST == 21) {
-      dense_lp_stage<F, NW, 1, 3, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, luts, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane);
+      dense_stage<F, NW, 1, 3, 16, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
     } else if constexpr (ST == 22) {
-      dense4_stage<F, NW, 2, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44>(frames, luts, tab, load_dense(tab, YF_D_C42), wave, lane);
+      dense_stage<F, NW, 2, 1, 8, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44, B_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
     } else if constexpr (ST == 23) {
       fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
-      dense_lp_stage<F, NW, 2, 3, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, luts, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane);
+      dense_stage<F, NW, 2, 3, 16, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane, vz);
     } else if constexpr (ST == 24) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, luts, tab, load_dw(tab, YF_W_DW49), wave, lane);
+      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), wave, lane, vz);
     } else if constexpr (ST == 25) {
-      dense_lp_stage<F, NW, 2, 3, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane);
+      dense_stage<F, NW, 2, 3, 16, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane, vz);
     } else {
       static_assert(ST == 26, "stage index");
-      dense_lp_stage<F, NW, 1, 2, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, luts, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane);
+      dense_stage<F, NW, 1, 2, 16, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
     }
   }
 }

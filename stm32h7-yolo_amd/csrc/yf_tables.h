@@ -14,46 +14,55 @@
 extern "C" {
 #endif
 
-/* ---- per output channel requantisation constants (16 B) --------------------------------------------------
- * TFLite:  acc = bias - zp_in*sum(w) + sum w*x_raw;  s = SRDHM(acc, M) = floor((acc*M + 2^30) / 2^31);
- *          y = RoundingDivideByPOT(s, rshift) + Z = (s + kc + (s >> 31)) >> rshift,  kc = 2^(rshift-1) + (Z << rshift),
- *          Z = zp_out + 128 when the value indexes a LUT, zp_out otherwise (exact for rshift >= 1).
- * Device form -- the accumulator carries acc + 2^31 (sign bit flipped: a valid UNSIGNED multiplicand whose top bit says
- * "acc >= 0"), and with N = 2*acc*M + 2^31 + (kc + sg) * 2^32, sg = -(acc < 0), y = N >> (32 + rshift):
- *          N >> 32 = hi32(acc_u * mult2 + 2^31) + khi + (acc_u >> 31)
- * i.e. one v_mad_u64_u32, one shift, one three-operand add, one shift (the signed form needs v_alignbit as well).
- * The host refuses a model with a channel outside 1 <= rshift <= 30 or M <= 2^30. */
+/* ---- requantisation constants of one PASS = 4 consecutive output channels (80 B) ------------------------------
+ * TFLite:  acc = bias - zp_in*sum(w) + sum w*x_raw;  s1 = SRDHM(acc, M) = floor(acc*M / 2^31 + 1/2);
+ *          y = RoundingDivideByPOT(s1, r) + Z = floor((s1 + h - [s1 < 0]) / 2^r) + Z,  h = 2^(r-1),  Z = zp_out + 128
+ *          (every stage produces the unsigned byte q + 128: it indexes a LUT / an add table, or is flipped back with ^0x80).
+ * Device form -- the MFMA accumulator starts at O = 2^30 (the inline constant 2.0 as the C operand: no v_mov), so
+ * acc_p = O + sum w*x_raw is a positive 32-bit multiplicand, and with
+ *          N = acc*2M + 2^31 + (h-1)*2^32 = acc_p*2M + C64,     C64 = (bias' - O)*2M + 2^31 + (h-1)*2^32  (mod 2^64)
+ * one v_mad_u64_u32 yields  hi32 = s1 + h - 1  and, as its carry-out, [N >= 0] = [s1 > -h]; every accumulator with
+ * -h < s1 < 0 rounds to 0 either way, so  s1 + h - [s1 < 0]  may be taken as  hi32 + carry:
+ *          y + Z = (hi32 + ZR + carry) >> r,   ZR = Z << r      (one v_addc_co_u32 with the carry, one v_ashrrev)
+ * followed by the clamp to [0, 255] (v_med3).  Four VALU instructions per output; bias, zero points and both rounding
+ * constants live in C64 / ZR.  The host refuses a model with a channel outside 1 <= r <= 20, M <= 2^30 or
+ * |bias'| + 255*sum|w| >= 2^29.
+ * Layout is struct-of-arrays so that one vector load brings the four multipliers (VGPRs: the multiplicand and the 64-bit
+ * addend cannot both come from SGPRs) and scalar loads bring the rest. */
+#define YF_ACC_OFFSET 0x40000000          /* O: bit pattern of the inline constant 2.0f */
 typedef struct {
-  int32_t bias_u;      /* (bias - zp_in*sum(w)) ^ 0x80000000: MFMA accumulator initial value */
-  uint32_t mult2;      /* 2 * M */
-  int32_t khi;         /* kc - M - 1 (mod 2^32) */
-  int32_t rshift;
-} yf_chan;
+  uint32_t mult2[4];   /* 2 * M                                  (vector registers) */
+  uint32_t zr[4];      /* (zp_out + 128) << rshift               (vector registers) */
+  uint32_t c64[4][2];  /* C64: low dword, high dword             (scalar register pairs) */
+  int32_t  rshift[4];  /*                                        (scalar registers) */
+} yf_pass;
 
 /* ---- dense (MFMA) stage ----------------------------------------------------------------------------------
  * Weight rows are stored [cout_pad4][krow] int8, krow = K rounded up to 16, zero filled; the k order is the
  * channel order of the stage's INPUT buffer (which may be a permutation of the tflite order: concat buffers). */
 typedef struct {
   uint32_t w_off;      /* byte offset of the weight rows in the table blob (16-B aligned) */
-  uint32_t c_off;      /* byte offset of the yf_chan array (cout_pad4 entries) */
+  uint32_t c_off;      /* byte offset of the yf_pass array (cout_pad4 / 4 entries) */
   uint16_t cout, cout_pad4, k, krow;
 } yf_dense;
 
-/* ---- depthwise stage: per group of 4 channels: 9 taps x 4 masked weight dwords, then 4 yf_chan ------------ */
+/* ---- depthwise stage: per group of 4 channels: 9 taps x 4 masked weight dwords, then one yf_pass --------- */
 typedef struct {
   uint32_t g_off;      /* byte offset of group 0; each group is YF_DW_GROUP_BYTES */
   uint16_t c, ngroups;
 } yf_dw;
-#define YF_DW_GROUP_BYTES (36 * 4 + 4 * 16)
+#define YF_DW_GROUP_BYTES (36 * 4 + 80)
 
 /* ---- residual add (tflite ADD, int8): out = clamp(zpo + MBQM(MBQM((a-zp1)<<20,m1,s1) + MBQM((b-zp2)<<20,m2,s2), mo, so)) */
 typedef struct {
   int32_t zp1, zp2, zpo;
   int32_t m1, s1, m2, s2, mo, so;
-  int32_t kco, rso;    /* fused final requantisation of sa+sb: y = (s + kco + (s>>31)) >> rso, rso = -so >= 1 */
+  int32_t kco, rso;    /* plain form of the final requantisation of sa+sb: y = (s + kco + (s>>31)) >> rso, rso = -so >= 1 */
+  uint32_t mo2, zro;   /* device form (see yf_pass): 2*mo, (zpo + 128) << rso */
+  uint32_t c64o[2];    /* (-O)*2mo + 2^31 + (2^(rso-1) - 1)*2^32: the offset O rides in table B */
 } yf_add;
 /* Device form of an ADD: two 256-entry int32 tables, index q+128:
- *   A[q1] = MBQM((q1 - zp1) << 20, m1, s1)   (the stored operand)     B[q2] = MBQM((q2 - zp2) << 20, m2, s2)
+ *   A[q1] = MBQM((q1 - zp1) << 20, m1, s1)   (the stored operand)     B[q2] = MBQM((q2 - zp2) << 20, m2, s2) + O
  * laid out [YF_N_ADD][2][256] right behind the byte LUTs. */
 #define YF_ADDLUT_BYTES (YF_N_ADD * 2 * 256 * 4)
 
@@ -73,10 +82,10 @@ enum {
   YF_L_LEAKY48, YF_L_LEAKY50, YF_L_LEAKY52, YF_N_LUT
 };
 
-/* conv2d_1 packs its 27 taps into two MFMA k-steps over RGBX pixels (4 bytes per pixel, X weight = 0):
- * step 0 carries the pixels (ky,kx) = (0,0)(0,1)(0,2)(1,0) | (1,1)(1,2)(2,0)(2,1) (two 16-byte halves),
- * step 1 carries (2,2) in its first dword.  Row layout [8 cout][2 steps][32 B]. */
-#define YF_CONV1_KROW 64
+/* conv2d_1 packs its 27 taps into three 16-byte MFMA k-steps over RGBX pixels (4 bytes per pixel, X weight = 0):
+ * step 0 carries the pixels (ky,kx) = (0,0)(0,1)(0,2)(1,0), step 1 (1,1)(1,2)(2,0)(2,1), step 2 (2,2) in its first
+ * dword.  Row layout [8 cout][3 steps][16 B]. */
+#define YF_CONV1_KROW 48
 
 typedef struct {
   yf_dense dense[YF_N_DENSE];
@@ -90,7 +99,7 @@ typedef struct {
 
 /* The table blob starts with a copy of the index (so kernels fetch stage descriptors with scalar loads instead of
  * carrying ~120 dwords of kernel arguments in SGPRs). */
-#define YF_INDEX_RESERVED 512
+#define YF_INDEX_RESERVED 768
 
 /* Channel order of concat_22's buffer T14: pool branch at [0,18), conv branch at [20,38) (4-byte aligned
  * starts so that packed 4-channel stores stay aligned); conv2d_23's k order follows it. */

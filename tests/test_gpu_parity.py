@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 STAGES = [("T1", 2), ("T2", 4), ("T3", 5), ("T4", 7), ("Q21", 21), ("T6", 11), ("T7", 12), ("T8", 14), ("T9", 16),
           ("T11", 18), ("T14", 22), ("T15", 24), ("Q45", 45), ("T17", 28), ("T18", 29), ("T19", 31), ("T20", 33),
           ("T22", 35), ("T23", 37), ("T24", 39), ("T26", 41), ("T30", 46), ("T31", 48), ("T32", 50), ("T33", 52)]
-VARIANTS = [(1, 4), (2, 4), (4, 4), (2, 8), (4, 8)]
+VARIANTS = [(1, 4), (2, 4), (2, 8), (4, 8), (202, 8)]     # (202, 8): the experimental (YF_EXP) build of the shipped shape
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,6 @@ from conftest import ROOT
 PKG = os.path.join(ROOT, "stm32h7-yolo_amd")
 N_DENSE, N_DW, N_ADD, N_LUT = 17, 7, 3, 19
 DENSE_OPS = [1, 5, 6, 12, 13, 17, 19, 23, 29, 30, 34, 36, 40, 42, 47, 51, 53]
-DENSE_LUT = [1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0]   # conv2d_17/34/40 index the add table B
 DW_OPS = [3, 10, 15, 27, 32, 38, 49]
 LEAKY_LUT_IDS = {2: 0, 4: 1, 7: 2, 11: 4, 14: 5, 16: 6, 20: 7, 24: 8, 28: 10, 31: 11, 33: 12, 37: 13, 39: 14, 48: 16, 50: 17, 52: 18}
 
@@ -28,7 +27,8 @@ class Dw(ctypes.Structure):
 
 
 class Add(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("zp1", "zp2", "zpo", "m1", "s1", "m2", "s2", "mo", "so", "kco", "rso")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("zp1", "zp2", "zpo", "m1", "s1", "m2", "s2", "mo", "so", "kco", "rso")] + \
+               [("mo2", ctypes.c_uint32), ("zro", ctypes.c_uint32), ("c64o", ctypes.c_uint32 * 2)]
 
 
 class Index(ctypes.Structure):
@@ -80,7 +80,7 @@ def test_mbqm_agrees_with_oracle(prep, oracle):
 def test_index_is_embedded_and_blocks_are_aligned(prep):
     ix, tab = prep["ix"], prep["tab"]
     assert tab[:ctypes.sizeof(Index)] == bytes(ix)
-    assert ctypes.sizeof(Index) <= 512
+    assert ctypes.sizeof(Index) <= 768
     for d in ix.dense:
         assert d.w_off % 16 == 0 and d.c_off % 16 == 0 and d.krow % 16 == 0 and d.cout_pad4 % 4 == 0
     for d in ix.dw:
@@ -110,44 +110,50 @@ def test_leaky_and_requant_luts_equal_oracle(prep, oracle, pack):
     assert np.array_equal(lut[15], q44[l43.astype(int) + 128])  # QUANTIZE #44 o LEAKY_RELU #43
 
 
-def _chan(tab, off, i):
-    """yf_chan (yf_tables.h) holds the DEVICE form {bias ^ 2^31, 2*M, kc - M - 1, rshift}; returned here in the plain
-    form (bias2, mult, kc, rshift) the TFLite identity is stated in, together with the raw device words."""
-    bias_u, mult2, khi, rs = struct.unpack_from("<iIii", tab, off + 16 * i)
+O = 0x40000000          # YF_ACC_OFFSET: the MFMA accumulator starts at the inline constant 2.0 (bit pattern 2^30)
+
+
+def _chan(tab, off, ch):
+    """Channel ch of a yf_pass array (yf_tables.h): {mult2[4], zr[4], c64[4][2], rshift[4]} per 4 channels, 80 bytes.
+    Returns (M, rshift, ZR, C64) of the device form."""
+    base = off + 80 * (ch // 4)
+    j = ch % 4
+    mult2, = struct.unpack_from("<I", tab, base + 4 * j)
+    zr, = struct.unpack_from("<I", tab, base + 16 + 4 * j)
+    lo, hi = struct.unpack_from("<II", tab, base + 32 + 8 * j)
+    rs, = struct.unpack_from("<i", tab, base + 64 + 4 * j)
     assert mult2 % 2 == 0
-    mult = mult2 >> 1
-    bias2 = ((bias_u & 0xFFFFFFFF) ^ 0x80000000)
-    bias2 = bias2 - (1 << 32) if bias2 >= (1 << 31) else bias2
-    kc = (khi + mult + 1 + (1 << 31)) % (1 << 32) - (1 << 31)
-    return bias2, mult, kc, rs
+    return mult2 >> 1, rs, zr, lo | (hi << 32)
 
 
-def _device_requant(acc, bias2, mult, kc, rs):
-    """the kernel's arithmetic on 32/64-bit unsigned words: hi32(acc_u * 2M + 2^31) + (kc - M - 1) + (acc_u >> 31), >> rs"""
-    acc_u = (acc + (1 << 31)) & 0xFFFFFFFF
-    d = acc_u * ((2 * mult) & 0xFFFFFFFF) + (1 << 31)
-    t = ((d >> 32) + ((kc - mult - 1) & 0xFFFFFFFF) + (acc_u >> 31)) & 0xFFFFFFFF
+def _device_requant(dot, mult, rs, zr, c64):
+    """The kernel's arithmetic on 32/64-bit unsigned words (yf_kernels.hip.h, rq4): the MFMA leaves acc_p = O + dot;
+    {carry, N} = acc_p * 2M + C64 (v_mad_u64_u32); t = hi32(N) + ZR + carry (v_addc_co_u32); y = t >> rs (arithmetic)."""
+    acc_p = O + dot
+    assert 0 < acc_p < (1 << 32)
+    n = acc_p * (2 * mult) + c64
+    carry, n = n >> 64, n & ((1 << 64) - 1)
+    assert carry in (0, 1)
+    t = ((n >> 32) + zr + carry) & 0xFFFFFFFF
     t = t - (1 << 32) if t >= (1 << 31) else t
     return t >> rs
 
 
-def _check_requant_identity(oracle, bias2, mult, kc, rs, zp_out, z_extra, rng):
-    """(s + kc + (s>>31)) >> rs == MBQM(acc, mult, -rs) + zp_out + z_extra on random and tie-prone accumulators, and the
-    sign-flipped unsigned form the kernel evaluates gives the same."""
-    accs = np.concatenate([rng.integers(-2**21, 2**21, 200), [0, 1, -1, bias2, -bias2]])
-    # accumulators whose SRDHM lands exactly on a rounding tie of the second shift (both signs)
+def _check_requant_identity(oracle, bias2, mult, rs, zr, c64, zp_out, abs_w, rng):
+    """device form == MBQM(acc, mult, -rs) + zp_out + 128 on random accumulators and on accumulators whose first
+    rounding lands exactly on a tie of the second shift (both signs: the carry stands in for TFLite's sign term)."""
+    lim = 255 * abs_w
+    dots = np.concatenate([rng.integers(-lim, lim + 1, 300), [0, 1, -1, lim, -lim, -bias2, -bias2 - 1, -bias2 + 1]])
     half = 1 << (rs - 1)
-    for k in (-3, -2, -1, 0, 1, 2):
-        target = k * (1 << rs) + half
-        a = int(round(target * 2.0**31 / mult))
-        accs = np.concatenate([accs, [a - 1, a, a + 1, -a - 1, -a, -a + 1]])
-    for acc in accs:
-        acc = int(acc)
-        s = oracle.lib.yfo_srdhm(acc, mult)
-        fused = (s + kc + (s >> 31)) >> rs
-        ref = oracle.lib.yfo_mbqm(acc, mult, -rs) + zp_out + z_extra
-        assert fused == ref, (acc, mult, rs)
-        assert _device_requant(acc, bias2, mult, kc, rs) == ref, (acc, mult, rs)      # the form the kernel evaluates
+    for k in (-40, -3, -2, -1, 0, 1, 2, 40):
+        target = k * (1 << rs) + half              # s1 value that is a tie of RoundingDivideByPOT
+        a = int(round(target * 2.0**31 / mult))    # accumulator whose SRDHM is (about) that value
+        dots = np.concatenate([dots, [a - bias2 + d for d in (-2, -1, 0, 1, 2)], [-a - bias2 + d for d in (-2, -1, 0, 1, 2)]])
+    assert zr == (zp_out + 128) << rs
+    for dot in dots:
+        dot = int(dot)
+        ref = oracle.lib.yfo_mbqm(dot + bias2, mult, -rs) + zp_out + 128
+        assert _device_requant(dot, mult, rs, zr, c64) == ref, (dot, bias2, mult, rs)
 
 
 def test_dense_tables(prep, oracle, pack):
@@ -165,12 +171,11 @@ def test_dense_tables(prep, oracle, pack):
         for ch in range(cout):
             row = np.frombuffer(tab, np.int8, d.krow, d.w_off + ch * d.krow).astype(np.int64)
             wf = w[ch].reshape(-1)
-            if op == 1:      # RGBX slots, two k-steps (yf_tables.h)
-                exp = np.zeros(64, np.int64)
+            if op == 1:      # RGBX slots, three 16-byte k-steps (yf_tables.h)
+                exp = np.zeros(48, np.int64)
                 for ky in range(3):
                     for kx in range(3):
-                        pix = ky * 3 + kx
-                        base = pix * 4 if pix < 8 else 32
+                        base = (ky * 3 + kx) * 4
                         exp[base:base + 3] = w[ch, ky, kx, :]
                 assert np.array_equal(row, exp)
             elif op == 23:   # T14 channel order: pool [0,18) | conv [20,38)
@@ -180,16 +185,14 @@ def test_dense_tables(prep, oracle, pack):
                 assert np.array_equal(row, exp)
             else:
                 assert np.array_equal(row[:wf.size], wf) and not row[wf.size:].any()
-            bias2, mult, kc, rs = _chan(tab, d.c_off, ch)
-            assert bias2 == int(bt["data"][ch]) - zp_in * int(wf.sum())
+            mult, rs, zr, c64 = _chan(tab, d.c_off, ch)
+            bias2 = int(bt["data"][ch]) - zp_in * int(wf.sum())
             m, sh = ctypes.c_int32(), ctypes.c_int()
             eff = float(np.float32(T[t_in]["scale"][0])) * float(np.float32(wt["scale"][ch])) / float(np.float32(to["scale"][0]))
             oracle.lib.yfo_quantize_multiplier(eff, ctypes.byref(m), ctypes.byref(sh))
-            assert (mult, -rs) == (m.value, sh.value) and rs >= 1 and mult > (1 << 30)
-            z = 128 if DENSE_LUT[s] else 0
-            assert kc == (1 << (rs - 1)) + ((to["zp"] + z) << rs)
-            if ch % 5 == 0:
-                _check_requant_identity(oracle, bias2, mult, kc, rs, to["zp"], z, rng)
+            assert (mult, -rs) == (m.value, sh.value) and 1 <= rs <= 20 and mult > (1 << 30)
+            assert c64 == ((bias2 - O) * 2 * mult + (1 << 31) + (((1 << (rs - 1)) - 1) << 32)) % (1 << 64)
+            _check_requant_identity(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(wf).sum()), rng)
 
 
 def test_depthwise_tables(prep, oracle, pack):
@@ -206,7 +209,7 @@ def test_depthwise_tables(prep, oracle, pack):
         c = wt["shape"][3]
         assert d.c == c and d.ngroups == (c + 3) // 4
         for g in range(d.ngroups):
-            base = d.g_off + g * (36 * 4 + 64)
+            base = d.g_off + g * (36 * 4 + 80)
             wd = np.frombuffer(tab, "<u4", 36, base).reshape(9, 4)
             for j in range(4):
                 ch = g * 4 + j
@@ -215,15 +218,14 @@ def test_depthwise_tables(prep, oracle, pack):
                     continue
                 taps = w[0].reshape(9, c)[:, ch]
                 assert np.array_equal(wd[:, j], (taps & 255).astype(np.uint32) << (8 * j))
-                bias2, mult, kc, rs = _chan(tab, base + 144, j)
-                assert bias2 == int(bt["data"][ch]) - T[t_in]["zp"] * int(taps.sum())
+                mult, rs, zr, c64 = _chan(tab, base + 144, j)
+                bias2 = int(bt["data"][ch]) - T[t_in]["zp"] * int(taps.sum())
                 m, sh = ctypes.c_int32(), ctypes.c_int()
                 eff = float(np.float32(T[t_in]["scale"][0])) * float(np.float32(wt["scale"][ch])) / float(np.float32(to["scale"][0]))
                 oracle.lib.yfo_quantize_multiplier(eff, ctypes.byref(m), ctypes.byref(sh))
-                assert (mult, -rs) == (m.value, sh.value) and rs >= 1
-                assert kc == (1 << (rs - 1)) + ((to["zp"] + 128) << rs)
-                if ch % 7 == 0:
-                    _check_requant_identity(oracle, bias2, mult, kc, rs, to["zp"], 128, rng)
+                assert (mult, -rs) == (m.value, sh.value) and 1 <= rs <= 20
+                assert c64 == ((bias2 - O) * 2 * mult + (1 << 31) + (((1 << (rs - 1)) - 1) << 32)) % (1 << 64)
+                _check_requant_identity(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(taps).sum()), rng)
 
 
 def test_add_tables(prep, oracle, pack):
@@ -248,10 +250,13 @@ def test_add_tables(prep, oracle, pack):
             q1, q2 = int(q1), int(q2)
             sa = oracle.lib.yfo_mbqm((q1 - a.zp1) * (1 << 20), a.m1, a.s1)
             sb = oracle.lib.yfo_mbqm((q2 - a.zp2) * (1 << 20), a.m2, a.s2)
-            assert (al[s, 0, q1 + 128], al[s, 1, q2 + 128]) == (sa, sb)
+            assert (al[s, 0, q1 + 128], al[s, 1, q2 + 128]) == (sa, sb + O)       # the accumulator offset rides in table B
             sm = oracle.lib.yfo_srdhm(sa + sb, a.mo)
             fused = (sm + a.kco + (sm >> 31)) >> a.rso
-            assert fused == oracle.lib.yfo_mbqm(sa + sb, a.mo, a.so) + a.zpo
+            ref = oracle.lib.yfo_mbqm(sa + sb, a.mo, a.so) + a.zpo
+            assert fused == ref
+            assert a.mo2 == 2 * a.mo and a.zro == (a.zpo + 128) << a.rso
+            assert _device_requant(sa + sb, a.mo, a.rso, a.zro, a.c64o[0] | (a.c64o[1] << 32)) == ref + 128
 
 
 def test_prepare_rejects_bad_arguments(prep):

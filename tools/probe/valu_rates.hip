@@ -61,7 +61,18 @@
   X(52, "v_cvt_f32_ubyte0 %0, %0") \
   X(53, "v_add_f64 %0, %0, %0") \
   X(54, "v_fma_f64 %0, %0, %0, %0") \
-  X(55, "v_mul_hi_i32 %0, %0, %1")
+  X(55, "v_mul_hi_i32 %0, %0, %1") \
+  X(56, "v_pk_lshlrev_b16 %0, 8, %0 op_sel_hi:[0,1]") \
+  X(57, "v_addc_co_u32_e64 %0, vcc, %0, %1, vcc") \
+  X(58, "v_pk_fma_f32 %0, %0, %0, %0") \
+  X(59, "v_pk_mul_f32 %0, %0, %0") \
+  X(60, "v_mad_u64_u32 %0, vcc, %1, %1, %0") \
+  X(61, "v_lshrrev_b32 %0, 3, %0") \
+  X(62, "v_pk_lshrrev_b16 %0, 8, %0 op_sel_hi:[0,1]") \
+  X(63, "v_and_b32 %0, 0xff00ff00, %0") \
+  X(64, "v_bfe_u32 %0, %0, 8, 8") \
+  X(65, "v_max_i32 %0, 0, %0") \
+  X(66, "v_min_u32 %0, %0, %1")
 
 template <int OP> __global__ void __launch_bounds__(256) k_rate(int* out, int seed) {
   int x0 = threadIdx.x + seed, x1 = x0 * 3 + 1, x2 = x0 * 5 + 2, x3 = x0 * 7 + 3, x4 = x0 * 11 + 4, x5 = x0 * 13 + 5, x6 = x0 * 17 + 6, x7 = x0 * 19 + 7;
@@ -69,10 +80,10 @@ template <int OP> __global__ void __launch_bounds__(256) k_rate(int* out, int se
   long long q0 = x0, q1 = x1, q2 = x2, q3 = x3, q4 = x4, q5 = x5, q6 = x6, q7 = x7;
   for (int it = 0; it < ITERS; ++it) {
 #define X(ID, STR) if constexpr (OP == ID) { \
-    if constexpr (ID == 53 || ID == 54) { \
+    if constexpr (ID == 53 || ID == 54 || ID == 58 || ID == 59) { \
       asm volatile(STR : "+v"(q0)); asm volatile(STR : "+v"(q1)); asm volatile(STR : "+v"(q2)); asm volatile(STR : "+v"(q3)); \
       asm volatile(STR : "+v"(q4)); asm volatile(STR : "+v"(q5)); asm volatile(STR : "+v"(q6)); asm volatile(STR : "+v"(q7)); \
-    } else if constexpr (ID == 37) { \
+    } else if constexpr (ID == 37 || ID == 60) { \
       asm volatile(STR : "+v"(q0) : "v"(m) : "vcc"); asm volatile(STR : "+v"(q1) : "v"(m) : "vcc"); \
       asm volatile(STR : "+v"(q2) : "v"(m) : "vcc"); asm volatile(STR : "+v"(q3) : "v"(m) : "vcc"); \
       asm volatile(STR : "+v"(q4) : "v"(m) : "vcc"); asm volatile(STR : "+v"(q5) : "v"(m) : "vcc"); \

@@ -9,7 +9,7 @@ d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((n,7,7,18), dtype=torch.i
 for nn in (4096,):
     if nn != n:
         d_in = d_in.repeat(nn//n,1,1,1).contiguous(); d_out = torch.zeros((nn,7,7,18), dtype=torch.int8, device='cuda')
-    for f, w in ((1,4),(2,4),(2,6),(2,8),(4,8)):
+    for f, w in ((1,4),(2,4),(2,8),(4,8),(2,8)):
         net.configure(f, w)
         net.time_device(d_in.data_ptr(), d_out.data_ptr(), nn, 3)
         ms = net.time_device(d_in.data_ptr(), d_out.data_ptr(), nn, 20)
