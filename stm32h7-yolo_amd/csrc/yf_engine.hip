@@ -14,7 +14,10 @@
 #undef YF_EXP
 #undef YF_STAGE_FN
 #define YF_NS yfx
-#define YF_EXP 1
+#ifndef YF_EXP_X
+#define YF_EXP_X 1
+#endif
+#define YF_EXP YF_EXP_X
 #ifndef YF_LAUNDER_X
 #define YF_LAUNDER_X 0      /* 7: no hoisting of per-lane index arithmetic in the experimental build */
 #endif

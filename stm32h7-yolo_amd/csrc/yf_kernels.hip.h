@@ -151,7 +151,11 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
 #define YF_RQ4_OPS : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(cy0), "=&s"(cy1), "=&s"(cy2), "=&s"(cy3) \
                    : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(m2[0]), "v"(m2[1]), "v"(m2[2]), "v"(m2[3]), \
                      "s"(c64[0]), "s"(c64[1]), "s"(c64[2]), "s"(c64[3])
+#if YF_EXP == 10   // what-if (hazard not padded)
+  if constexpr (AFTER_MFMA) asm(YF_RQ4_MADS YF_RQ4_OPS);
+#else
   if constexpr (AFTER_MFMA) asm("s_nop 7\n\ts_nop 1\n\t" YF_RQ4_MADS YF_RQ4_OPS);
+#endif
   else asm(YF_RQ4_MADS YF_RQ4_OPS);
 #undef YF_RQ4_MADS
 #undef YF_RQ4_OPS
@@ -165,10 +169,26 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
 // the four requantised channels of a pass as LUT indices / unsigned bytes (q + 128)
 template <bool AFTER_MFMA>
 __device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[4]) {
+#if YF_EXP == 4    // what-if (wrong results): no requantisation arithmetic
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = acc[j] & 255;
+#elif YF_EXP == 12 // what-if (wrong results): constants loaded and consumed by ONE cheap op per channel, no real arithmetic
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = (acc[j] + (int)m2[j] + (int)zr[j] + (int)c64[j] + rs[j]) & 255;
+#elif YF_EXP == 8  // what-if: 32-bit multiply-high + add instead of the 64-bit multiply-add with carry
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = min(max((int)(__umulhi((unsigned)acc[j], m2[j]) + zr[j] + (unsigned)c64[j]) >> rs[j], 0), 255);
+#elif YF_EXP == 9  // what-if: no shift, no clamp
+  int t[4];
+  rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = t[j] & 255;
+#else
   int t[4];
   rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
 #pragma unroll
   for (int j = 0; j < 4; ++j) idx[j] = min(max(t[j] >> rs[j], 0), 255);     // v_ashrrev, v_med3_i32
+#endif
 }
 constexpr int ACC0 = YF_ACC_OFFSET;            // MFMA C operand: the inline constant 2.0 (no v_mov)
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
@@ -184,7 +204,13 @@ __device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2,
 // checks it).  Absolute LDS addressing lets the table base ride in the ds_read immediate offset.
 typedef const __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
 template <int LUT_ID>
-__device__ __forceinline__ uint32_t lutb(int idx) { return *(lds_u8_ptr)(uint32_t)(LUT_ID * 256 + idx); }
+__device__ __forceinline__ uint32_t lutb(int idx) {
+#if YF_EXP == 3    // what-if (wrong results): no LUT read
+  return (uint32_t)idx;
+#else
+  return *(lds_u8_ptr)(uint32_t)(LUT_ID * 256 + idx);
+#endif
+}
 template <int LUT_ID>
 __device__ __forceinline__ uint32_t lut4(uint32_t d) {   // per byte: lut[q + 128]
   const uint32_t x = d ^ 0x80808080u;
@@ -217,12 +243,31 @@ __device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_p
 // vector load), c64[4] and rshift[4] to SGPRs
 struct PassV { v4u m2, zr; };
 __device__ __forceinline__ PassV load_pass_v(const uint8_t* pass, int vz) {
+#if YF_EXP == 2 || YF_EXP == 11     // what-if (wrong results): constants without a memory access
+  const unsigned u = (unsigned)(uintptr_t)pass + vz;
+  return PassV{v4u{u | 0x80000000u, u | 0x80000001u, u | 0x80000002u, u | 0x80000003u}, v4u{u, u, u, u}};
+#else
   const v4u* p = reinterpret_cast<const v4u*>(pass + vz);
   return PassV{p[0], p[1]};
+#endif
+}
+__device__ __forceinline__ v4i load_wfrag(const uint8_t* p, int vz) {
+#if YF_EXP == 2 || YF_EXP == 11
+  const int u = (int)(uintptr_t)p + vz;
+  return v4i{u, u + 1, u + 2, u + 3};
+#else
+  (void)vz;
+  return *reinterpret_cast<const v4i*>(p);
+#endif
 }
 struct PassS { v4ul c64; v4i rs; };
 __device__ __forceinline__ PassS load_pass_s(const uint8_t* pass) {
+#if YF_EXP == 11   // what-if (wrong results): scalar constants without a memory access
+  const unsigned long u = (unsigned long)(uintptr_t)pass;
+  return PassS{v4ul{u * 3, u * 5, u * 7, u * 9}, v4i{7, 8, 9, 7}};
+#else
   return PassS{*(cv4ul_ptr)(uintptr_t)(pass + 32), *(cv4i_ptr)(uintptr_t)(pass + 64)};
+#endif
 }
 // stage descriptors out of the index at the head of the table blob, as scalar loads (offsets stay in SGPRs)
 __device__ __forceinline__ yf_dense load_dense(const uint8_t* tab, int i) {
@@ -360,6 +405,9 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
   int cur_chunk = -1;
   v4i a[TPJ][KS];
   PassV pv[TPJ];
+#if YF_EXP == 1
+  PassS ksr[TPJ];                           // experiment: scalar constants resident per chunk instead of one load per tile
+#endif
   for (int j = j0; j < j1; ++j) {
     const int chunk = j / MT, mt = j - chunk * MT;
     if (chunk != cur_chunk) {
@@ -368,10 +416,13 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
       for (int t = 0; t < TPJ; ++t) {
         const int ps = min(chunk * TPJ + t, NP - 1);
         pv[t] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
+#if YF_EXP == 1
+        ksr[t] = load_pass_s(pp + ps * (int)sizeof(yf_pass));
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           a[t][ks] = v4i{0, 0, 0, 0};
-          if (a_on) a[t][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks);
+          if (a_on) a[t][ks] = load_wfrag(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks, vz);
         }
       }
     }
@@ -382,21 +433,38 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
     v4i b[KS];
     {
       const char* src = fbase + IN::at_p(p);
+#if YF_EXP == 5
+      { const int u = (int)(uintptr_t)src;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = v4i{u + ks, u + 1, u + 2, u + 3}; }
+      if (false)
+#endif
+      {
 #pragma unroll
       for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
       const char* last = src + 16 * (KS - 1);
       if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
       else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, 0, 0}; }
       else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), 0, 0, 0};
+      }
     }
 #pragma unroll
     for (int t = 0; t < TPJ; ++t) {
       const int ps = chunk * TPJ + t;
       if (ps < NP) {                                          // uniform
+#if YF_EXP == 1
+        const PassS k = ksr[t];
+#else
         const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
+#endif
         v4i acc = {ACC0, ACC0, ACC0, ACC0};
+#if YF_EXP == 7
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc += a[t][ks] + b[ks];
+#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
+#endif
         int idx[4];                         // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
         requant4<true>(acc, pv[t].m2, pv[t].zr, k.c64, k.rs, idx);
         epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, out_all, f, p, ps * 4, idx, ad);
@@ -423,7 +491,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, cons
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       a[ps][ks] = v4i{0, 0, 0, 0};
-      if (a_on) a[ps][ks] = *reinterpret_cast<const v4i*>(tab + d.w_off + (ps * 4 + (c & 3)) * YF_CONV1_KROW + 16 * ks);
+      if (a_on) a[ps][ks] = load_wfrag(tab + d.w_off + (ps * 4 + (c & 3)) * YF_CONV1_KROW + 16 * ks, vz);
     }
   }
   int j0, j1;
@@ -494,32 +562,66 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
     v4i a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;                // k-steps: taps 0-3, 4-7, 8
     if (a_on) {
       const uint32_t* wl = wg + (c & 3);                    // masked weight dwords of channel c&3: wl[4*tap]
+#if YF_EXP == 2 || YF_EXP == 11
+      a0 = load_wfrag((const uint8_t*)wl, vz); a1 = load_wfrag((const uint8_t*)(wl + 16), vz); a2[0] = a1[1] + 5;
+#else
       a0 = v4i{(int)wl[0], (int)wl[4], (int)wl[8], (int)wl[12]};
       a1 = v4i{(int)wl[16], (int)wl[20], (int)wl[24], (int)wl[28]};
       a2[0] = (int)wl[32];
+#endif
     }
     const PassV pv = load_pass_v(grp + 144, vz);
     const PassS k = load_pass_s(grp + 144);
-    for (; j < jend; ++j) {
-      int rem = j - cg * JPG;
+    // one job: 9 tap dwords -> 3 MFMAs -> requantise -> LUT -> packed store
+    auto taps = [&](int jj, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
+      int rem = jj - cg * JPG;
       const int fp = rem / (NRB * NSEG); rem -= fp * (NRB * NSEG);
       const int rb = rem / NSEG, seg = rem - rb * NSEG;
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       char* fb = frames + fp * FL * FRAME_BYTES;
       const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
-      v4i b0, b1, b2 = {0, 0, 0, 0};
+#if YF_EXP == 5    // what-if (wrong results): no LDS reads of the taps
+      { const int u = (int)(uintptr_t)src; b0 = v4i{u, u + 1, u + 2, u + 3}; b1 = v4i{u + 4, u + 5, u + 6, u + 7}; b2[0] = u + 8; }
+#else
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
       b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
+#endif
+      dst = fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg;
+    };
+    auto conv = [&](const v4i& b0, const v4i& b1, const v4i& b2) {
+#if YF_EXP == 7    // what-if (wrong results): no MFMA
+      return b0 + b1 + b2 + a0;
+#else
       v4i acc = {ACC0, ACC0, ACC0, ACC0};
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
+      return __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
+#endif
+    };
+    auto finish = [&](const v4i& acc, char* dst) {
       int idx[4];
       requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
-      *reinterpret_cast<uint32_t*>(fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg) =
-          join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+      *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+    };
+#if YF_EXP == 1   // experiment: two jobs in flight per iteration (memory-level parallelism inside the wave)
+    for (; j + 1 < jend; j += 2) {
+      v4i p0, p1, p2 = {0, 0, 0, 0}, q0, q1, q2 = {0, 0, 0, 0};
+      char *dp, *dq;
+      taps(j, p0, p1, p2, dp);
+      taps(j + 1, q0, q1, q2, dq);
+      const v4i ap = conv(p0, p1, p2);
+      const v4i aq = conv(q0, q1, q2);
+      finish(ap, dp);
+      finish(aq, dq);
+    }
+#endif
+    for (; j < jend; ++j) {
+      v4i b0, b1, b2 = {0, 0, 0, 0};
+      char* dst;
+      taps(j, b0, b1, b2, dst);
+      finish(conv(b0, b1, b2), dst);
     }
   }
 }
@@ -675,11 +777,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   };
   constexpr long DS = DumpOffsets::TOTAL;
 #ifdef YF_BARPROF
-  // Barrier-wait profile (tools/barrier_profile.py): cycles each wave spends inside __syncthreads(), per barrier index.
-  long long bar_wait[40] = {};
-  long long t_loop0 = 0;
+  // Stage timeline (tools/barrier_profile.py): for ONE group of every workgroup (its second: steady state) each wave stores
+  // the cycle counter on arrival at and on release from every __syncthreads(): [wg][wave][40][2] in prm.dump.
+  bool prof_on = false;
   int bar_no = 0;
-#define YF_SYNC() do { const long long t0_ = __builtin_readcyclecounter(); __syncthreads(); bar_wait[bar_no < 39 ? bar_no : 39] += __builtin_readcyclecounter() - t0_; ++bar_no; } while (0)
+  long long* prof_out = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 80;
+#define YF_SYNC() do { if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
+                       if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
 #else
 #define YF_SYNC() __syncthreads()
 #endif
@@ -704,7 +808,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const long first = grp * F;
 #ifdef YF_BARPROF
     bar_no = 0;
-    if (grp == (long)blockIdx.x) t_loop0 = __builtin_readcyclecounter();
+    prof_on = !DUMP && prm.dump != nullptr && grp == (long)blockIdx.x + gridDim.x;
 #endif
     // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
     // results in VGPRs for the whole kernel.  YF_LAUNDER selects stage groups (1 front 28x28, 2 middle 14x14, 4 tail
@@ -820,13 +924,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   {   // boxes of this workgroup's last group
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
-#ifdef YF_BARPROF
-    if (!DUMP && prm.dump != nullptr && lane == 0) {     // [wg][wave][41]: total cycles in the loop, then waits per barrier
-      long long* o = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + wave) * 41;
-      o[0] = __builtin_readcyclecounter() - t_loop0;
-      for (int i = 0; i < 40; ++i) o[1 + i] = bar_wait[i];
-    }
-#endif
   }
 #undef YF_DUMP
 #undef YF_STAGE_END

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Where do the waves wait?  Needs a library built with -DYF_BARPROF (make ... HIPFLAGS+=' -DYF_BARPROF'): the production
-kernel then records, per wave, the cycles spent inside every __syncthreads() of the group loop.  DEV TOOL."""
+"""Stage timeline of the fused kernel.  Needs a library built with -DYF_BARPROF
+(make -C stm32h7-yolo_amd/csrc OUT=../lib_prof HIPFLAGS+=' -DYF_BARPROF'; YF_LIB_PATH=.../lib_prof/libyf_network.so):
+every wave then stores the cycle counter on arrival at and on release from each __syncthreads() of its workgroup's
+second group (steady state).  Prints, per barrier interval, how long the waves worked (mean / slowest wave = the
+interval's critical path) and how long they waited.  DEV TOOL."""
 import importlib, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,19 +12,26 @@ from tools.stage_profile_names import NAMES
 n = int(os.environ.get("YF_N", "4096"))
 x = np.random.default_rng(1).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
 net = yf.Network().init()
+if os.environ.get("YF_CFG"): net.configure(*[int(v) for v in os.environ["YF_CFG"].split(",")])
 d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
-wgs, nw = min(512, n // 2), 8
-d_prof = torch.zeros((wgs * nw * 41,), dtype=torch.int64, device="cuda")
+wgs, nw = 512, 8
+d_prof = torch.zeros((wgs * nw * 80,), dtype=torch.int64, device="cuda")
 for _ in range(3):
     net.run_device(d_in.data_ptr(), d_out.data_ptr(), n, None, d_prof.data_ptr())
 torch.cuda.synchronize()
-p = d_prof.cpu().numpy().reshape(wgs, nw, 41).astype(np.float64)
-tot = p[:, :, 0]
-waits = p[:, :, 1:]
-print(f"{wgs} workgroups x {nw} waves, {n} frames: loop cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f})")
-print(f"time inside barriers: {100 * waits.sum(axis=2).mean() / tot.mean():.1f}% of the loop (mean over waves)")
-labels = ["top of loop (arena free)"] + [f"after {nm}" for nm in NAMES[:6]] + ["after pool_8 v", "after conv2d_10 (dw)"] + [f"after {nm}" for nm in NAMES[7:]]
-for i in range(40):
-    w = waits[:, :, i]
-    if w.sum() == 0: continue
-    print(f"  barrier {i:2d} {labels[i] if i < len(labels) else '':34s} mean {100 * w.mean() / tot.mean():5.2f}%   per wave: " + " ".join(f"{100 * w[:, k].mean() / tot.mean():4.1f}" for k in range(nw)))
+p = d_prof.cpu().numpy().reshape(wgs, nw, 40, 2).astype(np.float64)
+nb = int((p[0, 0, :, 0] > 0).sum())
+p = p[:, :, :nb, :]
+arrive, leave = p[..., 0], p[..., 1]
+body = np.empty_like(arrive); body[:, :, 0] = 0; body[:, :, 1:] = arrive[:, :, 1:] - leave[:, :, :-1]
+wait = leave - arrive
+span = leave[:, :, -1] - leave[:, :, 0]
+print(f"{wgs} workgroups x {nw} waves, {nb} barriers per group; cycles from the first to the last barrier of a group: "
+      f"mean {span.mean():.0f} (min {span.min():.0f} max {span.max():.0f})")
+print(f"working {100 * body.sum(axis=2).mean() / span.mean():.1f}%  waiting in barriers {100 * wait[:, :, 1:].sum(axis=2).mean() / span.mean():.1f}%")
+labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_10 (dw)"] + [f"{nm}" for nm in NAMES[7:]]
+print(f"{'interval ending at barrier':44s} {'work mean':>10s} {'slowest':>9s} {'wait mean':>10s}   work per wave")
+for i in range(1, nb):
+    b, w = body[:, :, i], wait[:, :, i]
+    print(f"  {i:2d} {labels[i] if i < len(labels) else '':40s} {b.mean():10.0f} {b.max(axis=1).mean():9.0f} {w.mean():10.0f}   "
+          + " ".join(f"{b[:, k].mean():6.0f}" for k in range(nw)))
