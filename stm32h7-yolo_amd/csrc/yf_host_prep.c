@@ -261,8 +261,12 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     };
     for (unsigned i = 0; i < sizeof leaky / sizeof leaky[0]; ++i)
       build_leaky_lut(leaky[i][1], leaky[i][2], L + 256 * leaky[i][0]);
-    build_requant_lut(58, 103, L + 256 * YF_L_Q21);          /* QUANTIZE #21: pool_8 branch of concat_22 */
-    build_requant_lut(74, 101, L + 256 * YF_L_Q45);          /* QUANTIZE #45: pool_25 branch of concat_46 */
+    /* the two pool LUTs are RAW-indexed (index = the int8 bit pattern, not q + 128): the pooling code extracts bytes
+     * straight out of its packed maxima */
+    uint8_t q21[256], q45[256];
+    build_requant_lut(58, 103, q21);                         /* QUANTIZE #21: pool_8 branch of concat_22 */
+    build_requant_lut(74, 101, q45);                         /* QUANTIZE #45: pool_25 branch of concat_46 */
+    for (int i = 0; i < 256; ++i) { L[256 * YF_L_Q21 + i] = q21[i ^ 128]; L[256 * YF_L_Q45 + i] = q45[i ^ 128]; }
     uint8_t l43[256], q44[256];
     build_leaky_lut(91, 92, l43);                            /* LEAKY_RELU #43 */
     build_requant_lut(92, 102, q44);                         /* QUANTIZE #44 */

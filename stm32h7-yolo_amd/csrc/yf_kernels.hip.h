@@ -191,6 +191,9 @@ __device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u 
 #endif
 }
 constexpr int ACC0 = YF_ACC_OFFSET;            // MFMA C operand: the inline constant 2.0 (no v_mov)
+// A register with no particular content and no instruction behind it: the k-slots of an MFMA B operand whose weights are
+// zero may hold anything (integer arithmetic: 0 * x = 0), so they are not cleared.
+__device__ __forceinline__ int any_value() { int u; asm volatile("" : "=v"(u)); return u; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // v_med3_i32
 // four zero-extended bytes -> one dword with three v_lshl_or_b32 (from a|b<<8|c<<16|d<<24 the compiler selects four ops)
 __device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
@@ -211,25 +214,38 @@ __device__ __forceinline__ uint32_t lutb(int idx) {
   return *(lds_u8_ptr)(uint32_t)(LUT_ID * 256 + idx);
 #endif
 }
-template <int LUT_ID>
-__device__ __forceinline__ uint32_t lut4(uint32_t d) {   // per byte: lut[q + 128]
-  const uint32_t x = d ^ 0x80808080u;
-  return lutb<LUT_ID>(x & 255) | (lutb<LUT_ID>((x >> 8) & 255) << 8) | (lutb<LUT_ID>((x >> 16) & 255) << 16) | (lutb<LUT_ID>(x >> 24) << 24);
-}
 __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {          // v_pk_max_i16
   v2s x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
   v2s r = __builtin_elementwise_max(x, y);
   uint32_t o; __builtin_memcpy(&o, &r, 4); return o;
 }
-// running per-byte signed max of packed int8x4: bytes are lifted into the high byte of int16 lanes
-struct ByteMax {
-  uint32_t mo = 0x80008000u, me = 0x80008000u;
-  __device__ __forceinline__ void add(uint32_t d) {
-    mo = pkmax(mo, d & 0xFF00FF00u);
-    me = pkmax(me, (d << 8) & 0xFF00FF00u);
-  }
-  __device__ __forceinline__ uint32_t get() const { return (mo & 0xFF00FF00u) | ((me >> 8) & 0x00FF00FFu); }
+// Per-byte signed max of packed int8x4 on the packed-int16 unit.  "o" compares bytes 3 and 1 where they stand (the high
+// byte of each int16 lane; the even byte below it only breaks ties between equal high bytes, which leaves the result's
+// high byte unchanged), "e" holds bytes 2 and 0 lifted into the high bytes by one v_pk_lshlrev_b16.  One shift per loaded
+// dword, two v_pk_max_i16 per max, one v_perm_b32 to merge.
+__device__ __forceinline__ uint32_t pk_shl8(uint32_t d) {                    // v_pk_lshlrev_b16 8
+  v2s x; __builtin_memcpy(&x, &d, 4);
+  x = x << 8;
+  uint32_t o; __builtin_memcpy(&o, &x, 4); return o;
+}
+struct SplitB {
+  uint32_t o, e;
+  __device__ __forceinline__ SplitB() : o(0x80008000u), e(0x80008000u) {}
+  __device__ __forceinline__ explicit SplitB(uint32_t d) : o(d), e(pk_shl8(d)) {}
+  __device__ __forceinline__ SplitB mx(const SplitB& b) const { SplitB r; r.o = pkmax(o, b.o); r.e = pkmax(e, b.e); return r; }
+  __device__ __forceinline__ uint32_t merge() const { return __builtin_amdgcn_perm(o, e, 0x07030501u); }   // {o.b3, e.b3, o.b1, e.b1}
+  // the four bytes as zero-extended values (two's complement bit patterns): indices of a raw-indexed byte LUT
+  __device__ __forceinline__ uint32_t b3() const { return o >> 24; }
+  __device__ __forceinline__ uint32_t b2() const { return e >> 24; }
+  __device__ __forceinline__ uint32_t b1() const { return (o >> 8) & 255u; }
+  __device__ __forceinline__ uint32_t b0() const { return (e >> 8) & 255u; }
 };
+// QUANTIZE of a pooled value through a RAW-indexed byte LUT (index = the int8 bit pattern; yf_host_prep.c stores the two
+// pool LUTs that way, so no ^0x80 is needed here)
+template <int LUT_ID>
+__device__ __forceinline__ uint32_t lut4_raw(const SplitB& v) {
+  return join4(lutb<LUT_ID>(v.b0()), lutb<LUT_ID>(v.b1()), lutb<LUT_ID>(v.b2()), lutb<LUT_ID>(v.b3()));
+}
 
 __device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret_cast<const uint32_t*>(p); }
 // wave-uniform table reads: the constant address space makes the compiler use scalar loads (SGPR results)
@@ -318,30 +334,42 @@ YF_STAGE_FN void fill_halo(char* frames, int zp, int tid) {
 }
 
 // ------------------------------------------------------------------------------------------------ input staging
-// NHWC int8 frames (9408 B) -> RGBX dwords with halo.  Coalesced 12-byte loads (4 pixels per lane).
+// NHWC int8 frames (G0*G0*3 B) -> RGBX dwords with halo.  One item = 4 pixels: one 12-byte load, three funnel shifts,
+// one 16-byte LDS store.  The X byte of a pixel is whatever byte follows it (its weights are zero, yf_tables.h), so no
+// masking is needed.
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }  // ({hi,lo} >> sh)[31:0]
 template <int F, int NT>
 YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long first_frame, long n_frames,
                                             int zp, int tid) {
   const uint32_t hv = (uint32_t)(zp & 255) * 0x01010101u;
   constexpr int RSW = B_IN::RS, HH = B_IN::H, WQ = B_IN::W / 4;    // dwords per halo'd row, rows, 4-pixel items per row
+  constexpr int PER_FRAME = HH * WQ, TOTAL = F * PER_FRAME, ITERS = (TOTAL + NT - 1) / NT;
   // halo: row 0 (RSW dwords) and dword column 3 of rows 1..HH
   for (int i = tid; i < F * (RSW + HH); i += NT) {
     const int f = i / (RSW + HH), k = i - f * (RSW + HH);
     const int idx = k < RSW ? k : (k - RSW + 1) * RSW + 3;
     *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B_IN::OFF + idx * 4) = hv;
   }
-  for (int i = tid; i < F * HH * WQ; i += NT) {
-    const int f = i / (HH * WQ), r = i - f * (HH * WQ);
-    long fi = first_frame + f; if (fi >= n_frames) fi = n_frames - 1;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + fi * IN_FRAME_BYTES + r * 12);
+  const long last = n_frames - 1 - first_frame;                   // frames past the end of the batch re-read the last one
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int i = tid + it * NT;
+    if (ITERS * NT != TOTAL && i >= TOTAL) break;
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
+    const int r = i - f * PER_FRAME;
+    const long fs = (long)f < last ? (long)f : last;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (first_frame + fs) * IN_FRAME_BYTES + r * 12);
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
     uint4 px;
-    px.x = d0 & 0x00FFFFFFu;
-    px.y = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
-    px.z = (d1 >> 16) | ((d2 & 0xFFu) << 16);
+    px.x = d0;
+    px.y = funnel(d1, d0, 24);
+    px.z = funnel(d2, d1, 16);
     px.w = d2 >> 8;
-    const int y = r / WQ, x4 = (r - y * WQ) * 4;
-    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * RSW + x4 + 4) * 4) = px;
+    const int y = (int)((uint32_t)r / (uint32_t)WQ);
+    const int xq = r - y * WQ;
+    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * RSW + 4 * xq + 4) * 4) = px;
   }
 }
 
@@ -444,8 +472,8 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
       for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
       const char* last = src + 16 * (KS - 1);
       if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
-      else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, 0, 0}; }
-      else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), 0, 0, 0};
+      else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, any_value(), any_value()}; }
+      else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), any_value(), any_value(), any_value()};
       }
     }
 #pragma unroll
@@ -507,7 +535,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, cons
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
     const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
     const v4i b1 = {(int)src[RSW + 1], (int)src[RSW + 2], (int)src[2 * RSW], (int)src[2 * RSW + 1]};
-    const v4i b2 = {(int)src[2 * RSW + 2], 0, 0, 0};
+    const v4i b2 = {(int)src[2 * RSW + 2], any_value(), any_value(), any_value()};
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
@@ -607,7 +635,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
     };
 #if YF_EXP == 1   // experiment: two jobs in flight per iteration (memory-level parallelism inside the wave)
     for (; j + 1 < jend; j += 2) {
-      v4i p0, p1, p2 = {0, 0, 0, 0}, q0, q1, q2 = {0, 0, 0, 0};
+      v4i p0, p1, p2 = {0, any_value(), any_value(), any_value()}, q0, q1, q2 = {0, any_value(), any_value(), any_value()};
       char *dp, *dq;
       taps(j, p0, p1, p2, dp);
       taps(j + 1, q0, q1, q2, dq);
@@ -618,7 +646,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
     }
 #endif
     for (; j < jend; ++j) {
-      v4i b0, b1, b2 = {0, 0, 0, 0};
+      v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
       char* dst;
       taps(j, b0, b1, b2, dst);
       finish(conv(b0, b1, b2), dst);
@@ -634,14 +662,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
 //   out[o] = max(S[o-2], S[o])                     (coordinates clamped into [0,LIM]: max is idempotent)
 // -- 2*NO+6 loads and 3*NO+5 packed maxima per NO outputs (direct form: 8 loads, 7 maxima per output).  The last
 // chunk is shifted inwards (recomputing a few outputs) so every chunk has exactly NO outputs.
-struct SplitB {      // packed int8x4 as two int16x2 registers (odd bytes / even bytes lifted into the high byte)
-  uint32_t o, e;
-  __device__ __forceinline__ SplitB() : o(0x80008000u), e(0x80008000u) {}
-  __device__ __forceinline__ explicit SplitB(uint32_t d) : o(d & 0xFF00FF00u), e((d << 8) & 0xFF00FF00u) {}
-  __device__ __forceinline__ SplitB mx(const SplitB& b) const { SplitB r; r.o = pkmax(o, b.o); r.e = pkmax(e, b.e); return r; }
-  __device__ __forceinline__ uint32_t merge() const { return (o & 0xFF00FF00u) | ((e >> 8) & 0x00FF00FFu); }
-};
-// LOADC(k): packed dword at clamped coordinate k along the pooled axis; STORE(o, v): write output o.
+// LOADC(k): packed dword at clamped coordinate k along the pooled axis; STORE(o, v): write output o (v: SplitB).
 template <int NO, int LIM, class LOADC, class STORE>
 __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
   constexpr int NR = NO + 3;                       // odd pairs o0-2 .. o0+NO
@@ -655,7 +676,7 @@ __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
 #pragma unroll
   for (int jj = 0; jj < NR - 1; ++jj) q[jj] = r[jj].mx(r[jj + 1]);
 #pragma unroll
-  for (int n = 0; n < NO; ++n) store(o0 + n, q[n].mx(q[n + 2]).merge());
+  for (int n = 0; n < NO; ++n) store(o0 + n, q[n].mx(q[n + 2]));
 }
 template <int F, int NT>
 YF_STAGE_FN void pool8_h(char* frames, int tid) {
@@ -669,7 +690,7 @@ YF_STAGE_FN void pool8_h(char* frames, int tid) {
     char* dst = fbase + B_HB::OFF + (y * OW) * 20 + 4 * cg;
     pool8_sweep<NO, B_T4::W - 1>(min(k * NO, OW - NO),
                                  [&](int x) { return lds_u32(row + x * B_T4::S); },
-                                 [&](int ox, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v; });
+                                 [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
   }
 }
 template <int F, int NT>
@@ -685,7 +706,7 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
     char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
     pool8_sweep<NO, B_HB::H - 1>(min(k * NO, OH - NO),
                                  [&](int r) { return lds_u32(col + r * (OW * 20)); },
-                                 [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4<YF_L_Q21>(v); });
+                                 [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4_raw<YF_L_Q21>(v); });
   }
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
@@ -697,13 +718,13 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
     const int p = t % PP; const int f = t / PP;
     const int oy = p / OW, ox = p - oy * OW;
     char* fbase = frames + f * FRAME_BYTES;
-    ByteMax m;
+    SplitB m;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
-        m.add(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg));
-    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4<YF_L_Q45>(m.get());
+        m = m.mx(SplitB(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
+    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
   }
 }
 
@@ -824,7 +845,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     (void)lane; (void)wave;
     YF_SYNC();                                                         // previous group's arena is dead
     stage_no = 0;
-    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_f);
+    int tid_s = tid0;
+    asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
+    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
     fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()

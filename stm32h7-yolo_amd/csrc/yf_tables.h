@@ -75,7 +75,8 @@ enum { YF_W_DW3 = 0, YF_W_DW10, YF_W_DW15, YF_W_DW27, YF_W_DW32, YF_W_DW38, YF_W
 enum { YF_A_ADD18 = 0, YF_A_ADD35, YF_A_ADD41, YF_N_ADD };
 
 /* 256-entry byte LUTs (index q+128, value int8 stored as a byte), in execution order.
- * LEAKY_n = TFLite int8 LEAKY_RELU of tflite op n; Q21/Q45 = QUANTIZE ops; L43Q44 = QUANTIZE#44 o LEAKY#43. */
+ * LEAKY_n = TFLite int8 LEAKY_RELU of tflite op n; Q21/Q45 = QUANTIZE ops; L43Q44 = QUANTIZE#44 o LEAKY#43.
+ * Q21 and Q45 (the max-pool outputs) are RAW-indexed instead: index = the int8 bit pattern as an unsigned byte. */
 enum {
   YF_L_LEAKY2 = 0, YF_L_LEAKY4, YF_L_LEAKY7, YF_L_Q21, YF_L_LEAKY11, YF_L_LEAKY14, YF_L_LEAKY16, YF_L_LEAKY20,
   YF_L_LEAKY24, YF_L_Q45, YF_L_LEAKY28, YF_L_LEAKY31, YF_L_LEAKY33, YF_L_LEAKY37, YF_L_LEAKY39, YF_L_L43Q44,

@@ -103,8 +103,8 @@ def test_leaky_and_requant_luts_equal_oracle(prep, oracle, pack):
                                            ctypes.byref(m), ctypes.byref(sh))
         return np.array([np.clip(oracle.lib.yfo_mbqm(q - T[t_in]["zp"], m.value, sh.value) + T[t_out]["zp"], -128, 127)
                          for q in range(-128, 128)], np.int8)
-    assert np.array_equal(lut[3], requant(58, 103))            # QUANTIZE #21
-    assert np.array_equal(lut[9], requant(74, 101))            # QUANTIZE #45
+    assert np.array_equal(np.roll(lut[3], 128), requant(58, 103))   # QUANTIZE #21, raw-indexed (index = int8 bit pattern)
+    assert np.array_equal(np.roll(lut[9], 128), requant(74, 101))   # QUANTIZE #45, raw-indexed
     q44 = requant(92, 102)
     l43 = oracle.leaky_lut(43)
     assert np.array_equal(lut[15], q44[l43.astype(int) + 128])  # QUANTIZE #44 o LEAKY_RELU #43
