@@ -350,7 +350,11 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
     const int idx = k < RSW ? k : (k - RSW + 1) * RSW + 3;
     *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B_IN::OFF + idx * 4) = hv;
   }
-  const long last = n_frames - 1 - first_frame;                   // frames past the end of the batch re-read the last one
+  // frames past the end of the batch re-read the last one; everything per item is 32-bit arithmetic off one scalar base
+  const long rest = n_frames - 1 - first_frame;
+  const int lastf = __builtin_amdgcn_readfirstlane((int)(rest < (long)(F - 1) ? rest : (long)(F - 1)));
+  const int8_t* base = in + first_frame * IN_FRAME_BYTES;
+  static_assert(RSW == B_IN::W + 4 && B_IN::S == 4, "dst = OFF + 16 * (r + y + RSW/4 + 1) relies on rows of W + 4 dwords");
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int i = tid + it * NT;
@@ -359,8 +363,8 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
 #pragma unroll
     for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
     const int r = i - f * PER_FRAME;
-    const long fs = (long)f < last ? (long)f : last;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (first_frame + fs) * IN_FRAME_BYTES + r * 12);
+    const uint32_t off = (uint32_t)(min(f, lastf) * PER_FRAME + r) * 12u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(base + off);
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
     uint4 px;
     px.x = d0;
@@ -368,8 +372,8 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
     px.z = funnel(d2, d1, 16);
     px.w = d2 >> 8;
     const int y = (int)((uint32_t)r / (uint32_t)WQ);
-    const int xq = r - y * WQ;
-    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + ((y + 1) * RSW + 4 * xq + 4) * 4) = px;
+    // halo'd dword index ((y + 1) * RSW + 4 * xq + 4) with xq = r - y * WQ, RSW = 4 * WQ + 4  ->  4 * (r + y) + RSW + 4
+    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
   }
 }
 
@@ -433,9 +437,7 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
   int cur_chunk = -1;
   v4i a[TPJ][KS];
   PassV pv[TPJ];
-#if YF_EXP == 1
-  PassS ksr[TPJ];                           // experiment: scalar constants resident per chunk instead of one load per tile
-#endif
+  PassS ksr[TPJ];                           // scalar constants stay resident per chunk (one load per tile costs a wait per tile)
   for (int j = j0; j < j1; ++j) {
     const int chunk = j / MT, mt = j - chunk * MT;
     if (chunk != cur_chunk) {
@@ -444,9 +446,7 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
       for (int t = 0; t < TPJ; ++t) {
         const int ps = min(chunk * TPJ + t, NP - 1);
         pv[t] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
-#if YF_EXP == 1
         ksr[t] = load_pass_s(pp + ps * (int)sizeof(yf_pass));
-#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           a[t][ks] = v4i{0, 0, 0, 0};
@@ -480,11 +480,7 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
     for (int t = 0; t < TPJ; ++t) {
       const int ps = chunk * TPJ + t;
       if (ps < NP) {                                          // uniform
-#if YF_EXP == 1
         const PassS k = ksr[t];
-#else
-        const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
-#endif
         v4i acc = {ACC0, ACC0, ACC0, ACC0};
 #if YF_EXP == 7
 #pragma unroll
@@ -633,7 +629,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
       requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
       *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
     };
-#if YF_EXP == 1   // experiment: two jobs in flight per iteration (memory-level parallelism inside the wave)
+    // two jobs in flight per iteration: the second job's tap reads and MFMAs overlap the first one's epilogue chain
     for (; j + 1 < jend; j += 2) {
       v4i p0, p1, p2 = {0, any_value(), any_value(), any_value()}, q0, q1, q2 = {0, any_value(), any_value(), any_value()};
       char *dp, *dq;
@@ -644,7 +640,6 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
       finish(ap, dp);
       finish(aq, dq);
     }
-#endif
     for (; j < jend; ++j) {
       v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
       char* dst;
@@ -783,7 +778,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   // Static issue priority for the first-dispatched half of the workgroup (waves w and w + NW/2 share a SIMD): one wave of
   // every SIMD pair runs ahead instead of both stalling on the same stage phases.  In-run A/B: -1.9 % kernel time; the
   // opposite assignment (younger half) costs +3.5 %, per-workgroup priorities do nothing.
+#if YF_EXP != 1
   if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
