@@ -201,8 +201,13 @@ typedef struct yf_det_ {      /* one detection; mirrors the fields printed at yo
   int32_t x1, y1, x2, y2;
 } yf_det;
 
-enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anchor-major, conf > 0.7, xyxy * scale, int32 */
-       YF_DECODE_FW = 1 };    /* stm32/X-CUBE-AI/App/yoloface.c:98-152: cell-major, conf >= 0.7, axis swap, clamp, x2 */
+enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anchor-major, conf > 0.7, xyxy * scale, int32
+                                 (float -> int32 as numpy on an x86-64 PC: truncation, out of range -> INT32_MIN) */
+       YF_DECODE_FW = 1,      /* stm32/X-CUBE-AI/App/yoloface.c:98-152 on the Cortex-M7: cell-major, conf >= 0.7, axis swap,
+                                 clamp, x2; float -> int is VCVT (truncation, SATURATING: a box edge beyond 2^31 becomes
+                                 INT32_MAX and prints as -2 after the x2) */
+       YF_DECODE_FW_HOST = 2 };/* the same loop compiled for an x86-64 host (cvttss2si: out of range -> INT32_MIN, which the
+                                 clamps then turn into 0 / 55); equals YF_DECODE_FW whenever every edge fits in int32 */
 
 /* Select GPU (default 0 / $LOCAL_RANK is NOT read here; the caller decides).  Call before ai_network_init. */
 YF_API int  yf_network_set_device(ai_handle network, int device);
@@ -220,7 +225,7 @@ YF_API long yf_network_dump_bytes(void);
  * LDS-resident kernel, 160x160 runs the same stage code layer by layer over an HBM arena owned by the library. */
 YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, const void* d_in, void* d_out, long n, void* stream);
 /* Box decode on the GPU from device-resident heads: d_dets yf_det[n][cap], d_counts int32[n] (true count, may
- * exceed cap).  mode = YF_DECODE_PY or YF_DECODE_FW. */
+ * exceed cap).  mode = YF_DECODE_PY, YF_DECODE_FW or YF_DECODE_FW_HOST. */
 YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                                      void* d_dets, void* d_counts, int cap, void* stream);
 /* Network and box decode in ONE launch (the firmware's ai_network_run + post-processing, yoloface.c:98-152 /
@@ -228,6 +233,13 @@ YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, lon
  * decodes its frames' heads while they are still on chip.  Same records as yf_network_decode_device. */
 YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, void* d_heads, long n, int mode, float w_scale, float h_scale,
                                          void* d_dets, void* d_counts, int cap, void* stream);
+/* The firmware's UART text for one frame (stm32/User/main.c:46,53 and yoloface.c:148, byte for byte, CR LF line ends):
+ *   === Frame N ===  /  40 dashes  /  [Face k] BBox: [x1, y1, x2, y2], Conf: c.cc  per record  /  40 dashes  /
+ *   [INFO] Total faces detected: count
+ * dets: the frame's firmware-mode records (host memory), count: its candidate count (lines are written for
+ * min(count, cap) records, the total line carries count like the firmware's face_num).  Returns the number of
+ * bytes the text needs (excluding the terminating NUL); at most buflen - 1 bytes are stored.  Host-only, no GPU. */
+YF_API long yf_network_format_uart(unsigned frame_no, const yf_det* dets, int count, int cap, char* buf, size_t buflen);
 /* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
 /* `iters` back-to-back launches of the fused kernel on `stream`, bracketed by HIP events on that stream;

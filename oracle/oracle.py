@@ -42,7 +42,7 @@ def _load():
     lib.yfo_decode_py.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Det), ctypes.c_int]
     lib.yfo_decode_c.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                 ctypes.POINTER(Det), ctypes.c_int]
+                                 ctypes.POINTER(Det), ctypes.c_int, ctypes.c_int]
     lib.yfo_prepare_rgb565.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.yfo_quantize_multiplier.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]
     lib.yfo_mbqm.restype = ctypes.c_int32
@@ -116,10 +116,11 @@ class Oracle:
                                    w_scale, h_scale, buf, max_dets)
         return [(d.frame, d.anchor, d.row, d.col, d.q_conf, d.conf, d.x1, d.y1, d.x2, d.y2) for d in buf[:min(n, max_dets)]]
 
-    def decode_c(self, head, frame=0, max_dets=147):
+    def decode_c(self, head, frame=0, max_dets=147, host_x86=False):
+        """yoloface.c:98-152; host_x86: float -> int as an x86-64 build of that file converts (the MCU saturates)."""
         hd = np.ascontiguousarray(head, dtype=np.int8)
         buf = (Det * max_dets)()
-        n = self.lib.yfo_decode_c(hd.ctypes.data, frame, self.sig.ctypes.data, self.ex.ctypes.data, buf, max_dets)
+        n = self.lib.yfo_decode_c(hd.ctypes.data, frame, self.sig.ctypes.data, self.ex.ctypes.data, buf, max_dets, int(host_x86))
         return [(d.frame, d.anchor, d.row, d.col, d.q_conf, d.conf, d.x1, d.y1, d.x2, d.y2) for d in buf[:min(n, max_dets)]]
 
     def prepare_rgb565(self, rgb565_112):

@@ -460,6 +460,13 @@ static inline int32_t f2i(float v) {
   if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
   return (int32_t)v;
 }
+/* float -> int32 on the firmware's Cortex-M7 (VCVT.S32.F32): truncation, saturation, NaN -> 0 */
+static inline int32_t f2i_sat(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return INT32_MAX;
+  if (v <= -2147483648.0f) return INT32_MIN;
+  return (int32_t)v;
+}
 static inline int32_t dbl(int32_t v) { return (int32_t)((uint32_t)v * 2u); }
 static const float k_anchors[3][2] = {{9.f, 14.f}, {12.f, 17.f}, {22.f, 21.f}};  /* tflite_prediction.py:45-47, yoloface.c:20 */
 
@@ -492,7 +499,7 @@ int yfo_decode_py(const int8_t* head, int gh, int gw, int frame, const float* si
 }
 
 /* stm32/X-CUBE-AI/App/yoloface.c:98-152 (post_process): cell-major, conf >= 0.7, LCD axis swap, clamps, x2. */
-int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* ex, yfo_det* dets, int max_dets) {
+int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* ex, yfo_det* dets, int max_dets, int host_x86) {
   int n = 0;
   for (int i = 0; i < 49; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -504,7 +511,9 @@ int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* e
       float y = (sig[p[1] + 128] + grid_y) * 8;
       float w = ex[p[2] + 128] * k_anchors[j][0];
       float h = ex[p[3] + 128] * k_anchors[j][1];
-      int y2 = f2i(x - w / 2), y1 = f2i(x + w / 2), x1 = f2i(y - h / 2), x2 = f2i(y + h / 2);
+      /* yoloface.c:135-138: float expressions assigned to int; the MCU saturates, an x86-64 host build does not */
+      int y2 = host_x86 ? f2i(x - w / 2) : f2i_sat(x - w / 2), y1 = host_x86 ? f2i(x + w / 2) : f2i_sat(x + w / 2);
+      int x1 = host_x86 ? f2i(y - h / 2) : f2i_sat(y - h / 2), x2 = host_x86 ? f2i(y + h / 2) : f2i_sat(y + h / 2);
       if (x1 < 0) x1 = 0;
       if (y1 < 0) y1 = 0;
       if (x2 > 55) x2 = 55;

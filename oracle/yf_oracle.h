@@ -60,7 +60,7 @@ int yfo_decode_py(const int8_t* head, int gh, int gw, int frame, const float* si
                   float w_scale, float h_scale, yfo_det* dets, int max_dets);
 /* Firmware decode (stm32/X-CUBE-AI/App/yoloface.c:98-152): cell-major order, conf >= 0.7, axis swap, clamp to
  * [0,55], x2.  Same tables. */
-int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* ex, yfo_det* dets, int max_dets);
+int yfo_decode_c(const int8_t* head, int frame, const float* sig, const float* ex, yfo_det* dets, int max_dets, int host_x86);
 
 /* Frame preparation (stm32/X-CUBE-AI/App/yoloface.c:26-93): 112x112 big-endian RGB565 -> 56x56 box average in
  * 5/6/5 space -> int8 NHWC (value-128). */

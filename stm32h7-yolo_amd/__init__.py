@@ -3,5 +3,6 @@
 The directory name carries a hyphen (it mirrors the reference repository's name), so import it with
     import importlib; yf = importlib.import_module("stm32h7-yolo_amd")
 """
-from .binding import (Network, NetworkError, build, load, LIB_PATH, DET_DTYPE, YF_DECODE_PY, YF_DECODE_FW,  # noqa: F401
+from .binding import (Network, NetworkError, build, load, LIB_PATH, DET_DTYPE, YF_DECODE_PY, YF_DECODE_FW, YF_DECODE_FW_HOST,  # noqa: F401
+                      format_uart,
                       IN_BYTES, OUT_BYTES)

@@ -24,7 +24,7 @@ IN_H, IN_W, IN_C = 56, 56, 3
 OUT_H, OUT_W, OUT_C = 7, 7, 18
 IN_BYTES, OUT_BYTES = IN_H * IN_W * IN_C, OUT_H * OUT_W * OUT_C
 WEIGHTS_BYTES, ACTIVATIONS_BYTES = 11304, 29784
-YF_DECODE_PY, YF_DECODE_FW = 0, 1
+YF_DECODE_PY, YF_DECODE_FW, YF_DECODE_FW_HOST = 0, 1, 2
 
 
 class AiError(ctypes.Structure):
@@ -85,7 +85,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
+           "yf_network_time_stages", "yf_network_format_uart", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
@@ -155,6 +155,8 @@ def load():
     lib.yf_network_run_decode_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
     lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_format_uart.restype = cl
+    lib.yf_network_format_uart.argtypes = [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.yf_network_time_device.restype = cl
     lib.yf_network_time_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.yf_network_time_stages.restype = cl
@@ -168,6 +170,18 @@ def load():
     lib.yf_network_kernel_name.argtypes = [vp]
     _lib = lib
     return lib
+
+
+def format_uart(frame_no, dets, count=None):
+    """The firmware's UART text of one frame (stm32/User/main.c:46,53; yoloface.c:148) through the library's C
+    formatter.  dets: DET_DTYPE records of the frame (firmware mode), count: the frame's candidate count."""
+    d = np.ascontiguousarray(dets, dtype=DET_DTYPE).reshape(-1)
+    count = d.shape[0] if count is None else int(count)
+    lib = load()
+    need = lib.yf_network_format_uart(frame_no, d.ctypes.data if d.shape[0] else None, count, d.shape[0], None, 0)
+    buf = ctypes.create_string_buffer(need + 1)
+    lib.yf_network_format_uart(frame_no, d.ctypes.data if d.shape[0] else None, count, d.shape[0], buf, need + 1)
+    return buf.raw[:need]
 
 
 class NetworkError(RuntimeError):

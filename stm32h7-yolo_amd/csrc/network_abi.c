@@ -305,6 +305,28 @@ YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, c
   return 0;
 }
 
+/* stm32/User/main.c:46,53 + yoloface.c:148: the text the firmware prints per frame, byte for byte. */
+YF_API long yf_network_format_uart(unsigned frame_no, const yf_det* dets, int count, int cap, char* buf, size_t buflen) {
+  static const char dashes[] = "----------------------------------------";
+  long need = 0;
+  size_t room = buf ? buflen : 0;
+#define YF_EMIT(...)                                                                                              \
+  do {                                                                                                            \
+    const size_t at_ = (size_t)need < room ? (size_t)need : room;                                                 \
+    const int w_ = snprintf(room ? buf + at_ : NULL, room - at_, __VA_ARGS__);                                    \
+    if (w_ < 0) { return -1; }                                                                                    \
+    need += w_;                                                                                                   \
+  } while (0)
+  YF_EMIT("=== Frame %d ===\r\n%s\r\n", (int)frame_no, dashes);
+  const int lines = dets ? (count < cap ? count : cap) : 0;
+  for (int k = 0; k < lines; ++k)        /* face_num is a uint8_t counted before the print (yoloface.c:125) */
+    YF_EMIT("[Face %d] BBox: [%d, %d, %d, %d], Conf: %.2f\r\n", (int)(uint8_t)(k + 1), dets[k].x1, dets[k].y1, dets[k].x2, dets[k].y2,
+            (double)dets[k].conf);
+  YF_EMIT("%s\r\n[INFO] Total faces detected: %d\r\n", dashes, (int)(uint8_t)count);
+#undef YF_EMIT
+  return need;
+}
+
 YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                                      void* d_dets, void* d_counts, int cap, void* stream) {
   yf_context* c = ready(network);

@@ -2,6 +2,7 @@
 // still in LDS).  Included once by yf_engine.hip, before the kernel header.
 //   YF_DECODE_PY: yoloface/tflite/tflite_prediction.py:42-63  (a, row, col), conf > 0.7
 //   YF_DECODE_FW: stm32/X-CUBE-AI/App/yoloface.c:98-152       (cell, a), conf >= 0.7, LCD axis swap, clamp, x2
+//                 float -> int saturates like the Cortex-M7's VCVT; YF_DECODE_FW_HOST converts like an x86-64 build
 // All transcendental values come from the committed float32 tables; the remaining float32 operations are single
 // IEEE operations (the engine is compiled with -ffp-contract=off).
 #ifndef YF_DECODE_HIP_H
@@ -18,6 +19,10 @@ __device__ __constant__ uint32_t d_exp_bits[256];
 // float -> int32 with the x86 convention of the reference's hosts (cvttss2si): truncate, out of range -> INT32_MIN
 __device__ __forceinline__ int f2i_x86(float v) {
   return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+// float -> int32 as the Cortex-M7 does it (VCVT.S32.F32): truncate, saturate, NaN -> 0
+__device__ __forceinline__ int f2i_sat(float v) {
+  return v != v ? 0 : (v >= 2147483648.0f ? 0x7FFFFFFF : (v <= -2147483648.0f ? (int)0x80000000 : (int)v));
 }
 __device__ __forceinline__ int dbl_wrap(int v) { return (int)((unsigned)v * 2u); }
 
@@ -56,7 +61,10 @@ __device__ __forceinline__ void decode_frame(const int8_t* head, long frame, int
         x1 *= w_scale; x2 *= w_scale; y1 *= h_scale; y2 *= h_scale;
         d.x1 = f2i_x86(x1); d.y1 = f2i_x86(y1); d.x2 = f2i_x86(x2); d.y2 = f2i_x86(y2);
       } else {
-        int y2 = f2i_x86(cx - bw / 2), y1 = f2i_x86(cx + bw / 2), x1 = f2i_x86(cy - bh / 2), x2 = f2i_x86(cy + bh / 2);
+        const float fy2 = cx - bw / 2, fy1 = cx + bw / 2, fx1 = cy - bh / 2, fx2 = cy + bh / 2;
+        const bool arm = mode == YF_DECODE_FW;
+        int y2 = arm ? f2i_sat(fy2) : f2i_x86(fy2), y1 = arm ? f2i_sat(fy1) : f2i_x86(fy1);
+        int x1 = arm ? f2i_sat(fx1) : f2i_x86(fx1), x2 = arm ? f2i_sat(fx2) : f2i_x86(fx2);
         if (x1 < 0) x1 = 0;
         if (y1 < 0) y1 = 0;
         if (x2 > 55) x2 = 55;

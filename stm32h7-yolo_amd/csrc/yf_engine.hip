@@ -240,7 +240,7 @@ int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_du
 
 int yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,
                                 void* d_dets, void* d_counts, int cap, void* stream) {
-  if (!e || !d_in || !d_out || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW)) return YF_ENG_ERR_ARG;
+  if (!e || !d_in || !d_out || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST)) return YF_ENG_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
   return launch(e, e->var, d_in, d_out, nullptr, n, (hipStream_t)stream, -1, &dec);
@@ -322,7 +322,7 @@ int yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, i
 
 int yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode, float w_scale, float h_scale,
                             void* d_dets, void* d_counts, int cap, void* stream) {
-  if (!e || !d_heads || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW)) return YF_ENG_ERR_ARG;
+  if (!e || !d_heads || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST)) return YF_ENG_ERR_ARG;
   if (n == 0) return YF_ENG_OK;
   HIPCHK(e, hipSetDevice(e->device));
   hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,

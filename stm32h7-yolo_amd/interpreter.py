@@ -118,11 +118,14 @@ def decode_boxes(head, conf_thres=0.7, w_scale=1.0, h_scale=1.0):
     return boxes.astype(np.int32)
 
 
-def format_uart(frame_no, dets_fw):
-    """The firmware's UART text (stm32/User/main.c:46,53; yoloface.c:148) for firmware-mode detections, parsed
-    unchanged by the reference monitor's regexes."""
-    lines = [f"=== Frame {frame_no} ===\r\n"]
+def format_uart(frame_no, dets_fw, count=None):
+    """The firmware's UART text of one frame, byte for byte (stm32/User/main.c:46,53: frame banner, 40 dashes, the
+    total line; yoloface.c:148: one line per face; CR LF line ends), parsed unchanged by the reference monitor's
+    regexes (上位机/IAP/main.py:325-363).  Pure-Python mirror of the library's yf_network_format_uart."""
+    dashes = "-" * 40
+    n = len(dets_fw) if count is None else int(count)
+    lines = ["=== Frame %d ===\r\n%s\r\n" % (frame_no, dashes)]
     for k, d in enumerate(dets_fw, 1):
-        lines.append("[Face %d] BBox: [%d, %d, %d, %d], Conf: %.2f\r\n" % (k, d["x1"], d["y1"], d["x2"], d["y2"], d["conf"]))
-    lines.append(f"[INFO] Total faces detected: {len(dets_fw)}\r\n")
+        lines.append("[Face %d] BBox: [%d, %d, %d, %d], Conf: %.2f\r\n" % (k & 255, d["x1"], d["y1"], d["x2"], d["y2"], d["conf"]))
+    lines.append("%s\r\n[INFO] Total faces detected: %d\r\n" % (dashes, n & 255))
     return "".join(lines)

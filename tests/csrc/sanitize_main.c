@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
   int8_t hot[OUT];
   memset(hot, 127, sizeof hot);
   if (yfo_decode_py(hot, 7, 7, 0, tabs, tabs + 256, 7.3f, 6.4f, dets, 147) != 147) return 10;
-  if (yfo_decode_c(hot, 0, tabs, tabs + 256, dets, 5) != 147) return 11;  /* capacity smaller than the count */
+  if (yfo_decode_c(hot, 0, tabs, tabs + 256, dets, 5, 0) != 147 || yfo_decode_c(hot, 0, tabs, tabs + 256, dets, 5, 1) != 147) return 11;  /* capacity smaller than the count */
   for (int i = 0; i < N; ++i) (void)yfo_decode_py(heads + i * OUT, 7, 7, i, tabs, tabs + 256, 1.f, 1.f, dets, 147);
   int8_t lut[256];
   for (int op = 0; op < yfo_num_ops(m); ++op) (void)yfo_leaky_lut(m, op, lut);

@@ -316,13 +316,13 @@ def _dets(buf, counts, cap):
     return out
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_box_decode_on_gpu_equals_oracle(yf, network, oracle, golden, torch_cuda, mode):
     torch = torch_cuda
     rng = np.random.default_rng(21)
     heads = rng.integers(-60, 40, (300, 7, 7, 18), dtype=np.int8)
     heads[:6] = golden["heads"]
-    heads[6] = 127                                    # every candidate fires: 147 detections
+    heads[6] = 127                                    # every candidate fires: 147 detections, every box edge beyond int32
     heads[7] = -128
     n, cap = heads.shape[0], 147
     d_h = torch.from_numpy(heads).cuda()
@@ -335,7 +335,7 @@ def test_box_decode_on_gpu_equals_oracle(yf, network, oracle, golden, torch_cuda
     counts = d_c.cpu().numpy()
     got = _dets(buf, counts, cap)
     for f in range(n):
-        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f)
+        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f, host_x86=(mode == 2))
         assert counts[f] == len(ref)
         assert got[f] == [(d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9]) for d in ref], f"frame {f}"
         assert all(int(d["frame"]) == f for d in buf[f, :counts[f]])
@@ -349,7 +349,7 @@ def test_box_decode_on_gpu_equals_oracle(yf, network, oracle, golden, torch_cuda
     assert _dets(buf2, counts, 5)[6] == got[6][:5]
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_network_and_decode_in_one_launch(yf, network, oracle, torch_cuda, mode):
     """yf_network_run_decode_device: heads AND detection records from one launch (the heads are decoded while still
     in LDS) equal the oracle's network followed by the oracle's decode; ragged batch (odd n) and a small capacity."""
@@ -372,7 +372,7 @@ def test_network_and_decode_in_one_launch(yf, network, oracle, torch_cuda, mode)
     got = _dets(buf, counts, cap)
     n_det = 0
     for f in range(n):
-        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f)
+        ref = oracle.decode_py(heads[f], f, ws, hs) if mode == 0 else oracle.decode_c(heads[f], f, host_x86=(mode == 2))
         assert counts[f] == len(ref)
         assert got[f] == [(d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9]) for d in ref][:cap], f"frame {f}"
         n_det += len(ref)
@@ -430,3 +430,57 @@ def test_reference_header_caller_binary(golden, tmp_path, binary):
         assert r.returncode == 0, r.stdout + r.stderr
         assert "OK 6" in r.stdout and "macc 1344320" in r.stdout
         assert np.array_equal(np.fromfile(fout, np.int8).reshape(6, 7, 7, 18), golden["heads"])
+
+
+def _rgb565_frames(golden):
+    """112x112 big-endian RGB565 camera frames: random colours, and the golden 56x56 frames blown up 2x (each 2x2 block
+    one colour, so the firmware's box average gives the frame back up to the 5/6/5 truncation)."""
+    rng = np.random.default_rng(77)
+    raw = [rng.integers(0, 256, (112, 112, 2), dtype=np.uint8) for _ in range(3)]
+    for x in golden["inputs"][3:6]:
+        u = (x.astype(np.int16) + 128).astype(np.uint16)
+        px = ((u[..., 0] >> 3) << 11) | ((u[..., 1] >> 2) << 5) | (u[..., 2] >> 3)
+        px = np.repeat(np.repeat(px, 2, axis=0), 2, axis=1)
+        raw.append(np.stack([(px >> 8).astype(np.uint8), (px & 255).astype(np.uint8)], axis=-1))
+    return np.stack(raw).reshape(len(raw), 112 * 112 * 2)
+
+
+def test_reference_yoloface_c_links_unchanged_and_runs_on_the_gpu(yf, network, oracle, golden, torch_cuda, tmp_path):
+    """SURVEY.md 8(a) row a15.  oracle/_ref/abi_yoloface_caller = the reference's UNMODIFIED stm32/X-CUBE-AI/App/yoloface.c
+    (aiInit, aiRun, the 112->56 resize, prepare_yolo_data, post_process) + its network_data.c, compiled where they lie
+    against the reference's AI headers, linked to libyf_network.so, driven like stm32/User/main.c:42-54.  Its three
+    artefacts must equal this library's own: in_data = the GPU frame preparation, out_data = the head of the fused
+    kernel, stdout = the UART text formatted from the GPU's firmware-mode records (host float -> int convention: the
+    binary is an x86-64 build of yoloface.c).  A boundary test, not an oracle pin."""
+    torch = torch_cuda
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_yoloface_caller")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/abi_yoloface_caller was not built (needs /root/reference at build time)")
+    binding = importlib.import_module("stm32h7-yolo_amd.binding")
+    raw = _rgb565_frames(golden)
+    n = raw.shape[0]
+    f_raw, f_in, f_out = str(tmp_path / "cam.bin"), str(tmp_path / "in_data.bin"), str(tmp_path / "out_data.bin")
+    raw.tofile(f_raw)
+    r = subprocess.run([exe, f_raw, str(n), f_in, f_out], capture_output=True, timeout=180)
+    assert r.returncode == 0, r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+    in_data = np.fromfile(f_in, np.int8).reshape(n, 56, 56, 3)
+    out_data = np.fromfile(f_out, np.int8).reshape(n, 7, 7, 18)
+    # this library's pipeline on the same camera frames, all on the GPU
+    d_raw = torch.from_numpy(raw).cuda()
+    d_x = torch.zeros((n, 56, 56, 3), dtype=torch.int8, device="cuda")
+    d_h = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+    cap = 147
+    d_d = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_c = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    network.prepare_rgb565_device(d_raw.data_ptr(), d_x.data_ptr(), n)
+    network.run_decode_device(d_x.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap, yf.YF_DECODE_FW_HOST)
+    torch.cuda.synchronize()
+    assert np.array_equal(in_data, d_x.cpu().numpy()), "prepare_yolo_data (reference C) vs the GPU frame preparation"
+    assert np.array_equal(in_data, np.stack([oracle.prepare_rgb565(f) for f in raw]))
+    assert np.array_equal(out_data, d_h.cpu().numpy()), "out_data behind the reference's aiRun vs the fused kernel"
+    assert np.array_equal(out_data, oracle.run(in_data))
+    buf = d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap)
+    counts = d_c.cpu().numpy()
+    text = b"".join(binding.format_uart(k + 1, buf[k, :min(int(counts[k]), cap)], int(counts[k])) for k in range(n))
+    assert r.stdout == text, "UART text of the reference application vs yf_network_format_uart over the GPU records"
+    assert int(counts.sum()) > 0, "no frame produced a detection: the text comparison would be vacuous"
