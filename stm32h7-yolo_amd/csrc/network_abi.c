@@ -41,6 +41,11 @@ static void latch(yf_context* c, unsigned type, unsigned code, const char* text)
   if (text) snprintf(c->err_text, sizeof c->err_text, "%s", text);
 }
 
+void yf_impl_fail_init(ai_handle network, unsigned code, const char* text) {
+  yf_context* c = acquire(network);
+  if (c) latch(c, AI_ERROR_INIT_FAILED, code, text);
+}
+
 static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = type; e.code = code; return e; }
 
 /* ------------------------------------------------------------------------------------------------ create / destroy */
@@ -383,6 +388,9 @@ YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, 
 
 YF_API const char* yf_network_last_error_text(ai_handle network) {
   yf_context* c = acquire(network);
+  /* with the reference's generated network.c in front (runtime-level path) the caller's handle is ITS ai_network object,
+   * not this library's context: there is one instance either way, so any non-NULL handle reads the singleton's text */
+  if (!c && network != AI_HANDLE_NULL && g_network.state != ST_NONE) c = &g_network;
   return c ? c->err_text : "invalid handle";
 }
 

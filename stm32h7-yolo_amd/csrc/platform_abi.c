@@ -4,14 +4,19 @@
  * (ai_platform_*), layers_conv2d.h:192, layers_pool.h:374, layers_generic.h:494,598, layers_nl.h:606,
  * ai_math_helpers.h (forward_* / nl_func / ai_sum_* -- only referenced as function pointers in the layer tables).
  *
- * network.c keeps ownership of its static ai_network object (`g_network`, network.c:2929-2939); this layer treats it
- * as an opaque tag: ai_platform_network_create hands it back as the handle, every other call checks the tag and
- * forwards to the fused engine.  The node list, tensors and arrays of network.c are never walked: the graph is the
- * baked yoloface graph (weights come from the caller's blob through ai_platform_get_weights_map's params).
+ * network.c keeps ownership of its static ai_network object (`g_network`, network.c:2929-2939):
+ * ai_platform_network_create hands it back as the handle, every other call checks it and forwards to the fused engine.
+ * The engine implements ONE graph -- the 31 c-layers of the yoloface model.  ai_platform_network_init therefore walks
+ * the caller's node list (from ai_network.input_node, the way the ST runtime's scheduler does, core_common.h:101-109)
+ * and compares every node -- kind, kernel, stride, padding, groups, fused non-linearity, output shape, weight count --
+ * with the graph the engine was built for; any difference latches AI_ERROR_INIT_FAILED instead of silently running a
+ * different network.  Weights come from the caller's blob (ai_platform_get_weights_map's params).
  */
 #include "yf_impl.h"
+#include "st_graph_view.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef uint8_t* ai_ptr;                      /* ai_platform_interface.h: ai_ptr */
 typedef uint32_t ai_size;
@@ -50,9 +55,110 @@ YF_API ai_error ai_platform_network_get_error(ai_handle network) {
   return yf_impl_get_error(g_own);
 }
 
+/* ---- the graph the fused engine implements, in execution order (reference network.c:2204-2927, report
+ * network_generate_report.txt:290-480).  pad = {x0, y0, x1, y1} as network.c states it. */
+typedef struct { uint16_t id; uint8_t kind; uint16_t groups; uint8_t k, stride, nl; uint8_t pad[4]; uint16_t oh, ow, oc; uint32_t weights; } yf_expected_node;
+enum { K_CONV = 0, K_POOL = 1, K_ADD = 2, K_CONCAT = 3 };
+static const yf_expected_node k_graph[31] = {
+  /* id  kind      groups k  s  nl  pad            out H W C      weight elements */
+  {  2, K_CONV,      1, 3, 2, 1, {1, 1, 0, 0}, 28, 28,  8,   216}, {  4, K_CONV,   8, 3, 1, 1, {1, 1, 1, 1}, 28, 28,  8,    72},
+  {  5, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0}, 28, 28,  4,    32}, {  7, K_CONV,   1, 1, 1, 1, {0, 0, 0, 0}, 28, 28, 18,    72},
+  { 11, K_CONV,     18, 3, 2, 1, {1, 1, 0, 0}, 14, 14, 18,   162}, { 12, K_CONV,   1, 1, 1, 0, {0, 0, 0, 0}, 14, 14,  6,   108},
+  { 14, K_CONV,      1, 1, 1, 1, {0, 0, 0, 0}, 14, 14, 36,   216}, { 16, K_CONV,  36, 3, 1, 1, {1, 1, 1, 1}, 14, 14, 36,   324},
+  { 17, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0}, 14, 14,  6,   216}, { 18, K_ADD,    0, 0, 0, 0, {0, 0, 0, 0}, 14, 14,  6,     0},
+  { 20, K_CONV,      1, 1, 1, 1, {0, 0, 0, 0}, 14, 14, 18,   108}, {  8, K_POOL,   0, 8, 2, 0, {3, 3, 4, 4}, 14, 14, 18,     0},
+  { 22, K_CONCAT,    0, 0, 0, 0, {0, 0, 0, 0}, 14, 14, 36,     0}, { 24, K_CONV,   1, 1, 1, 1, {0, 0, 0, 0}, 14, 14, 24,   864},
+  { 28, K_CONV,     24, 3, 2, 1, {1, 1, 0, 0},  7,  7, 24,   216}, { 29, K_CONV,   1, 1, 1, 0, {0, 0, 0, 0},  7,  7,  8,   192},
+  { 31, K_CONV,      1, 1, 1, 1, {0, 0, 0, 0},  7,  7, 40,   320}, { 33, K_CONV,  40, 3, 1, 1, {1, 1, 1, 1},  7,  7, 40,   360},
+  { 34, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0},  7,  7,  8,   320}, { 35, K_ADD,    0, 0, 0, 0, {0, 0, 0, 0},  7,  7,  8,     0},
+  { 37, K_CONV,      1, 1, 1, 1, {0, 0, 0, 0},  7,  7, 40,   320}, { 39, K_CONV,  40, 3, 1, 1, {1, 1, 1, 1},  7,  7, 40,   360},
+  { 40, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0},  7,  7,  8,   320}, { 41, K_ADD,    0, 0, 0, 0, {0, 0, 0, 0},  7,  7,  8,     0},
+  { 43, K_CONV,      1, 1, 1, 1, {0, 0, 0, 0},  7,  7, 24,   192}, { 25, K_POOL,   0, 4, 2, 0, {1, 1, 2, 2},  7,  7, 24,     0},
+  { 46, K_CONCAT,    0, 0, 0, 0, {0, 0, 0, 0},  7,  7, 48,     0}, { 48, K_CONV,   1, 1, 1, 1, {0, 0, 0, 0},  7,  7, 40,  1920},
+  { 50, K_CONV,     40, 3, 1, 1, {1, 1, 1, 1},  7,  7, 40,   360}, { 52, K_CONV,   1, 1, 1, 1, {0, 0, 0, 0},  7,  7, 32,  1280},
+  { 53, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0},  7,  7, 18,   576},
+};
+
+YF_API void forward_conv2d_integer_SSSA_ch(void* layer);
+YF_API void forward_mp_integer_INT8(void* layer);
+YF_API void forward_eltwise_integer_INT8(void* layer);
+YF_API void forward_concat(void* layer);
+YF_API void nl_func_array_integer(void);
+
+static int shape4(const stv_storage* s, uint32_t out[4]) {
+  if (!s->data || STV_STORAGE_SIZE(*s) != 4) return 0;
+  memcpy(out, s->data, 16);
+  return 1;
+}
+
+/* 0 = the caller's graph is the yoloface graph; otherwise `why` says where it differs */
+static int verify_graph(const stv_network* net, char* why, size_t n) {
+  static const char* const kind_name[] = {"conv2d", "pool", "eltwise add", "concat"};
+  const stv_node* node = net->input_node;
+  for (int i = 0; i < 31; ++i) {
+    const yf_expected_node* e = &k_graph[i];
+#define BAD(...)                                                                                                   \
+  do {                                                                                                             \
+    const int w_ = snprintf(why, n, "the caller's graph is not the yoloface graph: node %d (id %u, expected %s id %u): ", i, \
+                            node ? (unsigned)node->id : 0u, kind_name[e->kind], (unsigned)e->id);               \
+    if (w_ > 0 && (size_t)w_ < n) { snprintf(why + w_, n - (size_t)w_, __VA_ARGS__); }                          \
+    return 1;                                                                                                      \
+  } while (0)
+    if (!node) BAD("the list ends after %d nodes", i);
+    static const uint16_t type_of[] = {STV_LAYER_CONV2D, STV_LAYER_POOL, STV_LAYER_ELTWISE_INTEGER, STV_LAYER_CONCAT};
+    void (*const fwd_of[])(void*) = {forward_conv2d_integer_SSSA_ch, forward_mp_integer_INT8, forward_eltwise_integer_INT8, forward_concat};
+    if (node->type != type_of[e->kind] || node->forward != fwd_of[e->kind]) BAD("layer type 0x%x / kernel differ", (unsigned)node->type);
+    if (node->id != e->id) BAD("layer id %u", (unsigned)node->id);
+    if (!node->tensors || node->tensors->size < 2 || !node->tensors->chain) BAD("no tensor chain");
+    const stv_tensor_list* outs = &node->tensors->chain[1];
+    uint32_t sh[4];
+    if (outs->size < 1 || !outs->tensor || !outs->tensor[0] || !shape4(&outs->tensor[0]->shape, sh)) BAD("no output tensor");
+    if (sh[0] != 1 || sh[1] != e->oc || sh[2] != e->ow || sh[3] != e->oh)
+      BAD("output shape %ux%ux%u, expected %ux%ux%u", (unsigned)sh[3], (unsigned)sh[2], (unsigned)sh[1], (unsigned)e->oh, (unsigned)e->ow, (unsigned)e->oc);
+    if (e->kind == K_CONV) {
+      const stv_conv2d* c = (const stv_conv2d*)node;
+      uint32_t pad[4];
+      if (c->groups != e->groups) BAD("groups %u, expected %u", (unsigned)c->groups, (unsigned)e->groups);
+      if (c->filter_stride.data[0] != e->stride || c->filter_stride.data[1] != e->stride)
+        BAD("stride %ux%u, expected %ux%u", (unsigned)c->filter_stride.data[0], (unsigned)c->filter_stride.data[1], (unsigned)e->stride, (unsigned)e->stride);
+      if (c->dilation.data[0] != 1 || c->dilation.data[1] != 1) BAD("dilation %ux%u", (unsigned)c->dilation.data[0], (unsigned)c->dilation.data[1]);
+      if (!shape4(&c->filter_pad, pad) || pad[0] != e->pad[0] || pad[1] != e->pad[1] || pad[2] != e->pad[2] || pad[3] != e->pad[3])
+        BAD("padding {%u,%u,%u,%u}, expected {%u,%u,%u,%u}", (unsigned)pad[0], (unsigned)pad[1], (unsigned)pad[2], (unsigned)pad[3],
+            (unsigned)e->pad[0], (unsigned)e->pad[1], (unsigned)e->pad[2], (unsigned)e->pad[3]);
+      if ((c->nl_func != NULL) != (e->nl != 0) || (c->nl_func && c->nl_func != nl_func_array_integer)) BAD("fused non-linearity %s", c->nl_func ? "present" : "absent");
+      if (e->nl && (!c->nl_params || c->nl_params->size != 256)) BAD("non-linearity table is not a 256-entry LUT");
+      if (node->tensors->size < 3) BAD("no weight tensors");
+      const stv_tensor_list* ws = &node->tensors->chain[2];
+      if (ws->size < 2 || !ws->tensor || !ws->tensor[0] || !ws->tensor[0]->data || ws->tensor[0]->data->size != e->weights)
+        BAD("weight tensor has %u elements, expected %u", ws->size >= 1 && ws->tensor && ws->tensor[0] && ws->tensor[0]->data ? (unsigned)ws->tensor[0]->data->size : 0u, (unsigned)e->weights);
+      if (!ws->tensor[1] || !ws->tensor[1]->data || ws->tensor[1]->data->size != e->oc) BAD("bias tensor size");
+    } else if (e->kind == K_POOL) {
+      const stv_pool* p = (const stv_pool*)node;
+      uint32_t pad[4];
+      if (p->pool_size.data[0] != e->k || p->pool_size.data[1] != e->k) BAD("window %ux%u, expected %ux%u", (unsigned)p->pool_size.data[0], (unsigned)p->pool_size.data[1], (unsigned)e->k, (unsigned)e->k);
+      if (p->pool_stride.data[0] != e->stride || p->pool_stride.data[1] != e->stride) BAD("stride %ux%u", (unsigned)p->pool_stride.data[0], (unsigned)p->pool_stride.data[1]);
+      if (!shape4(&p->pool_pad, pad) || pad[0] != e->pad[0] || pad[1] != e->pad[1] || pad[2] != e->pad[2] || pad[3] != e->pad[3])
+        BAD("padding {%u,%u,%u,%u}", (unsigned)pad[0], (unsigned)pad[1], (unsigned)pad[2], (unsigned)pad[3]);
+    } else {
+      const stv_tensor_list* ins = &node->tensors->chain[0];
+      if (ins->size != 2) BAD("%u inputs, expected 2", (unsigned)ins->size);
+    }
+    const stv_node* next = (node->next == node) ? NULL : node->next;     /* network.c ends the list with a self link (:2209) */
+    if (i == 30 && next) BAD("more than 31 nodes");
+    node = next;
+#undef BAD
+  }
+  return 0;
+}
+
 /* returns the caller's context on success (network.c:3388-3389 treats NULL as failure) */
 YF_API void* ai_platform_network_init(ai_handle network, const ai_network_params* params) {
   if (!own(network)) return NULL;
+  char why[384];
+  if (verify_graph((const stv_network*)network, why, sizeof why) != 0) {
+    yf_impl_fail_init(g_own, AI_ERROR_CODE_NETWORK, why);
+    return NULL;
+  }
   return yf_impl_init(g_own, params) ? network : NULL;
 }
 

@@ -10,4 +10,6 @@ ai_i32    yf_impl_run(ai_handle network, const ai_buffer* input, ai_buffer* outp
 ai_i32    yf_impl_forward(ai_handle network, const ai_buffer* input);
 ai_bool   yf_impl_get_report(ai_handle network, ai_network_report* report);
 const uint8_t* yf_impl_resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act);
+/* latch an initialisation failure (first error wins, text replaces the previous one) */
+void      yf_impl_fail_init(ai_handle network, unsigned code, const char* text);
 #endif

@@ -173,3 +173,40 @@ def test_library_weight_blob_is_the_generated_one(yf):
     src = open(os.path.join(ROOT, "stm32h7-yolo_amd", "csrc", "gen", "yf_weights_blob_gen.c")).read()
     body = src[src.index("{") + 1: src.rindex("}")]
     assert blob == bytes(int(v) for v in re.findall(r"\d+", body))
+
+
+@pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
+def test_graph_views_match_reference_layout(tmp_path):
+    """csrc/st_graph_view.h restates the layout of the objects in the reference's generated network.c (ai_network, layer
+    base, conv2d / pool layers, tensor chain, storage klass, array).  tests/abi/graph_probe.c prints every size and offset
+    the library reads, once from ST's headers and once from the library's own views."""
+    outs = []
+    for flags in (["-I/root/reference/stm32/Middlewares/ST/AI/Inc"], ["-DYF_OWN_VIEWS", "-I" + os.path.join(ROOT, "stm32h7-yolo_amd", "csrc")]):
+        exe = str(tmp_path / ("probe" + str(len(outs))))
+        subprocess.check_call(["gcc", "-std=gnu11"] + flags + [os.path.join(ROOT, "tests", "abi", "graph_probe.c"), "-o", exe])
+        outs.append(subprocess.check_output([exe]).decode())
+    assert outs[0] == outs[1] and "ai_layer_conv2d 104" in outs[0]
+
+
+def test_tampered_reference_graph_is_refused():
+    """Runtime-level drop-in, SURVEY.md 8(f)3: ai_platform_network_init walks the CALLER's node list (the reference's
+    generated network.c) and refuses any graph that is not the one the fused engine implements.  oracle/_ref/abi_graph_tamper
+    includes the reference's unmodified network.c and changes one field of one layer in memory before ai_network_init."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_graph_tamper")
+    if has_reference():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/abi_graph_tamper was not built (needs /root/reference at build time)")
+    expect = {"stride": "node 14 (id 28", "groups": "groups 1, expected 36", "pad": "padding {1,1,1,0}, expected {1,1,0,0}",
+              "nl": "fused non-linearity present", "pool": "window 8x4, expected 8x8", "shape": "output shape 7x7x12, expected 7x7x18",
+              "order": "layer id 7", "weights": "weight tensor has 1000 elements, expected 1920"}
+    for what, text in expect.items():
+        r = subprocess.run([exe, what], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 4, (what, r.stdout, r.stderr)
+        assert "type=0x30 code=0x10" in r.stdout and "not the yoloface graph" in r.stdout and text in r.stdout, (what, r.stdout)
+    r = subprocess.run([exe, "none"], capture_output=True, text=True, timeout=120)      # the unedited graph passes the check
+    assert "not the yoloface graph" not in r.stdout
+    if _no_gpu():
+        assert r.returncode == 4 and "no HIP device" in r.stdout          # ... and then fails loudly for want of a GPU
+    else:
+        assert r.returncode == 0 and "init ok" in r.stdout
