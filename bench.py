@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """images/s of the int8 YOLO-face 56x56 forward on N MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path over this rank's batch of 4096 synthetic frames already resident in HBM:
-fused forward kernel -> GPU box decode -> (N > 1) RCCL all-gather of the int8 heads.  Weak scaling: every rank
-owns 4096 frames (BASELINE configs[1] at N=1, configs[2] = 32768 frames at N=8).
+A step = one pass of the hot path over this rank's batch of 4096 synthetic frames already resident in HBM: ONE launch of the
+fused kernel (forward + box decode) and, at N > 1, one RCCL all-gather of the DETECTIONS (fixed-capacity records + counts;
+the int8 heads stay on their rank unless --gather-heads).  Weak scaling: every rank owns 4096 frames (BASELINE configs[1] at
+N=1, configs[2] = 32768 frames at N=8).  The timed loop rotates through 8 distinct input batches (308 MB per rank, more than
+the 256 MB Infinity Cache), so the input bytes really come from HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -23,10 +26,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAMES_PER_GPU = 4096
+N_INPUT_BATCHES = 8                          # 8 x 38.5 MB > the 256 MB Infinity Cache
 ALGO_BYTES_PER_FRAME = 9408 + 882            # input + head, everything else stays in LDS
 DENSE_OPS_PER_FRAME = 2 * 813792             # int8 ops eligible for MFMA (dense convs), SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0                   # dense int8 MFMA = 2x the ~2.5 PF bf16 rate (MI355X_MICROARCH.md, Matrix cores)
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9             # MI355X_MICROARCH.md chip-level parameters
+VALU_CYCLES_PER_INSTR = 4.0                  # issue cost of a wave64 VALU instruction: 4.3-4.5 cycles for most of the epilogue's
+                                             # ops, 2.3-2.7 for add/and/shift/mov (profiles/r01_e_valu_issue_rates.txt)
+A160_BYTES_PER_FRAME = 160 * 160 * 3 + 20 * 20 * 18          # 84 000 B: algorithmic bytes of the 160x160 variant
+FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp32 logits out
+
+
+def kernel_source_hash():
+    """Identity of the running kernel build: sha256 over the device sources and build flags (works without git)."""
+    h = hashlib.sha256()
+    for f in ("yf_kernels.hip.h", "yf_engine.hip", "yf_decode.hip.h", "yf_tables.h", "Makefile"):
+        h.update(open(os.path.join(ROOT, "stm32h7-yolo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_counters(kernel_name):
+    """Counters of the fused kernel from the committed rocprofv3 PMC summary (profiles/pmc_current.json: separate --pmc passes,
+    tools/profile_pmc.sh).  They are only reported when that profile was taken on THIS build (same kernel name, same source
+    hash); otherwise null plus the reason -- a stale number is worse than none."""
+    p = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if not os.path.exists(p):
+        return None, "profiles/pmc_current.json is missing"
+    d = json.load(open(p))
+    if d.get("source_hash") != kernel_source_hash():
+        return None, f"profile {d.get('profile')} was taken on kernel sources {d.get('source_hash')}, this build is {kernel_source_hash()}"
+    if d.get("kernel") != kernel_name:
+        return None, f"profile is of {d.get('kernel')}, running {kernel_name}"
+    return d, None
 
 
 def cpu_baseline(x, got_heads):
@@ -52,13 +84,61 @@ def cpu_baseline(x, got_heads):
                 single_thread_images_per_s=round(one, 1)), mism
 
 
+def event_time_ms(stream, fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return float(e0.elapsed_time(e1)) / iters
+
+
+def secondary_configs(net, dev, stream):
+    """BASELINE configs[4] (160x160, batch 1024) and configs[3] (fp16, batch 4096), timed after the headline region with
+    HIP events on the launch stream.  Parity of both is the job of tests/test_gpu_parity.py; here only time."""
+    sp = stream.cuda_stream
+    out = {}
+    rng = np.random.default_rng(4)
+    n = 1024
+    d_in = torch.from_numpy(rng.integers(-128, 128, (n, 160, 160, 3), dtype=np.int8)).to(dev)
+    d_out = torch.zeros((n, 20, 20, 18), dtype=torch.int8, device=dev)
+    run = lambda: net.run_device_hw(160, 160, d_in.data_ptr(), d_out.data_ptr(), n, sp)      # noqa: E731
+    for _ in range(3):
+        run()
+    ms = event_time_ms(stream, run, 10)
+    gbs = n * A160_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+    out["int8_160x160"] = {"workload": "BASELINE configs[4]: batch=1024 int8 160x160x3 frames, one GPU", "ms_per_step": round(ms, 4),
+                           "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * A160_BYTES_PER_FRAME,
+                           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
+                           "kernel": net.kernel_name_160 if hasattr(net, "kernel_name_160") else "see DESIGN.md, 160x160 variant"}
+    del d_in, d_out
+    n = 4096
+    net.fp16_init()
+    d_in = torch.from_numpy((rng.integers(0, 256, (n, 56, 56, 3)).astype(np.float32) / 255).astype(np.float16)).to(dev)
+    d_out = torch.zeros((n, 7, 7, 18), dtype=torch.float32, device=dev)
+    run = lambda: net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n, sp)              # noqa: E731
+    for _ in range(3):
+        run()
+    ms = event_time_ms(stream, run, 10)
+    gbs = n * FP16_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+    out["fp16_56x56"] = {"workload": "BASELINE configs[3]: batch=4096 fp16 56x56x3 frames (weights of the reference's ONNX export), one GPU",
+                         "ms_per_step": round(ms, 4), "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * FP16_BYTES_PER_FRAME,
+                         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
+                         "dtype": "f16 (f32 accumulate)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400, help="timed steps (one step = one 4096-frame batch per GPU, ~0.23 ms)")
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (one step = one 4096-frame batch per GPU, ~0.2 ms)")
     ap.add_argument("--warmup", type=int, default=100, help="untimed steps; the first ~50 steps after idle run ~6%% slower (clock ramp)")
     ap.add_argument("--frames-per-wg", type=int, default=0)
     ap.add_argument("--waves-per-wg", type=int, default=0)
+    ap.add_argument("--det-cap", type=int, default=4, help="detection records kept (and exchanged) per frame; the count is always the true count")
+    ap.add_argument("--gather-heads", action="store_true", help="also all-gather the int8 heads (882 B per frame) at N > 1")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 160x160 and fp16 side configurations")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
@@ -86,19 +166,25 @@ def main():
     n, n_total = FRAMES_PER_GPU, FRAMES_PER_GPU * world
     a, b = sharding.shard_range(n_total, rank, world)
     assert b - a == n
-    x = np.random.default_rng([1, rank]).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
-    if rank == 0:       # golden frames inside the timed batch
-        x[:6] = np.fromfile(os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), np.int8).reshape(-1, 56, 56, 3)
-    d_in = torch.from_numpy(x).to(dev)
-    cap = 16
-    # Per-rank output record: [heads n x 882 B | detection records n x cap x 28 B | counts n x 4 B] in ONE buffer, so that
-    # the exchange at N > 1 is ONE all-gather per step.  Two such buffers alternate: the all-gather of step k runs on
-    # RCCL's stream while the kernel of step k+1 fills the other buffer (collective overlapped with compute).
-    off_d = (n * 882 + 15) & ~15
-    off_c = off_d + n * cap * 28
-    rec_bytes = (off_c + n * 4 + 15) & ~15
+    golden_in = np.fromfile(os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), np.int8).reshape(-1, 56, 56, 3)
+    xs = []
+    for k in range(N_INPUT_BATCHES):
+        xk = np.random.default_rng([1, rank, k]).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
+        if rank == 0 and k == 0:    # golden frames inside the timed batch
+            xk[:6] = golden_in
+        xs.append(xk)
+    d_ins = [torch.from_numpy(xk).to(dev) for xk in xs]
+    x = xs[0]
+    cap = args.det_cap
+    # Per-rank exchange record: [detection records n x cap x 28 B | counts n x 4 B (| heads n x 882 B)] in ONE buffer, so the
+    # exchange at N > 1 is ONE all-gather per step.  Two such buffers alternate: the all-gather of step k runs on RCCL's
+    # stream while the kernel of step k+1 fills the other buffer (collective overlapped with compute).
+    off_c = (n * cap * 28 + 15) & ~15
+    off_h = (off_c + n * 4 + 15) & ~15
+    rec_bytes = off_h + (((n * 882 + 15) & ~15) if args.gather_heads else 0)
     n_buf = 2 if world > 1 else 1
     local = [torch.zeros((rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+    heads_local = [local[i][off_h:off_h + n * 882] if args.gather_heads else torch.zeros((n * 882,), dtype=torch.uint8, device=dev) for i in range(n_buf)]
     gath = [torch.zeros((world * rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(n_buf)] if world > 1 else []
     pending = [None] * n_buf
     stream = torch.cuda.current_stream()
@@ -106,25 +192,25 @@ def main():
 
     def views(buf, r=0):
         base = buf[r * rec_bytes:(r + 1) * rec_bytes]
-        return (base[:n * 882].view(torch.int8).view(n, 7, 7, 18), base[off_d:off_c].view(n, cap, 28),
-                base[off_c:off_c + n * 4].view(torch.int32))
+        return base[:n * cap * 28].view(n, cap, 28), base[off_c:off_c + n * 4].view(torch.int32)
 
-    def launch(i):
+    def launch(i, k=0):
         p = local[i].data_ptr()
         # ONE launch per step: the fused network kernel also decodes the boxes of its frames (heads still in LDS)
-        net.run_decode_device(d_in.data_ptr(), p, n, p + off_d, p + off_c, cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
+        net.run_decode_device(d_ins[k].data_ptr(), heads_local[i].data_ptr(), n, p, p + off_c, cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
 
     step_no = 0
 
     def step():
         nonlocal step_no
         i = step_no % n_buf
+        k = step_no % N_INPUT_BATCHES
         step_no += 1
         if pending[i] is not None:          # the gather that last read this buffer must be done before it is overwritten
             pending[i].wait()
             pending[i] = None
-        launch(i)
-        if world > 1:       # every rank ends up with all heads and all detection records (RCCL over xGMI)
+        launch(i, k)
+        if world > 1:       # every rank ends up with every rank's detection records and counts (RCCL over xGMI)
             if args.backend == "nccl":
                 pending[i] = dist.all_gather_into_tensor(gath[i], local[i], async_op=True)
             else:           # rehearsal: the same exchange through host copies
@@ -148,7 +234,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_begin.record(stream)
-    for k in range(args.steps):
+    for _ in range(args.steps):
         step()
     drain()
     ev_end.record(stream)
@@ -161,67 +247,117 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(ev_begin.elapsed_time(ev_end)) / args.steps
-    last = (step_no - 1) % n_buf
     if world > 1:           # the timed region above also holds the collectives: time the kernel alone, same stream, same inputs
-        k_only = 100
-        ev_begin.record(stream)
-        for _ in range(k_only):
-            launch(last)
-        ev_end.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = float(ev_begin.elapsed_time(ev_end)) / k_only
+        kernel_ms = event_time_ms(stream, lambda: launch(0, 0), 100)
 
-    d_heads, d_dets, d_counts = views(local[last])
-    heads = d_heads.cpu().numpy()
+    # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames), then compare
+    step_no = 0
+    step()
+    drain()
+    torch.cuda.synchronize()
+    d_dets, d_counts = views(local[0])
+    heads = heads_local[0].view(torch.int8).view(n, 7, 7, 18).cpu().numpy()
+    dets = d_dets.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap)
+    counts = d_counts.cpu().numpy()
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    n_chk = n if world == 1 else 256            # at N > 1 every rank checks a slice of ITS shard (the full check is the N = 1 run's)
+    problems = []
+    ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if world > 1 else None
+    if world > 1 and not np.array_equal(heads[:n_chk], ref_heads):
+        problems.append(f"rank {rank}: heads differ from the oracle on its first {n_chk} frames")
+    for f in range(min(n_chk, 64)):             # decoded records of the first frames against the oracle's decode of the GPU heads
+        want = orc.decode_py(heads[f], f, 1.0, 1.0)
+        got = [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["q_conf"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in dets[f, :min(cap, counts[f])]]
+        if counts[f] != len(want) or got != [(w[1], w[2], w[3], w[4], w[6], w[7], w[8], w[9]) for w in want][:cap]:
+            problems.append(f"rank {rank}: detection records of frame {f} differ from the oracle's decode")
+            break
+    if rank == 0:                               # the golden frames' detections are committed (tests/golden/golden_meta.json)
+        meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_meta.json")))
+        for f, fr in enumerate(meta["frames"]):
+            want = [(g["anchor"], g["row"], g["col"], g["x1"], g["y1"], g["x2"], g["y2"]) for g in fr["detections_py"]]
+            got = [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in dets[f, :min(cap, counts[f])]]
+            if counts[f] != len(want) or got != want[:cap]:
+                problems.append(f"golden frame {f}: detections differ from tests/golden/golden_meta.json")
     ok_gather = True
-    if world > 1:   # every rank must hold every rank's record (heads, detections, counts), in rank = frame order
-        ok_gather = bool(torch.equal(gath[last][rank * rec_bytes:(rank + 1) * rec_bytes], local[last]))
-        g_heads = torch.cat([views(gath[last], r)[0] for r in range(world)])        # [n_total, 7, 7, 18]
-        ok_gather = ok_gather and tuple(g_heads.shape) == (n_total, 7, 7, 18) and bool(torch.equal(g_heads[a:b], d_heads))
-        flag = torch.tensor([int(ok_gather)], device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:   # every rank must hold every rank's records, in rank = frame order
+        ok_gather = bool(torch.equal(gath[0][rank * rec_bytes:(rank + 1) * rec_bytes], local[0]))
+        g_counts = torch.cat([views(gath[0], r)[1] for r in range(world)])           # [n_total]
+        ok_gather = ok_gather and tuple(g_counts.shape) == (n_total,) and bool(torch.equal(g_counts[a:b], d_counts))
+        g_frames = torch.cat([views(gath[0], r)[0] for r in range(world)])[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
+        first_rec = np.nonzero(torch.cat([views(gath[0], r)[1] for r in range(world)]).cpu().numpy() > 0)[0]
+        # record k of rank r carries its LOCAL frame index: the global order is rank-major
+        ok_gather = ok_gather and all(int(g_frames[i]) == int(i % n) for i in first_rec[:512])
+        flag = torch.tensor([int(ok_gather and not problems)], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok_gather = bool(flag.item())
+        all_ok = bool(flag.item())
+    else:
+        all_ok = not problems
 
+    fail = None
     if rank == 0:
         value = n_total * args.steps / elapsed
+        exch = (f" + RCCL all-gather of detection records (cap {cap}) and counts" + (" and heads" if args.gather_heads else "")) if world > 1 else ""
         line = {
             "metric": "images/sec int8 YOLO-face 56x56", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=4096 int8 YOLO-face 56x56x3 frames per GPU, fused LDS-resident "
-                                   "forward + GPU box decode" + (f" + RCCL all-gather of {n_total} heads and detection records" if world > 1 else ""),
+                                   "forward + GPU box decode" + exch,
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
-                       "kernel": net.kernel_name, "parallelism": f"batch-shard x{world}, all-gather heads" if world > 1 else "single GPU"},
+                       "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
+                       "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
+                       "parallelism": f"batch-shard x{world}, all-gather of detections" if world > 1 else "single GPU",
+                       "exchange_bytes_per_rank_per_step": rec_bytes if world > 1 else 0},
         }
         achieved = n * ALGO_BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # PMC passes are separate rocprofv3 runs (profiles/README.md)
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        prof, why = profile_counters(net.kernel_name)
         line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                            "traffic_source": (f"{prof['profile']} (kernel sources {prof['source_hash']})" if prof else why),
                             "kernel": net.kernel_name, "kernel_ms": round(kernel_ms, 4),
                             "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_FRAME}
         tops = n * DENSE_OPS_PER_FRAME / (kernel_ms * 1e-3) / 1e12
         line["roofline_mfma"] = {"bound": "mfma", "achieved": round(tops, 3), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                                  "frac": round(tops / MFMA_I8_PEAK_TOPS, 6)}
+        # The bound that binds in practice: VALU issue (requantisation epilogue, index arithmetic, pooling).  Instructions per
+        # launch come from the PMC profile of this build; peak = every SIMD issuing one wave64 VALU instruction per 4 cycles.
+        valu_peak = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INSTR
+        if prof and prof.get("SQ_INSTS_VALU"):
+            ips = prof["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
+            line["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ips / 1e9, 2), "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instr/s",
+                                     "frac": round(ips / valu_peak, 4), "valu_instructions_per_launch": prof["SQ_INSTS_VALU"],
+                                     "valu_instructions_per_frame": round(prof["SQ_INSTS_VALU"] / n, 1), "cycles_per_instruction_assumed": VALU_CYCLES_PER_INSTR,
+                                     "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
+        else:
+            line["roofline_valu"] = {"bound": "valu-issue", "achieved": None, "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instr/s", "frac": None, "source": why}
         if world == 1:
             cb, mism = cpu_baseline(x, heads)
             line["cpu_baseline"] = cb
-            line["parity"] = "bit-exact vs oracle on %d/%d frames" % (n - (mism > 0) * 1, n) if mism == 0 else f"MISMATCH: {mism} head bytes differ"
+            line["parity"] = ("bit-exact vs oracle on %d/%d frames; decoded boxes of the golden frames equal tests/golden" % (n, n)) if mism == 0 and not problems \
+                else f"MISMATCH: {mism} head bytes differ; {problems}"
             # PCIe-inclusive rate through the reference ABI (host buffers): reported, never `value`
             t1 = time.perf_counter()
             net.run(x)
             line["pcie_inclusive_images_per_s"] = round(n / (time.perf_counter() - t1), 1)
-            if mism:
-                print(json.dumps(line))
-                raise SystemExit("GPU result differs from the oracle")
+            if mism or problems:
+                fail = f"GPU result differs from the oracle ({mism} head bytes; {problems})"
+            elif not args.no_secondary:
+                line["secondary"] = secondary_configs(net, dev, stream)
         else:
             line["all_gather_ok"] = ok_gather
-        print(json.dumps(line))
+            line["parity"] = "every rank: heads of its first 256 frames and decoded records of its first 64 frames equal the oracle; golden detections equal tests/golden" \
+                if all_ok else f"FAILED on at least one rank (rank 0: {problems})"
+            if not all_ok:
+                fail = "all-gather or per-rank parity check failed"
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if not all_ok:
+            raise SystemExit(fail or f"rank {rank}: check failed: {problems}")
+    if fail:
+        raise SystemExit(fail)
 
 
 if __name__ == "__main__":

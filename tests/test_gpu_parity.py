@@ -484,3 +484,24 @@ def test_reference_yoloface_c_links_unchanged_and_runs_on_the_gpu(yf, network, o
     text = b"".join(binding.format_uart(k + 1, buf[k, :min(int(counts[k]), cap)], int(counts[k])) for k in range(n))
     assert r.stdout == text, "UART text of the reference application vs yf_network_format_uart over the GPU records"
     assert int(counts.sum()) > 0, "no frame produced a detection: the text comparison would be vacuous"
+
+
+def test_bench_two_ranks_exchange_detections(tmp_path):
+    """The N > 1 path of bench.py end to end on ONE GPU: two fresh processes (torch.distributed.run, backend gloo: the
+    collective goes through host copies, everything else -- sharding, double-buffered record exchange, per-rank parity
+    check, rank-major record order -- is the code the 8-GPU run executes with RCCL).  The exchange is detections only:
+    fixed-capacity records + counts, <= 0.6 MB per rank per step at 4096 frames."""
+    import json
+    import sys
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["all_gather_ok"] is True and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 8192 and line["parity"].startswith("every rank")
+    assert 0 < line["config"]["exchange_bytes_per_rank_per_step"] <= 600_000

@@ -7,8 +7,8 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-TRACE_ARGS="$*"                       # kernel trace: the default bench command (400 steps after 100 warm-up)
-ARGS="--steps 20 --warmup 5 $*"        # counter passes: per-launch counts do not depend on the clock state
+TRACE_ARGS="--no-secondary $*"        # kernel trace: the default bench command (400 steps after 100 warm-up), headline kernel only
+ARGS="--steps 20 --warmup 5 --no-secondary $*"   # counter passes: per-launch counts do not depend on the clock state
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $TRACE_ARGS > $OUT/bench_line.json 2> $OUT/trace.err
 i=0
 for grp in \

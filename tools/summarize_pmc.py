@@ -37,6 +37,22 @@ def main():
         res["hbm"] = {"fetch_bytes_raw": fetch_kb * 1024, "write_bytes": write_kb * 1024,
                       "note": "FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x "
                               "(MI355X_MICROARCH.md, HBM) -- see profiles/README.md for the calibration used"}
+    # what bench.py reports as roofline.traffic / roofline_valu: stamped with the build the profile was taken on, so that
+    # bench.py can refuse the numbers once the kernel sources change (bench.py: profile_counters)
+    try:
+        bl = json.loads(open(os.path.join(out, "bench_line.json")).read().strip().splitlines()[-1])
+        cur = {"profile": os.path.basename(os.path.normpath(out)), "kernel": bl["config"]["kernel"], "source_hash": bl["config"]["kernel_source_hash"],
+               "kernel_trace_avg_ns": res.get("trace", {}).get("avg_ns"), "bench_kernel_ms": bl["roofline"]["kernel_ms"]}
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            if k in c:
+                cur[k] = round(c[k]["per_launch"])
+        if "hbm" in res:
+            cur["fetch_bytes_raw"] = res["hbm"]["fetch_bytes_raw"]
+            cur["write_bytes"] = res["hbm"]["write_bytes"]
+            cur["hbm_bytes_per_launch"] = round(2 * res["hbm"]["fetch_bytes_raw"] + res["hbm"]["write_bytes"])   # gfx950: FETCH_SIZE counts half of a streaming read
+        json.dump(cur, open(os.path.join(out, "pmc_current.json"), "w"), indent=1)
+    except Exception as e:      # noqa: BLE001
+        print("pmc_current.json not written:", e)
     json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
     print(json.dumps(res, indent=1)[:3000])
 
