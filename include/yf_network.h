@@ -240,6 +240,16 @@ YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, vo
  * min(count, cap) records, the total line carries count like the firmware's face_num).  Returns the number of
  * bytes the text needs (excluding the terminating NUL); at most buflen - 1 bytes are stored.  Host-only, no GPU. */
 YF_API long yf_network_format_uart(unsigned frame_no, const yf_det* dets, int count, int cap, char* buf, size_t buflen);
+/* Multi-GPU: one process per GPU, each with its own network instance on its device
+ * (yf_network_set_device(local_rank) before ai_network_init).  Frames are independent: rank r of `world` runs the contiguous
+ * slice [*begin, *end) of an n-frame batch (the first n % world ranks take one frame more) ... */
+YF_API void yf_network_shard_range(long n, int rank, int world, long* begin, long* end);
+/* ... and the only exchange is an all-gather of per-frame results (detection records + counts, optionally heads): every
+ * rank contributes `bytes_per_rank` device bytes at d_send and receives world * bytes_per_rank at d_recv, in rank = frame
+ * order.  nccl_comm is the host application's ncclComm_t (RCCL; the library resolves ncclAllGather from librccl.so at
+ * the first call and links nothing at build time).  Asynchronous on `stream`.  Returns bytes_per_rank or <= 0. */
+YF_API long yf_network_all_gather_device(ai_handle network, void* nccl_comm, const void* d_send, void* d_recv,
+                                         size_t bytes_per_rank, void* stream);
 /* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
 /* `iters` back-to-back launches of the fused kernel on `stream`, bracketed by HIP events on that stream;

@@ -8,6 +8,7 @@ The library has no CPU compute path: without a gfx950 GPU `init()` raises.
 import ctypes
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -85,7 +86,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_format_uart", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
+           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
@@ -155,6 +156,10 @@ def load():
     lib.yf_network_run_decode_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
     lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_shard_range.restype = None
+    lib.yf_network_shard_range.argtypes = [cl, ctypes.c_int, ctypes.c_int, ctypes.POINTER(cl), ctypes.POINTER(cl)]
+    lib.yf_network_all_gather_device.restype = cl
+    lib.yf_network_all_gather_device.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.yf_network_format_uart.restype = cl
     lib.yf_network_format_uart.argtypes = [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.yf_network_time_device.restype = cl
@@ -195,11 +200,19 @@ def make_buffer(fmt, h, w, ch, n_batches=1, data=None):
     return AiBuffer(fmt, n_batches, h, w, ch, data, None)
 
 
+_live_owner = None      # weakref to the Network object that currently owns the library's single context
+
+
 class Network:
-    """The one network instance of the library (the reference has a static singleton too, network.c:2929)."""
+    """The one network instance of the library (the reference has a static singleton too, network.c:2929).
+    ai_network_create re-creates that singleton, so constructing a second Network (or an Interpreter) SUPERSEDES the first:
+    the older object is marked dead and its calls raise instead of failing later with a puzzling INVALID_STATE."""
 
     def __init__(self, device=0, frames_per_wg=0, waves_per_wg=0):
+        global _live_owner
         self.lib = load()
+        self._device, self._cfg = device, (frames_per_wg, waves_per_wg)
+        self._take_ownership()
         self.handle = ctypes.c_void_p()
         err = self.lib.ai_network_create(ctypes.byref(self.handle), None)          # yoloface.c:192
         if err.type != 0:
@@ -210,7 +223,31 @@ class Network:
         self._activations = (ctypes.c_uint8 * ACTIVATIONS_BYTES)()                 # yoloface.c:180-181
         self.ready = False
 
+    def _take_ownership(self):
+        global _live_owner
+        prev = _live_owner() if _live_owner is not None else None
+        if prev is not None and prev is not self:
+            prev.ready, prev.superseded, prev.handle = False, True, ctypes.c_void_p()    # NULL handle: every call fails, _raise says why
+        _live_owner = weakref.ref(self)
+        self.superseded = False
+
+    def reclaim(self):
+        """Make THIS object the owner of the library's single instance again (ai_network_create anew); call init() next."""
+        self._take_ownership()
+        self.handle = ctypes.c_void_p()
+        err = self.lib.ai_network_create(ctypes.byref(self.handle), None)
+        if err.type != 0:
+            raise NetworkError("ai_network_create", err.type, err.code)
+        self.lib.yf_network_set_device(self.handle, self._device)
+        if any(self._cfg):
+            self.lib.yf_network_configure(self.handle, *self._cfg)
+        self.ready = False
+        return self
+
     def _raise(self, what):
+        if self.superseded:
+            raise NetworkError(what + ": this Network object was superseded by a newer Network/Interpreter (the library has ONE "
+                               "network instance, like the reference: network.c:2929)", 0x11, 0x14)
         err = self.lib.ai_network_get_error(self.handle)
         text = (self.lib.yf_network_last_error_text(self.handle) or b"").decode()
         raise NetworkError(what, err.type, err.code, text)

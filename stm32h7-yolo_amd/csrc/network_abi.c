@@ -14,6 +14,7 @@
 #include "yf_host_prep.h"
 #include "yf_impl.h"
 #include "yf_fp16.h"
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -266,10 +267,14 @@ YF_API int yf_network_set_device(ai_handle network, int device) {
 YF_API int yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg) {
   yf_context* c = acquire(network);
   if (!c) return -1;
-  c->cfg_frames = frames_per_wg; c->cfg_waves = waves_per_wg;
-  if (c->state == ST_READY && yf_engine_configure(c->engine, frames_per_wg, waves_per_wg) != YF_ENG_OK) {
+  /* validate first: a rejected shape must not poison the stored configuration (every later ai_network_init would fail) */
+  const int f = frames_per_wg > 0 ? frames_per_wg : (c->cfg_frames > 0 ? c->cfg_frames : 2);
+  const int w = waves_per_wg > 0 ? waves_per_wg : (c->cfg_waves > 0 ? c->cfg_waves : 8);
+  if (!yf_engine_variant_exists(f, w)) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_NETWORK_PARAMS, "no such kernel variant"); return -1; }
+  if (c->state == ST_READY && yf_engine_configure(c->engine, f, w) != YF_ENG_OK) {
     latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_NETWORK_PARAMS, yf_engine_error(c->engine)); return -1;
   }
+  c->cfg_frames = f; c->cfg_waves = w;
   return 0;
 }
 
@@ -308,6 +313,38 @@ YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, c
   if (height == 160 && width == 160) return finish(c, yf_engine_run_device_160(c->engine, d_in, d_out, n, stream), n);
   latch(c, AI_ERROR_INVALID_INPUT, AI_ERROR_CODE_INVALID_SIZE, "supported input sizes: 56x56 (fused) and 160x160 (layer-by-layer)");
   return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ multi-GPU */
+YF_API void yf_network_shard_range(long n, int rank, int world, long* begin, long* end) {
+  if (world < 1) world = 1;
+  if (rank < 0) rank = 0;
+  const long base = n / world, extra = n % world;
+  const long b = rank * base + (rank < extra ? rank : extra);
+  if (begin) *begin = b;
+  if (end) *end = b + base + (rank < extra ? 1 : 0);
+}
+
+/* ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream) out of librccl.so, resolved on first use */
+typedef int (*yf_nccl_all_gather_fn)(const void*, void*, size_t, int, void*, void*);
+YF_API long yf_network_all_gather_device(ai_handle network, void* nccl_comm, const void* d_send, void* d_recv,
+                                         size_t bytes_per_rank, void* stream) {
+  yf_context* c = acquire(network);
+  if (!c) return 0;
+  if (!nccl_comm || !d_send || !d_recv || bytes_per_rank == 0) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_INVALID_PTR, "all-gather: NULL communicator/buffer or zero size"); return 0; }
+  static yf_nccl_all_gather_fn fn;
+  if (!fn) {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h) fn = (yf_nccl_all_gather_fn)dlsym(h, "ncclAllGather");
+    if (!fn) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, "all-gather: librccl.so / ncclAllGather not found"); return 0; }
+  }
+  const int rc = fn(d_send, d_recv, bytes_per_rank, 0 /* ncclInt8 */, nccl_comm, stream);
+  if (rc != 0) {
+    char t[96]; snprintf(t, sizeof t, "ncclAllGather failed with ncclResult_t %d", rc);
+    latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, t); return 0;
+  }
+  return (long)bytes_per_rank;
 }
 
 /* stm32/User/main.c:46,53 + yoloface.c:148: the text the firmware prints per frame, byte for byte. */

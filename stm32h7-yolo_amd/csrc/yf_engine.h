@@ -15,6 +15,8 @@ enum { YF_ENG_OK = 0, YF_ENG_ERR_HIP = -1, YF_ENG_ERR_ARG = -2, YF_ENG_ERR_NO_DE
 
 int  yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen);
 void yf_engine_destroy(yf_engine* e);
+/* 1 if a production kernel of that shape is compiled in (frames_per_wg may carry the +200 experimental-build tag) */
+int  yf_engine_variant_exists(int frames_per_wg, int waves_per_wg);
 int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);
 const char* yf_engine_error(const yf_engine* e);
 const char* yf_engine_kernel_name(const yf_engine* e);

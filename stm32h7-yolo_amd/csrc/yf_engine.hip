@@ -189,6 +189,11 @@ void yf_engine_destroy(yf_engine* e) {
   delete e;
 }
 
+int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) {
+  const bool exp = frames_per_wg >= 200;
+  return find_variant(exp ? frames_per_wg - 200 : frames_per_wg, waves_per_wg, false, exp) != nullptr;
+}
+
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
   /* frames_per_wg + 200 selects the experimental (YF_EXP) build of the same shape */

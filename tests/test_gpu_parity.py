@@ -411,7 +411,9 @@ def test_interpreter_mirror(oracle, golden, network):
     boxes = ip.decode_boxes(out[0], 0.7, 1.0, 1.0)
     want = golden["meta"]["frames"][5]["detections_py"]
     assert [tuple(int(v) for v in b) for b in boxes] == [(d["x1"], d["y1"], d["x2"], d["y2"]) for d in want]
-    network.init()            # the mirror re-initialised the singleton; leave it ready for later tests
+    with pytest.raises(Exception, match="superseded"):       # the mirror owns the library's single instance now
+        network.run_device(0, 0, 1)
+    network.reclaim().init()  # hand the singleton back to the session fixture for the later tests
 
 
 @pytest.mark.parametrize("binary", ["abi_ref_caller", "abi_ref_runtime_caller"])
@@ -505,3 +507,33 @@ def test_bench_two_ranks_exchange_detections(tmp_path):
     assert line["n_gpus"] == 2 and line["all_gather_ok"] is True and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 8192 and line["parity"].startswith("every rank")
     assert 0 < line["config"]["exchange_bytes_per_rank_per_step"] <= 600_000
+
+
+def test_c_level_all_gather_through_rccl(network, torch_cuda):
+    """yf_network_all_gather_device: the exchange step a C host application calls (one process per GPU, its own ncclComm_t).
+    With one GPU on the box the communicator has one rank; the call still goes through librccl's ncclAllGather on the
+    caller's stream.  Bad arguments are latched like every other entry point."""
+    import ctypes
+    torch = torch_cuda
+    try:
+        rccl = ctypes.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not loadable")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    n = 4096 * (4 * 28 + 4)
+    send = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+    recv = torch.zeros_like(send)
+    lib = network.lib
+    assert lib.yf_network_all_gather_device(network.handle, comm, send.data_ptr(), recv.data_ptr(), n, None) == n
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    assert lib.yf_network_all_gather_device(network.handle, None, send.data_ptr(), recv.data_ptr(), n, None) == 0
+    assert network.get_error()[0] == 0x14                                   # AI_ERROR_INVALID_PARAM, latched once
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -56,3 +56,16 @@ def test_two_rank_gloo_all_gather_reproduces_full_batch(n, oracle):
         assert p.exitcode == 0
     x = np.random.default_rng(123).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
     assert np.array_equal(got, oracle.run(x))
+
+
+def test_c_shard_range_equals_the_python_one(yf):
+    """yf_network_shard_range is what a C host application uses (multi-GPU); same split as sharding.py."""
+    import ctypes
+    lib = yf.load()
+    sh = importlib.import_module("stm32h7-yolo_amd.sharding")
+    for n in (0, 1, 7, 8, 4096, 32768, 32771):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                a, b = ctypes.c_long(), ctypes.c_long()
+                lib.yf_network_shard_range(n, r, world, ctypes.byref(a), ctypes.byref(b))
+                assert (a.value, b.value) == sh.shard_range(n, r, world)
