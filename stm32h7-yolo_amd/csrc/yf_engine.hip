@@ -106,7 +106,7 @@ struct yf_engine {
   const Variant* var = nullptr;
   const Variant* var_dump = nullptr;
   void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
-  char* arena160 = nullptr; long arena160_frames = 0;
+  char* arena160 = nullptr; long arena160_frames = 0; bool layerwise160 = false;
   hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -130,6 +130,26 @@ static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned gr
   } else {
     return YF_ENG_OK;
   }
+}
+
+// 160x160, banded form: four kernels, each fusing a group of stages over row bands staged through LDS
+struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; int wgs_per_cu; };
+static BandKernel k_band[4] = {
+  {(const void*)yf160::band::band_k1<8>,  "band_k1", 512,  (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
+  {(const void*)yf160::band::band_k2<8>,  "band_k2", 512,  (size_t)yf160::band::K2_LDS, yf160::band::K2_BANDS, 1},
+  {(const void*)yf160::band::band_k3<8>,  "band_k3", 512,  (size_t)yf160::band::K3_LDS, yf160::band::K3_BANDS, 1},
+  {(const void*)yf160::band::band_k4<16>, "band_k4", 1024, (size_t)yf160::band::K4_LDS, 1, 1},
+};
+static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
+  for (const BandKernel& k : k_band) {
+    const long jobs = prm.n * k.jobs_per_frame;
+    const long full = (long)e->cus * k.wgs_per_cu;           // persistent grid: every workgroup resident, jobs grid-strided
+    const unsigned grid = (unsigned)(jobs < full ? jobs : full);
+    void* args[] = {(void*)&prm};
+    const hipError_t rc = hipLaunchKernel(k.fn, dim3(grid), dim3(k.threads), args, k.lds, s);
+    if (rc != hipSuccess) { e->err = std::string(k.name) + " launch: " + hipGetErrorString(rc); return YF_ENG_ERR_HIP; }
+  }
+  return YF_ENG_OK;
 }
 
 extern "C" {
@@ -168,6 +188,17 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     if ((rc = hipFuncGetAttributes(&at, (const void*)yf160::generic_stage_kernel<1, 8>)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
     if (at.sharedSizeBytes != 0) { delete e; return fail("generic stage kernel has static LDS", YF_ENG_ERR_HIP); }
   }
+  for (BandKernel& k : k_band) {
+    hipFuncAttributes at;
+    if ((rc = hipFuncGetAttributes(&at, k.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
+    if (at.sharedSizeBytes != 0) { delete e; return fail(std::string(k.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP); }
+    if ((rc = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds)) != hipSuccess)
+      return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
+    int occ = 0;
+    if ((rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, (int)k.threads, k.lds)) != hipSuccess) return bail(rc, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    k.wgs_per_cu = occ > 0 ? occ : 1;
+  }
+  { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // A/B and debugging only
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
   e->var = find_variant(2, 8, false);
@@ -291,20 +322,30 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
   if (n == 0) return YF_ENG_OK;
   if (((uintptr_t)d_in & 3) != 0 || ((uintptr_t)d_out & 1) != 0) { e->err = "input must be 4-byte, output 2-byte aligned"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
-  const long cap = n < 1024 ? n : 1024;                       // frames per chunk (~0.86 MB of arena each)
+  const long cap = n < 1024 ? n : 1024;                       // frames per chunk of the HBM arena
+  const size_t per_frame = e->layerwise160 ? (size_t)yf160::FRAME_BYTES : (size_t)yf160::band::ARENA_BYTES;
   if (cap > e->arena160_frames) {
     if (e->arena160) (void)hipFree(e->arena160);
     e->arena160 = nullptr; e->arena160_frames = 0;
-    HIPCHK(e, hipMalloc((void**)&e->arena160, (size_t)cap * yf160::FRAME_BYTES));
+    HIPCHK(e, hipMalloc((void**)&e->arena160, (size_t)cap * per_frame));
     e->arena160_frames = cap;
   }
   for (long done = 0; done < n; done += cap) {
     const long m = (n - done) < cap ? (n - done) : cap;
-    yf160::GenParams prm;
-    prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
-    prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
-    prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
-    const int rc = launch160_from<0>(e, prm, (unsigned)m, (hipStream_t)stream);
+    int rc;
+    if (e->layerwise160) {
+      yf160::GenParams prm;
+      prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
+      prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
+      prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
+      rc = launch160_from<0>(e, prm, (unsigned)m, (hipStream_t)stream);
+    } else {
+      yf160::band::Params prm;
+      prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
+      prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
+      prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
+      rc = launch160_banded(e, prm, (hipStream_t)stream);
+    }
     if (rc) return rc;
   }
   return YF_ENG_OK;

@@ -500,9 +500,9 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
 // ------------------------------------------------------------------------------------------------ conv2d_1
 // 3x3 stride 2, Cin 3 -> 8 on RGBX dwords, lane-private like the 1x1 stages: the lane's pixel gathers its nine taps
 // (nine aligned dwords of the staged frame) into three k-steps, both 4-channel passes share them.
-template <int F, int NW>
+template <int F, int NW, class IN = B_IN, class OUT = B_T1>
 YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, const yf_dense d, int wave, int lane, int vz) {
-  constexpr int P = B_T1::P, W1 = B_T1::W, RSW = B_IN::RS, TOT = F * P;
+  constexpr int P = OUT::P, W1 = OUT::W, RSW = IN::RS, TOT = F * P;
   constexpr int MT = (TOT + 63) / 64;
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
@@ -528,7 +528,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, cons
     const int oy = p / W1, ox = p - oy * W1;
     char* fbase = frames + f * FRAME_BYTES;
     // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + B_IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
     const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
     const v4i b1 = {(int)src[RSW + 1], (int)src[RSW + 2], (int)src[2 * RSW], (int)src[2 * RSW + 1]};
     const v4i b2 = {(int)src[2 * RSW + 2], any_value(), any_value(), any_value()};
@@ -541,7 +541,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, cons
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
       int idx[4];                           // no exec mask (surplus lanes redo pixel TOT-1)
       requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
-      epilogue_store<EPI_LUT, YF_L_LEAKY2, B_T1, 0, B_T1>(fbase, nullptr, f, p, 4 * ps, idx, ad);
+      epilogue_store<EPI_LUT, YF_L_LEAKY2, OUT, 0, OUT>(fbase, nullptr, f, p, 4 * ps, idx, ad);
     }
   }
 }
@@ -1058,6 +1058,339 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------ banded form
+// Second form for sizes that do not fit in LDS (160x160): FOUR kernels, each fusing a group of stages over a BAND of rows of
+// one frame.  A workgroup copies the band of its input tensor (with the halo rows the group needs) from the per-frame HBM
+// arena into LDS with coalesced loads, runs the SAME stage functions as the 56x56 kernel on band-local buffers, and writes
+// the band of its output tensor back.  Only five tensors cross HBM (T4, the pooled half of concat_22, T7, T8, T15):
+// ~0.78 MB per frame instead of 1.7 MB, all of it in full-row transfers.
+//   K1  input rows -> conv2d_1 -> conv2d_3 (dw) -> conv2d_5 -> conv2d_6 -> T4            band = 8 rows of the 80x80 grid
+//   K2  T4 -> pool_8 (+QUANTIZE) -> P8 ; conv2d_10 (dw) -> conv2d_12 -> T7 -> conv2d_13 -> T8     band = 4 rows of 40x40
+//   K3  T8 -> conv2d_15 (dw) -> conv2d_17 + add(T7) -> conv2d_19 | P8 -> conv2d_23 -> T15         band = 8 rows of 40x40
+//   K4  T15 -> pool_25, conv2d_27 (dw) ... conv2d_53 -> head                                       whole 20x20 grid
+// Halo rules: a band's input copy spans whole halo'd rows of the global tensor, so image borders bring their zero-point
+// halo with them and interior band edges bring real neighbour rows; the producer fills halo columns (and the first / last
+// band the top / bottom halo row) before the copy-out.
+namespace band {
+constexpr int LB = LUT_BYTES;                                   // LUTs at LDS offset 0 (absolute addressing)
+// per-frame HBM arena of the banded form (bytes)
+constexpr int T4_ROW = (G1 + 1) * 20, T8_ROW = (G2 + 2) * 36, T15_ROW = (G2 + 1) * 24;
+constexpr int A_T4 = 0;                                          // [G1 + 1 halo'd rows][G1 + 1][20]   top/left halo
+constexpr int A_P8 = (A_T4 + (G1 + 1) * T4_ROW + 63) & ~63;      // [G2][G2][20]                       pool_8 + QUANTIZE#21
+constexpr int A_T7 = (A_P8 + G2 * G2 * 20 + 63) & ~63;           // [G2][G2][8]
+constexpr int A_T8 = (A_T7 + G2 * G2 * 8 + 63) & ~63;            // [G2 + 2][G2 + 2][36]               halo ring
+constexpr int A_T15 = (A_T8 + (G2 + 2) * T8_ROW + 63) & ~63;     // [G2 + 1][G2 + 1][24]               top/left halo
+constexpr int ARENA_BYTES = (A_T15 + (G2 + 1) * T15_ROW + 63) & ~63;
+
+struct Params { const int8_t* in; int8_t* out; long n; const uint8_t* tab; char* arena; };
+
+template <int NT>
+__device__ __forceinline__ void copy_dwords(char* dst, const char* src, int bytes, int tid) {       // both 4-byte aligned
+  for (int i = tid; i < bytes / 4; i += NT) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+}
+template <int NT>
+__device__ __forceinline__ void fill_dwords(char* dst, uint32_t v, int bytes, int tid) {
+  for (int i = tid; i < bytes / 4; i += NT) reinterpret_cast<uint32_t*>(dst)[i] = v;
+}
+// column `col` (pixel units) of `rows` rows of a buffer with ROW bytes per row and S bytes per pixel <- v
+template <int NT, int ROW, int S>
+__device__ __forceinline__ void fill_column(char* base, int col, int rows, uint32_t v, int tid) {
+  constexpr int DW = S / 4;
+  for (int i = tid; i < rows * DW; i += NT) {
+    const int r = i / DW, d = i - r * DW;
+    *reinterpret_cast<uint32_t*>(base + r * ROW + col * S + 4 * d) = v;
+  }
+}
+__device__ __forceinline__ uint32_t splat(int zp) { return (uint32_t)(zp & 255) * 0x01010101u; }
+
+template <int NT>
+__device__ __forceinline__ void load_luts(uint8_t* luts, const uint8_t* __restrict__ tab, int tid) {
+  for (int i = tid; i < LUT_BYTES / 16; i += NT)
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------------------------------
+constexpr int K1_BH = 8, K1_BANDS = G1 / K1_BH, K1_NIN = 2 * K1_BH + 5, K1_NT1 = K1_BH + 2;
+static_assert(G1 % K1_BH == 0, "band height must divide the grid");
+typedef Buf<LB,                                  G0, K1_NIN - 1, 4, G0 + 4, 1, 4> L1_IN;    // RGBX rows: local row l = global halo'd row 2(a-1)+l
+typedef Buf<L1_IN::OFF + K1_NIN * (G0 + 4) * 4,  G1, K1_NT1,     8, G1 + 2, 0, 1> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
+typedef Buf<L1_T1::OFF + K1_NT1 * (G1 + 2) * 8,  G1, K1_BH,      8, G1,     0, 0> L1_T2;
+typedef Buf<L1_T2::OFF + K1_BH * G1 * 8,         G1, K1_BH,      4, G1,     0, 0> L1_T3;
+typedef Buf<L1_T3::OFF + K1_BH * G1 * 4,         G1, K1_BH,     20, G1 + 1, 0, 1> L1_T4;    // left halo column
+constexpr int K1_LDS = L1_T4::OFF + K1_BH * T4_ROW;
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k1(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  const int zp_in = (int)uniform_u32(tab + offsetof(yf_table_index, in_zp));
+  const uint32_t z_in = splat(zp_in), z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
+  for (long job = blockIdx.x; job < prm.n * K1_BANDS; job += gridDim.x) {
+    const long fr = job / K1_BANDS;
+    const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
+    char* frames = smem;                                          // band-local buffers live at their LDS offsets
+    char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    __syncthreads();                                              // previous band's buffers are dead
+    {   // input rows -> RGBX with halo column; local row l <-> input row 2(a-1)+l-1, out of range = zero point
+      constexpr int RSW = G0 + 4, WQ = G0 / 4;
+      const int8_t* in = prm.in + fr * (long)IN_FRAME_BYTES;
+      for (int i = tid; i < K1_NIN * (WQ + 1); i += NT) {
+        const int l = i / (WQ + 1), xq = i - l * (WQ + 1);
+        const int r = 2 * (a - 1) + l - 1;
+        char* row = frames + L1_IN::OFF + l * RSW * 4;
+        if (xq == WQ) { *reinterpret_cast<uint32_t*>(row + 12) = z_in; continue; }           // halo column (dword 3)
+        uint4 px = {z_in, z_in, z_in, z_in};
+        if (r >= 0 && r < G0) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (long)r * (G0 * 3) + xq * 12);
+          const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+          px.x = d0; px.y = funnel(d1, d0, 24); px.z = funnel(d2, d1, 16); px.w = d2 >> 8;
+        }
+        *reinterpret_cast<uint4*>(row + 16 + 16 * xq) = px;
+      }
+    }
+    __syncthreads();
+    conv1_stage<F, NW, L1_IN, L1_T1>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
+    fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
+    fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
+    __syncthreads();
+    if (a == 0) fill_dwords<NT>(frames + L1_T1::OFF, z_t1, (G1 + 2) * 8, tid);                               // T1 row -1 = halo
+    if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * (G1 + 2) * 8, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
+    if (a == 0 || a + K1_BH == G1) __syncthreads();
+    dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3>(frames, nullptr, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4>(frames, nullptr, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
+    fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
+    __syncthreads();
+    copy_dwords<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);             // halo'd rows a+1 ..
+    if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
+  }
+}
+
+// ---- K2 ----------------------------------------------------------------------------------------------------------------
+constexpr int K2_BP = 4, K2_BANDS = G2 / K2_BP, K2_NR = 2 * K2_BP + 6;
+static_assert(G2 % K2_BP == 0, "band height must divide the grid");
+typedef Buf<LB,                                G1, K2_NR, 20, G1 + 1, 0, 1> L2_T4;      // local row l = T4 row 2p-3+l (global halo'd row 2p-2+l)
+typedef Buf<LB + 2 * T4_ROW,                   G1, K2_NR, 20, G1 + 1, 0, 1> L2_T4_DW;   // the same rows as conv2d_10 addresses them: halo'd row 2p = local 2
+typedef Buf<L2_T4::OFF + K2_NR * T4_ROW,       G2, K2_NR, 20, G2,     0, 0> L2_HB;
+typedef Buf<L2_HB::OFF + K2_NR * G2 * 20,      G2, K2_BP, 20, G2,     0, 0> L2_P8;
+typedef Buf<L2_P8::OFF + K2_BP * G2 * 20,      G2, K2_BP, 32, G2,     0, 0> L2_T6;
+typedef Buf<L2_T6::OFF + K2_BP * G2 * 32,      G2, K2_BP,  8, G2,     0, 0> L2_T7;
+typedef Buf<L2_T7::OFF + K2_BP * G2 * 8,       G2, K2_BP, 36, G2 + 2, 0, 1> L2_T8;
+constexpr int K2_LDS = L2_T8::OFF + K2_BP * T8_ROW;
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15));
+  for (long job = blockIdx.x; job < prm.n * K2_BANDS; job += gridDim.x) {
+    const long fr = job / K2_BANDS;
+    const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;             // first 40x40 row of the band
+    char* frames = smem;
+    char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    __syncthreads();
+    {   // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
+      const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K2_NR, G1 + 1);
+      copy_dwords<NT>(frames + L2_T4::OFF + (lo - h0) * T4_ROW, arena + A_T4 + lo * T4_ROW, (hi - lo) * T4_ROW, tid);
+    }
+    __syncthreads();
+    {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
+      constexpr int NO = 5, NCH = G2 / NO;
+      static_assert(G2 % NO == 0, "sweeps of 5 outputs");
+      for (int i = tid; i < K2_NR * NCH * 5; i += NT) {
+        const int cg = i % 5; int t = i / 5;
+        const int k = t % NCH; const int l = t / NCH;
+        const char* row = frames + L2_T4::OFF + l * T4_ROW + 20 + 4 * cg;                 // pixel 0 sits behind the halo column
+        char* dst = frames + L2_HB::OFF + l * (G2 * 20) + 4 * cg;
+        pool8_sweep<NO, G1 - 1>(k * NO, [&](int x) { return lds_u32(row + x * 20); },
+                                [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
+      }
+    }
+    __syncthreads();
+    {   // vertical pass: output rows p0 .. p0+3 need T4 rows 2p0-3 .. 2p0+10 clamped to the image = the 14 band rows
+      for (int i = tid; i < G2 * 5; i += NT) {
+        const int cg = i % 5, ox = i / 5;
+        const char* col = frames + L2_HB::OFF + ox * 20 + 4 * cg;
+        char* dst = frames + L2_P8::OFF + ox * 20 + 4 * cg;
+        pool8_sweep<K2_BP, G1 - 1>(p0, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
+                                   [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 20)) = lut4_raw<YF_L_Q21>(v); });
+      }
+    }
+    dw_mfma_stage<F, NW, 2, L2_T4_DW, L2_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 2, 16, L2_T6, L2_T7, 0, 6, EPI_RAW, 0, L2_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 3, 1, 8, L2_T7, L2_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L2_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
+    fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, 0, K2_BP, z_t8, tid);
+    fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, G2 + 1, K2_BP, z_t8, tid);
+    __syncthreads();
+    copy_dwords<NT>(arena + A_P8 + p0 * (G2 * 20), frames + L2_P8::OFF, K2_BP * G2 * 20, tid);
+    copy_dwords<NT>(arena + A_T7 + p0 * (G2 * 8), frames + L2_T7::OFF, K2_BP * G2 * 8, tid);
+    copy_dwords<NT>(arena + A_T8 + (p0 + 1) * T8_ROW, frames + L2_T8::OFF, K2_BP * T8_ROW, tid);             // halo'd rows p0+1 ..
+    if (p0 == 0) fill_dwords<NT>(arena + A_T8, z_t8, T8_ROW, tid);
+    if (p0 + K2_BP == G2) fill_dwords<NT>(arena + A_T8 + (G2 + 1) * T8_ROW, z_t8, T8_ROW, tid);
+  }
+}
+
+// ---- K3 ----------------------------------------------------------------------------------------------------------------
+constexpr int K3_BP = 8, K3_BANDS = G2 / K3_BP;
+static_assert(G2 % K3_BP == 0, "band height must divide the grid");
+typedef Buf<LB,                                  G2, K3_BP + 2, 36, G2 + 2, 0, 1> L3_T8;    // halo'd rows p0 .. p0+BP+1
+typedef Buf<L3_T8::OFF + (K3_BP + 2) * T8_ROW,   G2, K3_BP,     48, G2,     0, 0> L3_T9;
+typedef Buf<L3_T9::OFF + K3_BP * G2 * 48,        G2, K3_BP,      8, G2,     0, 0> L3_T7;
+typedef Buf<L3_T7::OFF + K3_BP * G2 * 8,         G2, K3_BP,      8, G2,     0, 0> L3_T11;
+typedef Buf<L3_T11::OFF + K3_BP * G2 * 8,        G2, K3_BP,     48, G2,     0, 0> L3_T14;
+typedef Buf<L3_T14::OFF + K3_BP * G2 * 48,       G2, K3_BP,     24, G2 + 1, 0, 1> L3_T15;
+constexpr int K3_LDS = L3_T15::OFF + K3_BP * T15_ROW;
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  auto addctx = [&](int k) {
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
+  };
+  const uint32_t z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
+  for (long job = blockIdx.x; job < prm.n * K3_BANDS; job += gridDim.x) {
+    const long fr = job / K3_BANDS;
+    const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
+    char* frames = smem;
+    char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    __syncthreads();
+    copy_dwords<NT>(frames + L3_T8::OFF, arena + A_T8 + p0 * T8_ROW, (K3_BP + 2) * T8_ROW, tid);
+    copy_dwords<NT>(frames + L3_T7::OFF, arena + A_T7 + p0 * (G2 * 8), K3_BP * G2 * 8, tid);
+    for (int i = tid; i < K3_BP * G2 * 5; i += NT) {                       // pooled half of concat_22: 20 of every 48 bytes
+      const int d = i % 5, px = i / 5;
+      *reinterpret_cast<uint32_t*>(frames + L3_T14::OFF + px * 48 + 4 * d) =
+          *reinterpret_cast<const uint32_t*>(arena + A_P8 + (p0 * G2 + px) * 20 + 4 * d);
+    }
+    __syncthreads();
+    dw_mfma_stage<F, NW, 1, L3_T8, L3_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 3, 16, L3_T9, L3_T11, 0, 6, EPI_ADD, YF_A_ADD18, L3_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 2, 1, 8, L3_T11, L3_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L3_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 2, 3, 16, L3_T14, L3_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L3_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
+    fill_column<NT, T15_ROW, 24>(frames + L3_T15::OFF, 0, K3_BP, z_t15, tid);
+    __syncthreads();
+    copy_dwords<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L3_T15::OFF, K3_BP * T15_ROW, tid);
+    if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
+  }
+}
+
+// ---- K4: the 20x20 tail, whole frame ------------------------------------------------------------------------------------
+typedef Buf<LB,                                   G2, G2, 24, G2 + 1, 1, 1> L4_T15;   // as in the arena
+typedef Buf<L4_T15::OFF + (G2 + 1) * T15_ROW,     G3, G3, 48, G3,     0, 0> L4_T30;
+typedef Buf<L4_T30::OFF + G3 * G3 * 48,           G3, G3, 32, G3,     0, 0> L4_T17;
+typedef Buf<L4_T17::OFF + G3 * G3 * 32,           G3, G3,  8, G3,     0, 0> L4_T18;
+typedef Buf<L4_T18::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T22;
+typedef Buf<L4_T22::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T26;
+typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1> L4_T19;   // aliases T15 (dead after pool_25 / conv2d_27)
+typedef Buf<LB + (G3 + 2) * (G3 + 2) * 40,        G3, G3, 48, G3,     0, 0> L4_T20;   // "
+typedef Buf<L4_T17::OFF,                          G3, G3, 32, G3,     0, 0> L4_T33;   // aliases T17 (dead after conv2d_29)
+constexpr int K4_LDS = L4_T26::OFF + G3 * G3 * 8;
+static_assert(L4_T20::OFF + G3 * G3 * 48 <= L4_T30::OFF, "T19 + T20 fit in T15's slot");
+
+template <int F, int NT>
+YF_STAGE_FN void pool25_band(char* frames, int tid) {        // pool25 of the fused kernel on the L4 buffers
+  constexpr int PP = L4_T30::P, OW = L4_T30::W, LIM = L4_T15::W - 1;
+  for (int i = tid; i < PP * 6; i += NT) {
+    const int cg = i % 6; const int p = i / 6;
+    const int oy = p / OW, ox = p - oy * OW;
+    SplitB m;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx)
+        m = m.mx(SplitB(lds_u32(frames + L4_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
+    *reinterpret_cast<uint32_t*>(frames + L4_T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
+  }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  auto addctx = [&](int k) {
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
+  };
+  for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
+    char* frames = smem;
+    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
+    const char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    __syncthreads();
+    copy_dwords<NT>(frames + L4_T15::OFF, arena + A_T15, (G2 + 1) * T15_ROW, tid);
+    __syncthreads();
+    pool25_band<F, NT>(frames, tid);
+    dw_mfma_stage<F, NW, 2, L4_T15, L4_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
+    __syncthreads();
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
+    dense_stage<F, NW, 3, 1, 8, L4_T18, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, wave, lane, vz);
+    __syncthreads();
+    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
+    __syncthreads();
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
+    dense_stage<F, NW, 3, 1, 8, L4_T22, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, wave, lane, vz);
+    __syncthreads();
+    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
+    __syncthreads();
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
+    dense_stage<F, NW, 2, 3, 16, L4_T30, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane, vz);
+    __syncthreads();
+    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 2, 3, 16, L4_T20, L4_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane, vz);
+    __syncthreads();
+    dense_stage<F, NW, 1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
+  }
+}
+}  // namespace band
 #endif  // YF_GENERIC
 
 }  // namespace YF_NS

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""160x160 parity of the layer-by-layer path against the CPU oracle (debug tool; runs on the GPU box)."""
+"""160x160 parity of the banded (default) or layer-by-layer (YF_160_LAYERWISE=1) path against the CPU oracle (debug tool; runs on the GPU box)."""
 import importlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
