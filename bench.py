@@ -111,7 +111,7 @@ def secondary_configs(net, dev, stream):
     out["int8_160x160"] = {"workload": "BASELINE configs[4]: batch=1024 int8 160x160x3 frames, one GPU", "ms_per_step": round(ms, 4),
                            "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * A160_BYTES_PER_FRAME,
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
-                           "kernel": net.kernel_name_160 if hasattr(net, "kernel_name_160") else "see DESIGN.md, 160x160 variant"}
+                           "kernel": "band_k1..band_k4: four launches, each a group of fused stages over row bands staged through LDS (DESIGN.md, 160x160)"}
     del d_in, d_out
     n = 4096
     net.fp16_init()

@@ -135,7 +135,10 @@ static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned gr
 // 160x160, banded form: four kernels, each fusing a group of stages over row bands staged through LDS
 struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; int wgs_per_cu; };
 static BandKernel k_band[4] = {
-  {(const void*)yf160::band::band_k1<8>,  "band_k1", 512,  (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
+#ifndef YF_K1_NW
+#define YF_K1_NW 8
+#endif
+  {(const void*)yf160::band::band_k1<YF_K1_NW>,  "band_k1", YF_K1_NW * 64,  (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
   {(const void*)yf160::band::band_k2<8>,  "band_k2", 512,  (size_t)yf160::band::K2_LDS, yf160::band::K2_BANDS, 1},
   {(const void*)yf160::band::band_k3<8>,  "band_k3", 512,  (size_t)yf160::band::K3_LDS, yf160::band::K3_BANDS, 1},
   {(const void*)yf160::band::band_k4<16>, "band_k4", 1024, (size_t)yf160::band::K4_LDS, 1, 1},

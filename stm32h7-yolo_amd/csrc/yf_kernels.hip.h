@@ -1074,20 +1074,28 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
 // band the top / bottom halo row) before the copy-out.
 namespace band {
 constexpr int LB = LUT_BYTES;                                   // LUTs at LDS offset 0 (absolute addressing)
-// per-frame HBM arena of the banded form (bytes)
-constexpr int T4_ROW = (G1 + 1) * 20, T8_ROW = (G2 + 2) * 36, T15_ROW = (G2 + 1) * 24;
-constexpr int A_T4 = 0;                                          // [G1 + 1 halo'd rows][G1 + 1][20]   top/left halo
+// per-frame HBM arena of the banded form (bytes); rows are padded to multiples of 16 bytes so bands move as 16-byte vectors
+constexpr int T4_RS = G1 + 4, T8_RS = G2 + 4, T15_RS = G2 + 2;   // pixels per halo'd row
+constexpr int T4_ROW = T4_RS * 20, T8_ROW = T8_RS * 36, T15_ROW = T15_RS * 24;
+static_assert(T4_ROW % 16 == 0 && T8_ROW % 16 == 0 && T15_ROW % 16 == 0 && (G2 * 20) % 16 == 0 && (G2 * 8) % 16 == 0, "16-byte rows");
+constexpr int A_T4 = 0;                                          // [G1 + 1 halo'd rows][T4_RS][20]    top/left halo
 constexpr int A_P8 = (A_T4 + (G1 + 1) * T4_ROW + 63) & ~63;      // [G2][G2][20]                       pool_8 + QUANTIZE#21
 constexpr int A_T7 = (A_P8 + G2 * G2 * 20 + 63) & ~63;           // [G2][G2][8]
-constexpr int A_T8 = (A_T7 + G2 * G2 * 8 + 63) & ~63;            // [G2 + 2][G2 + 2][36]               halo ring
-constexpr int A_T15 = (A_T8 + (G2 + 2) * T8_ROW + 63) & ~63;     // [G2 + 1][G2 + 1][24]               top/left halo
+constexpr int A_T8 = (A_T7 + G2 * G2 * 8 + 63) & ~63;            // [G2 + 2][T8_RS][36]                halo ring
+constexpr int A_T15 = (A_T8 + (G2 + 2) * T8_ROW + 63) & ~63;     // [G2 + 1][T15_RS][24]               top/left halo
 constexpr int ARENA_BYTES = (A_T15 + (G2 + 1) * T15_ROW + 63) & ~63;
 
 struct Params { const int8_t* in; int8_t* out; long n; const uint8_t* tab; char* arena; };
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding global access (vmcnt(0)):
+// that would drain the next band's prefetch loads and this band's copy-out stores at every stage boundary.  Nothing a
+// band kernel writes to HBM is read back by the same kernel, so LDS ordering is all the stages need.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// N bytes LDS -> HBM as 16-byte vectors (both 16-byte aligned, N a multiple of 16)
 template <int NT>
-__device__ __forceinline__ void copy_dwords(char* dst, const char* src, int bytes, int tid) {       // both 4-byte aligned
-  for (int i = tid; i < bytes / 4; i += NT) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+__device__ __forceinline__ void store_rows(char* dst, const char* src, int bytes, int tid) {
+  for (int i = tid; i < bytes / 16; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
 }
 template <int NT>
 __device__ __forceinline__ void fill_dwords(char* dst, uint32_t v, int bytes, int tid) {
@@ -1110,20 +1118,49 @@ __device__ __forceinline__ void load_luts(uint8_t* luts, const uint8_t* __restri
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
 }
 
+// A band's input, prefetched: CNT 16-byte vectors of a contiguous HBM range, vector i owned by thread i % NT.  fetch() issues
+// the loads for the NEXT job right after the current job's data has been committed to LDS; nothing waits for them until
+// the commit at the top of the next iteration, so the HBM latency hides behind the whole band's compute.
+template <int NT, int CNT>
+struct Prefetch {
+  static constexpr int PER = (CNT + NT - 1) / NT;
+  v4u v[PER];                                   // native vectors: HIP's uint4 class keeps the array in scratch
+};
+template <int NT, int CNT>
+__device__ __forceinline__ void pf_fetch(Prefetch<NT, CNT>& p, const char* src, int n16, int tid) {      // n16 <= CNT vectors
+#pragma unroll
+  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) p.v[k] = reinterpret_cast<const v4u*>(src)[min(tid + k * NT, n16 - 1)];
+}
+template <int NT, int CNT>
+__device__ __forceinline__ void pf_commit(const Prefetch<NT, CNT>& p, char* dst, int n16, int tid) {
+#pragma unroll
+  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) { const int i = tid + k * NT; if (i < n16) reinterpret_cast<v4u*>(dst)[i] = p.v[k]; }
+}
+
 // ---- K1 ----------------------------------------------------------------------------------------------------------------
-constexpr int K1_BH = 8, K1_BANDS = G1 / K1_BH, K1_NIN = 2 * K1_BH + 5, K1_NT1 = K1_BH + 2;
+#ifndef YF_K1_BH
+#define YF_K1_BH 16
+#endif
+#ifndef YF_K1_OCC
+#define YF_K1_OCC 4
+#endif
+constexpr int K1_BH = YF_K1_BH, K1_BANDS = G1 / K1_BH, K1_NIN = 2 * K1_BH + 5, K1_NT1 = K1_BH + 2;
 static_assert(G1 % K1_BH == 0, "band height must divide the grid");
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int K1_IN_BYTES = K1_NIN * (G0 + 4) * 4, K1_T1_BYTES = K1_NT1 * (G1 + 2) * 8;
+constexpr int K1_R0 = cmax(K1_IN_BYTES + K1_T1_BYTES, K1_BH * T4_ROW);                       // IN + T1, later T4
 typedef Buf<LB,                                  G0, K1_NIN - 1, 4, G0 + 4, 1, 4> L1_IN;    // RGBX rows: local row l = global halo'd row 2(a-1)+l
-typedef Buf<L1_IN::OFF + K1_NIN * (G0 + 4) * 4,  G1, K1_NT1,     8, G1 + 2, 0, 1> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
-typedef Buf<L1_T1::OFF + K1_NT1 * (G1 + 2) * 8,  G1, K1_BH,      8, G1,     0, 0> L1_T2;
+typedef Buf<L1_IN::OFF + K1_IN_BYTES,            G1, K1_NT1,     8, G1 + 2, 0, 1> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
+typedef Buf<LB + K1_R0,                          G1, K1_BH,      8, G1,     0, 0> L1_T2;
 typedef Buf<L1_T2::OFF + K1_BH * G1 * 8,         G1, K1_BH,      4, G1,     0, 0> L1_T3;
-typedef Buf<L1_T3::OFF + K1_BH * G1 * 4,         G1, K1_BH,     20, G1 + 1, 0, 1> L1_T4;    // left halo column
-constexpr int K1_LDS = L1_T4::OFF + K1_BH * T4_ROW;
+typedef Buf<LB,                                  G1, K1_BH,     20, T4_RS,  0, 1> L1_T4;    // left halo column; aliases IN and T1 (dead after conv2d_3)
+constexpr int K1_LDS = L1_T3::OFF + K1_BH * G1 * 4;
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k1(const Params prm) {
+__global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64, F = 1;
+  constexpr int RSW = G0 + 4, WQ = G0 / 4, ITEMS = K1_NIN * WQ, PER = (ITEMS + NT - 1) / NT;     // item = 4 pixels = 12 input bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint8_t* __restrict__ tab = prm.tab;
@@ -1131,62 +1168,79 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k1(const Params prm) {
   asm volatile("" : "+v"(vz));
   load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
   const AddK no_add = {};
-  const int zp_in = (int)uniform_u32(tab + offsetof(yf_table_index, in_zp));
-  const uint32_t z_in = splat(zp_in), z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
-  for (long job = blockIdx.x; job < prm.n * K1_BANDS; job += gridDim.x) {
+  const uint32_t z_in = splat((int)uniform_u32(tab + offsetof(yf_table_index, in_zp)));
+  const uint32_t z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
+  char* frames = smem;                                            // band-local buffers live at their LDS offsets
+  const long jobs = prm.n * K1_BANDS;
+  uint32_t pre[PER][3];
+  // input rows of a band: local row l <-> input row 2(a-1)+l-1, out of range = zero point
+  auto fetch = [&](long job) {
     const long fr = job / K1_BANDS;
-    const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
-    char* frames = smem;                                          // band-local buffers live at their LDS offsets
-    char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    __syncthreads();                                              // previous band's buffers are dead
-    {   // input rows -> RGBX with halo column; local row l <-> input row 2(a-1)+l-1, out of range = zero point
-      constexpr int RSW = G0 + 4, WQ = G0 / 4;
-      const int8_t* in = prm.in + fr * (long)IN_FRAME_BYTES;
-      for (int i = tid; i < K1_NIN * (WQ + 1); i += NT) {
-        const int l = i / (WQ + 1), xq = i - l * (WQ + 1);
-        const int r = 2 * (a - 1) + l - 1;
-        char* row = frames + L1_IN::OFF + l * RSW * 4;
-        if (xq == WQ) { *reinterpret_cast<uint32_t*>(row + 12) = z_in; continue; }           // halo column (dword 3)
-        uint4 px = {z_in, z_in, z_in, z_in};
-        if (r >= 0 && r < G0) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (long)r * (G0 * 3) + xq * 12);
-          const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
-          px.x = d0; px.y = funnel(d1, d0, 24); px.z = funnel(d2, d1, 16); px.w = d2 >> 8;
-        }
-        *reinterpret_cast<uint4*>(row + 16 + 16 * xq) = px;
+    const int a = (int)(job - fr * K1_BANDS) * K1_BH;
+    const int8_t* in = prm.in + fr * (long)IN_FRAME_BYTES;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      const int l = i / WQ, xq = i - l * WQ;
+      const int r = 2 * (a - 1) + l - 1;
+      pre[k][0] = pre[k][1] = pre[k][2] = z_in;
+      if (i < ITEMS && r >= 0 && r < G0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in + r * (G0 * 3) + xq * 12);
+        pre[k][0] = src[0]; pre[k][1] = src[1]; pre[k][2] = src[2];
       }
     }
-    __syncthreads();
+  };
+  long job = blockIdx.x;
+  if (job < jobs) fetch(job);
+  for (; job < jobs; job += gridDim.x) {
+    const long fr = job / K1_BANDS;
+    const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
+    char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    lds_barrier();                                                // previous band's buffers are dead
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                               // RGB -> RGBX dwords behind the halo column
+      const int i = tid + k * NT;
+      if (i < ITEMS) {
+        const int l = i / WQ, xq = i - l * WQ;
+        uint4 px;
+        px.x = pre[k][0]; px.y = funnel(pre[k][1], pre[k][0], 24); px.z = funnel(pre[k][2], pre[k][1], 16); px.w = pre[k][2] >> 8;
+        *reinterpret_cast<uint4*>(frames + L1_IN::OFF + l * RSW * 4 + 16 + 16 * xq) = px;
+      }
+    }
+    if (tid < K1_NIN) *reinterpret_cast<uint32_t*>(frames + L1_IN::OFF + tid * RSW * 4 + 12) = z_in;        // halo column (dword 3)
+    lds_barrier();
+    if (job + gridDim.x < jobs) fetch(job + gridDim.x);
     conv1_stage<F, NW, L1_IN, L1_T1>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
     fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
     fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
-    __syncthreads();
+    lds_barrier();
     if (a == 0) fill_dwords<NT>(frames + L1_T1::OFF, z_t1, (G1 + 2) * 8, tid);                               // T1 row -1 = halo
     if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * (G1 + 2) * 8, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
-    if (a == 0 || a + K1_BH == G1) __syncthreads();
+    if (a == 0 || a + K1_BH == G1) lds_barrier();
     dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3>(frames, nullptr, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4>(frames, nullptr, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
     fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
-    __syncthreads();
-    copy_dwords<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);             // halo'd rows a+1 ..
+    lds_barrier();
+    store_rows<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);              // halo'd rows a+1 ..
     if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
   }
 }
 
 // ---- K2 ----------------------------------------------------------------------------------------------------------------
-constexpr int K2_BP = 4, K2_BANDS = G2 / K2_BP, K2_NR = 2 * K2_BP + 6;
-static_assert(G2 % K2_BP == 0, "band height must divide the grid");
-typedef Buf<LB,                                G1, K2_NR, 20, G1 + 1, 0, 1> L2_T4;      // local row l = T4 row 2p-3+l (global halo'd row 2p-2+l)
-typedef Buf<LB + 2 * T4_ROW,                   G1, K2_NR, 20, G1 + 1, 0, 1> L2_T4_DW;   // the same rows as conv2d_10 addresses them: halo'd row 2p = local 2
+constexpr int K2_BP = 8, K2_BANDS = G2 / K2_BP, K2_NR = 2 * K2_BP + 6;
+static_assert(G2 % K2_BP == 0 && K2_BP % 4 == 0, "band height must divide the grid; the vertical pool pass sweeps 4 rows");
+typedef Buf<LB,                                G1, K2_NR, 20, T4_RS,  0, 1> L2_T4;      // local row l = T4 row 2p-3+l (global halo'd row 2p-2+l)
+typedef Buf<LB + 2 * T4_ROW,                   G1, K2_NR, 20, T4_RS,  0, 1> L2_T4_DW;   // the same rows as conv2d_10 addresses them: halo'd row 2p = local 2
 typedef Buf<L2_T4::OFF + K2_NR * T4_ROW,       G2, K2_NR, 20, G2,     0, 0> L2_HB;
+typedef Buf<L2_HB::OFF,                        G2, K2_BP, 32, G2,     0, 0> L2_T6;      // aliases HB (dead after the vertical pool pass)
 typedef Buf<L2_HB::OFF + K2_NR * G2 * 20,      G2, K2_BP, 20, G2,     0, 0> L2_P8;
-typedef Buf<L2_P8::OFF + K2_BP * G2 * 20,      G2, K2_BP, 32, G2,     0, 0> L2_T6;
-typedef Buf<L2_T6::OFF + K2_BP * G2 * 32,      G2, K2_BP,  8, G2,     0, 0> L2_T7;
-typedef Buf<L2_T7::OFF + K2_BP * G2 * 8,       G2, K2_BP, 36, G2 + 2, 0, 1> L2_T8;
-constexpr int K2_LDS = L2_T8::OFF + K2_BP * T8_ROW;
+typedef Buf<L2_P8::OFF + K2_BP * G2 * 20,      G2, K2_BP,  8, G2,     0, 0> L2_T7;
+typedef Buf<LB,                                G2, K2_BP, 36, T8_RS,  0, 1> L2_T8;      // aliases T4 (dead after conv2d_10)
+constexpr int K2_LDS = L2_T7::OFF + K2_BP * G2 * 8;
+static_assert(K2_BP * G2 * 32 <= K2_NR * G2 * 20 && K2_BP * T8_ROW <= K2_NR * T4_ROW, "aliases fit");
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
@@ -1200,17 +1254,27 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
   load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
   const AddK no_add = {};
   const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15));
-  for (long job = blockIdx.x; job < prm.n * K2_BANDS; job += gridDim.x) {
+  char* frames = smem;
+  const long jobs = prm.n * K2_BANDS;
+  Prefetch<NT, K2_NR * T4_ROW / 16> pre;
+  // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
+  auto range = [&](long job, const char*& src, int& lo_local, int& n16) {
+    const long fr = job / K2_BANDS;
+    const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;
+    const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K2_NR, G1 + 1);
+    src = prm.arena + fr * (long)ARENA_BYTES + A_T4 + lo * T4_ROW;
+    lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
+  };
+  long job = blockIdx.x;
+  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
+  for (; job < jobs; job += gridDim.x) {
     const long fr = job / K2_BANDS;
     const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;             // first 40x40 row of the band
-    char* frames = smem;
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    __syncthreads();
-    {   // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
-      const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K2_NR, G1 + 1);
-      copy_dwords<NT>(frames + L2_T4::OFF + (lo - h0) * T4_ROW, arena + A_T4 + lo * T4_ROW, (hi - lo) * T4_ROW, tid);
-    }
-    __syncthreads();
+    lds_barrier();
+    { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L2_T4::OFF + ll * T4_ROW, n16, tid); }
+    lds_barrier();
+    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
     {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
       constexpr int NO = 5, NCH = G2 / NO;
       static_assert(G2 % NO == 0, "sweeps of 5 outputs");
@@ -1223,27 +1287,30 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
                                 [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
       }
     }
-    __syncthreads();
-    {   // vertical pass: output rows p0 .. p0+3 need T4 rows 2p0-3 .. 2p0+10 clamped to the image = the 14 band rows
-      for (int i = tid; i < G2 * 5; i += NT) {
-        const int cg = i % 5, ox = i / 5;
+    lds_barrier();
+    {   // vertical pass: output rows p0 .. p0+BP-1 need T4 rows 2p0-3 .. 2p0+2BP+2 clamped to the image = the band rows
+      constexpr int NO = 4, NSW = K2_BP / NO;
+      for (int i = tid; i < NSW * G2 * 5; i += NT) {
+        const int cg = i % 5; int t = i / 5;
+        const int ox = t % G2; const int sw = t / G2;
         const char* col = frames + L2_HB::OFF + ox * 20 + 4 * cg;
         char* dst = frames + L2_P8::OFF + ox * 20 + 4 * cg;
-        pool8_sweep<K2_BP, G1 - 1>(p0, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
-                                   [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 20)) = lut4_raw<YF_L_Q21>(v); });
+        pool8_sweep<NO, G1 - 1>(p0 + sw * NO, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
+                                [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 20)) = lut4_raw<YF_L_Q21>(v); });
       }
     }
+    lds_barrier();                                                 // T6 (written next) aliases HB
     dw_mfma_stage<F, NW, 2, L2_T4_DW, L2_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 2, 16, L2_T6, L2_T7, 0, 6, EPI_RAW, 0, L2_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 3, 1, 8, L2_T7, L2_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L2_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
     fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, 0, K2_BP, z_t8, tid);
     fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, G2 + 1, K2_BP, z_t8, tid);
-    __syncthreads();
-    copy_dwords<NT>(arena + A_P8 + p0 * (G2 * 20), frames + L2_P8::OFF, K2_BP * G2 * 20, tid);
-    copy_dwords<NT>(arena + A_T7 + p0 * (G2 * 8), frames + L2_T7::OFF, K2_BP * G2 * 8, tid);
-    copy_dwords<NT>(arena + A_T8 + (p0 + 1) * T8_ROW, frames + L2_T8::OFF, K2_BP * T8_ROW, tid);             // halo'd rows p0+1 ..
+    lds_barrier();
+    store_rows<NT>(arena + A_P8 + p0 * (G2 * 20), frames + L2_P8::OFF, K2_BP * G2 * 20, tid);
+    store_rows<NT>(arena + A_T7 + p0 * (G2 * 8), frames + L2_T7::OFF, K2_BP * G2 * 8, tid);
+    store_rows<NT>(arena + A_T8 + (p0 + 1) * T8_ROW, frames + L2_T8::OFF, K2_BP * T8_ROW, tid);              // halo'd rows p0+1 ..
     if (p0 == 0) fill_dwords<NT>(arena + A_T8, z_t8, T8_ROW, tid);
     if (p0 + K2_BP == G2) fill_dwords<NT>(arena + A_T8 + (G2 + 1) * T8_ROW, z_t8, T8_ROW, tid);
   }
@@ -1252,12 +1319,12 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
 // ---- K3 ----------------------------------------------------------------------------------------------------------------
 constexpr int K3_BP = 8, K3_BANDS = G2 / K3_BP;
 static_assert(G2 % K3_BP == 0, "band height must divide the grid");
-typedef Buf<LB,                                  G2, K3_BP + 2, 36, G2 + 2, 0, 1> L3_T8;    // halo'd rows p0 .. p0+BP+1
+typedef Buf<LB,                                  G2, K3_BP + 2, 36, T8_RS,  0, 1> L3_T8;    // halo'd rows p0 .. p0+BP+1
 typedef Buf<L3_T8::OFF + (K3_BP + 2) * T8_ROW,   G2, K3_BP,     48, G2,     0, 0> L3_T9;
 typedef Buf<L3_T9::OFF + K3_BP * G2 * 48,        G2, K3_BP,      8, G2,     0, 0> L3_T7;
 typedef Buf<L3_T7::OFF + K3_BP * G2 * 8,         G2, K3_BP,      8, G2,     0, 0> L3_T11;
 typedef Buf<L3_T11::OFF + K3_BP * G2 * 8,        G2, K3_BP,     48, G2,     0, 0> L3_T14;
-typedef Buf<L3_T14::OFF + K3_BP * G2 * 48,       G2, K3_BP,     24, G2 + 1, 0, 1> L3_T15;
+typedef Buf<L3_T14::OFF + K3_BP * G2 * 48,       G2, K3_BP,     24, T15_RS, 0, 1> L3_T15;
 constexpr int K3_LDS = L3_T15::OFF + K3_BP * T15_ROW;
 
 template <int NW>
@@ -1278,36 +1345,59 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
                 (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   const uint32_t z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
-  for (long job = blockIdx.x; job < prm.n * K3_BANDS; job += gridDim.x) {
+  char* frames = smem;
+  const long jobs = prm.n * K3_BANDS;
+  constexpr int N_T8 = (K3_BP + 2) * T8_ROW / 16, N_T7 = K3_BP * G2 * 8 / 16, N_P8 = K3_BP * G2 * 20 / 16;
+  Prefetch<NT, N_T8> pre8;
+  Prefetch<NT, N_T7> pre7;
+  Prefetch<NT, N_P8> prep;
+  auto fetch = [&](long job) {
     const long fr = job / K3_BANDS;
     const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
-    char* frames = smem;
+    const char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    pf_fetch(pre8, arena + A_T8 + p0 * T8_ROW, N_T8, tid);
+    pf_fetch(pre7, arena + A_T7 + p0 * (G2 * 8), N_T7, tid);
+    pf_fetch(prep, arena + A_P8 + p0 * (G2 * 20), N_P8, tid);
+  };
+  long job = blockIdx.x;
+  if (job < jobs) fetch(job);
+  for (; job < jobs; job += gridDim.x) {
+    const long fr = job / K3_BANDS;
+    const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    __syncthreads();
-    copy_dwords<NT>(frames + L3_T8::OFF, arena + A_T8 + p0 * T8_ROW, (K3_BP + 2) * T8_ROW, tid);
-    copy_dwords<NT>(frames + L3_T7::OFF, arena + A_T7 + p0 * (G2 * 8), K3_BP * G2 * 8, tid);
-    for (int i = tid; i < K3_BP * G2 * 5; i += NT) {                       // pooled half of concat_22: 20 of every 48 bytes
-      const int d = i % 5, px = i / 5;
-      *reinterpret_cast<uint32_t*>(frames + L3_T14::OFF + px * 48 + 4 * d) =
-          *reinterpret_cast<const uint32_t*>(arena + A_P8 + (p0 * G2 + px) * 20 + 4 * d);
+    lds_barrier();
+    pf_commit(pre8, frames + L3_T8::OFF, N_T8, tid);
+    pf_commit(pre7, frames + L3_T7::OFF, N_T7, tid);
+#pragma unroll
+    for (int k = 0; k < prep.PER; ++k) {                                   // pooled half of concat_22: 20 of every 48 bytes
+      const int i = tid + k * NT;
+      if (i < N_P8) {
+        const uint32_t w[4] = {prep.v[k][0], prep.v[k][1], prep.v[k][2], prep.v[k][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d = 4 * i + j, px = d / 5, c = d - 5 * px;
+          *reinterpret_cast<uint32_t*>(frames + L3_T14::OFF + px * 48 + 4 * c) = w[j];
+        }
+      }
     }
-    __syncthreads();
+    lds_barrier();
+    if (job + gridDim.x < jobs) fetch(job + gridDim.x);
     dw_mfma_stage<F, NW, 1, L3_T8, L3_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 3, 16, L3_T9, L3_T11, 0, 6, EPI_ADD, YF_A_ADD18, L3_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 2, 1, 8, L3_T11, L3_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L3_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 2, 3, 16, L3_T14, L3_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L3_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
     fill_column<NT, T15_ROW, 24>(frames + L3_T15::OFF, 0, K3_BP, z_t15, tid);
-    __syncthreads();
-    copy_dwords<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L3_T15::OFF, K3_BP * T15_ROW, tid);
+    lds_barrier();
+    store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L3_T15::OFF, K3_BP * T15_ROW, tid);
     if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
   }
 }
 
 // ---- K4: the 20x20 tail, whole frame ------------------------------------------------------------------------------------
-typedef Buf<LB,                                   G2, G2, 24, G2 + 1, 1, 1> L4_T15;   // as in the arena
+typedef Buf<LB,                                   G2, G2, 24, T15_RS, 1, 1> L4_T15;   // as in the arena
 typedef Buf<L4_T15::OFF + (G2 + 1) * T15_ROW,     G3, G3, 48, G3,     0, 0> L4_T30;
 typedef Buf<L4_T30::OFF + G3 * G3 * 48,           G3, G3, 32, G3,     0, 0> L4_T17;
 typedef Buf<L4_T17::OFF + G3 * G3 * 32,           G3, G3,  8, G3,     0, 0> L4_T18;
@@ -1352,41 +1442,45 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
                 (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
                 (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
-  for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
-    char* frames = smem;
+  char* frames = smem;
+  constexpr int N_T15 = (G2 + 1) * T15_ROW / 16;
+  Prefetch<NT, N_T15> pre;
+  long fr = blockIdx.x;
+  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N_T15, tid);
+  for (; fr < prm.n; fr += gridDim.x) {
     char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
-    const char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    __syncthreads();
-    copy_dwords<NT>(frames + L4_T15::OFF, arena + A_T15, (G2 + 1) * T15_ROW, tid);
-    __syncthreads();
+    lds_barrier();
+    pf_commit(pre, frames + L4_T15::OFF, N_T15, tid);
+    lds_barrier();
+    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N_T15, tid);
     pool25_band<F, NT>(frames, tid);
     dw_mfma_stage<F, NW, 2, L4_T15, L4_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
     dense_stage<F, NW, 3, 1, 8, L4_T18, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
     dense_stage<F, NW, 3, 1, 8, L4_T22, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
     dense_stage<F, NW, 2, 3, 16, L4_T30, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 2, 3, 16, L4_T20, L4_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane, vz);
-    __syncthreads();
+    lds_barrier();
     dense_stage<F, NW, 1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
   }
 }
