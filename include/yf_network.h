@@ -240,6 +240,10 @@ YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, vo
  * min(count, cap) records, the total line carries count like the firmware's face_num).  Returns the number of
  * bytes the text needs (excluding the terminating NUL); at most buflen - 1 bytes are stored.  Host-only, no GPU. */
 YF_API long yf_network_format_uart(unsigned frame_no, const yf_det* dets, int count, int cap, char* buf, size_t buflen);
+/* Diagnostic: the byte offsets of the device table blob that are compiled into the kernels -- w_off[17], c_off[17] of the
+ * dense stages, g_off[7] of the depthwise stages, lut_off, total (43 ints).  ai_network_init refuses to start when the
+ * blob built from the caller's weights is laid out differently.  Returns the number of ints; host-only, no GPU. */
+YF_API int yf_network_table_plan(int32_t* out, int cap);
 /* Multi-GPU: one process per GPU, each with its own network instance on its device
  * (yf_network_set_device(local_rank) before ai_network_init).  Frames are independent: rank r of `world` runs the contiguous
  * slice [*begin, *end) of an n-frame batch (the first n % world ranks take one frame more) ... */

@@ -86,7 +86,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
+           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",

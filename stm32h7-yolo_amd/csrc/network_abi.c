@@ -311,9 +311,11 @@ YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, c
   if (!c) return 0;
   if (height == 56 && width == 56) return finish(c, yf_engine_run_device(c->engine, d_in, d_out, NULL, n, stream), n);
   if (height == 160 && width == 160) return finish(c, yf_engine_run_device_160(c->engine, d_in, d_out, n, stream), n);
-  latch(c, AI_ERROR_INVALID_INPUT, AI_ERROR_CODE_INVALID_SIZE, "supported input sizes: 56x56 (fused) and 160x160 (layer-by-layer)");
+  latch(c, AI_ERROR_INVALID_INPUT, AI_ERROR_CODE_INVALID_SIZE, "supported input sizes: 56x56 (one fused kernel) and 160x160 (banded kernels)");
   return 0;
 }
+
+YF_API int yf_network_table_plan(int32_t* out, int cap) { return yf_engine_table_plan(out, cap); }
 
 /* ------------------------------------------------------------------------------------------------ multi-GPU */
 YF_API void yf_network_shard_range(long n, int rank, int world, long* begin, long* end) {

@@ -18,6 +18,8 @@ void yf_engine_destroy(yf_engine* e);
 /* 1 if a production kernel of that shape is compiled in (frames_per_wg may carry the +200 experimental-build tag) */
 int  yf_engine_variant_exists(int frames_per_wg, int waves_per_wg);
 int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);
+/* byte offsets compiled into the kernels: w_off[17], c_off[17] (dense stages), g_off[7] (depthwise), lut_off, total = 43 ints */
+int  yf_engine_table_plan(int32_t* out, int cap);
 const char* yf_engine_error(const yf_engine* e);
 const char* yf_engine_kernel_name(const yf_engine* e);
 

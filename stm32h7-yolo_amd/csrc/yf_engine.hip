@@ -173,6 +173,12 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   if ((rc = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(rc, "hipGetDeviceProperties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return fail(std::string("unsupported GPU ") + prop.gcnArchName + " (this library is gfx950 only)", YF_ENG_ERR_NO_DEVICE); }
   e->cus = prop.multiProcessorCount;
+  {   // the kernels address the tables at compiled-in offsets (yf_kernels.hip.h, TablePlan): the blob must be laid out that way
+    bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
+    for (int i = 0; i < YF_N_DENSE; ++i) same = same && (int)ix->dense[i].w_off == yf::PLAN.w_off[i] && (int)ix->dense[i].c_off == yf::PLAN.c_off[i];
+    for (int i = 0; i < YF_N_DW; ++i) same = same && (int)ix->dw[i].g_off == yf::PLAN.g_off[i];
+    if (!same) { delete e; return fail("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG); }
+  }
   if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
   if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
   if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_sig_bits), yf_sigmoid_bits, sizeof yf_sigmoid_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(sigmoid)");
@@ -221,6 +227,17 @@ void yf_engine_destroy(yf_engine* e) {
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
+}
+
+int yf_engine_table_plan(int32_t* out, int cap) {
+  const int need = 2 * YF_N_DENSE + YF_N_DW + 2;
+  if (!out || cap < need) return need;
+  int k = 0;
+  for (int i = 0; i < YF_N_DENSE; ++i) out[k++] = yf::PLAN.w_off[i];
+  for (int i = 0; i < YF_N_DENSE; ++i) out[k++] = yf::PLAN.c_off[i];
+  for (int i = 0; i < YF_N_DW; ++i) out[k++] = yf::PLAN.g_off[i];
+  out[k++] = yf::PLAN.lut_off; out[k++] = yf::PLAN.total;
+  return need;
 }
 
 int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) {

@@ -286,15 +286,37 @@ __device__ __forceinline__ PassS load_pass_s(const uint8_t* pass) {
 #endif
 }
 // stage descriptors out of the index at the head of the table blob, as scalar loads (offsets stay in SGPRs)
-__device__ __forceinline__ yf_dense load_dense(const uint8_t* tab, int i) {
-  const uint8_t* p = tab + offsetof(yf_table_index, dense) + i * sizeof(yf_dense);
+// Table layout, compiled in.  The blob is laid out by yf_prepare_tables (yf_host_prep.c) stage by stage with 16-byte
+// alignment, and every size in it follows from the network's architecture alone -- so the byte offsets are constants of the
+// build.  Kernels address tab + constant (no descriptor fetch in front of every stage's first table load); the engine
+// compares this plan with the index the host preparation produced and refuses to start on any difference.
+struct TablePlan { int w_off[YF_N_DENSE], c_off[YF_N_DENSE], g_off[YF_N_DW], lut_off, total; };
+constexpr int PLAN_COUT[YF_N_DENSE] = {8, 4, 18, 6, 36, 6, 18, 24, 8, 40, 8, 40, 8, 24, 40, 32, 18};
+constexpr int PLAN_KROW[YF_N_DENSE] = {YF_CONV1_KROW, 16, 16, 32, 16, 48, 16, 48, 32, 16, 48, 16, 48, 16, 48, 48, 32};
+constexpr int PLAN_DWC[YF_N_DW] = {8, 18, 36, 24, 40, 40, 40};
+constexpr TablePlan make_plan() {
+  TablePlan p = {};
+  int off = YF_INDEX_RESERVED;
+  for (int i = 0; i < YF_N_DENSE; ++i) {
+    const int cp = (PLAN_COUT[i] + 3) & ~3;
+    off = (off + 15) & ~15; p.w_off[i] = off; off += cp * PLAN_KROW[i];
+    off = (off + 15) & ~15; p.c_off[i] = off; off += (cp / 4) * (int)sizeof(yf_pass);
+  }
+  for (int i = 0; i < YF_N_DW; ++i) { off = (off + 15) & ~15; p.g_off[i] = off; off += ((PLAN_DWC[i] + 3) / 4) * YF_DW_GROUP_BYTES; }
+  off = (off + 15) & ~15; p.lut_off = off; off += YF_N_LUT * 256 + YF_ADDLUT_BYTES;
+  off = (off + 15) & ~15; off += 64;            // zeroed tail (16-byte reads past the last row stay in bounds)
+  p.total = off;
+  return p;
+}
+constexpr TablePlan PLAN = make_plan();
+__device__ __forceinline__ yf_dense load_dense(const uint8_t*, int i) {
   yf_dense d = {};
-  d.w_off = uniform_u32(p); d.c_off = uniform_u32(p + 4);
+  d.w_off = (uint32_t)PLAN.w_off[i]; d.c_off = (uint32_t)PLAN.c_off[i];
   return d;
 }
-__device__ __forceinline__ yf_dw load_dw(const uint8_t* tab, int i) {
+__device__ __forceinline__ yf_dw load_dw(const uint8_t*, int i) {
   yf_dw d = {};
-  d.g_off = uniform_u32(tab + offsetof(yf_table_index, dw) + i * sizeof(yf_dw));
+  d.g_off = (uint32_t)PLAN.g_off[i];
   return d;
 }
 __device__ __forceinline__ int load_halo_zp(const uint8_t* tab, int i) {
@@ -783,7 +805,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #endif
 
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
 
   const long n_groups = (prm.n + F - 1) / F;
   const AddK no_add = {};
@@ -980,7 +1002,7 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint8_t* __restrict__ tab = prm.tab;
   for (int i = tid; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
   __syncthreads();
   const AddK no_add = {};
   auto addctx = [&](int k) {
@@ -1115,7 +1137,7 @@ __device__ __forceinline__ uint32_t splat(int zp) { return (uint32_t)(zp & 255) 
 template <int NT>
 __device__ __forceinline__ void load_luts(uint8_t* luts, const uint8_t* __restrict__ tab, int tid) {
   for (int i = tid; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + uniform_u32(tab + offsetof(yf_table_index, lut_off)))[i];
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
 }
 
 // A band's input, prefetched: CNT 16-byte vectors of a contiguous HBM range, vector i owned by thread i % NT.  fetch() issues

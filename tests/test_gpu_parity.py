@@ -190,6 +190,16 @@ def test_baseline_config5_160x160(network, oracle, torch_cuda):
     got = d_out.cpu().numpy()
     assert np.array_equal(got[:1024], ref[idx])
     assert (got[1024] == 77).all()
+    # ragged launches: fewer band jobs than resident workgroups, a second chunk of the 1024-frame arena with one frame
+    for n in (1, 3, 1025):
+        pick = rng.integers(0, 12, n)
+        d_in = torch.from_numpy(block[pick]).cuda()
+        d_out = torch.full((n + 1, 20, 20, 18), 77, dtype=torch.int8, device="cuda")
+        network.run_device_hw(160, 160, d_in.data_ptr(), d_out.data_ptr(), n)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:n], ref[pick]), n
+        assert (got[n] == 77).all()
     # the generic entry point also accepts 56x56 (fused kernel) and refuses other sizes with a latched error
     x = rnd(77, 9)
     d_in = torch.from_numpy(x).cuda()
@@ -200,6 +210,17 @@ def test_baseline_config5_160x160(network, oracle, torch_cuda):
     with pytest.raises(Exception) as ei:
         network.run_device_hw(64, 64, d_in.data_ptr(), d_out.data_ptr(), 1)
     assert (ei.value.type, ei.value.code) == (0x12, 0x18)
+
+
+def test_160x160_layer_by_layer_form_agrees(torch_cuda):
+    """The layer-by-layer form of the 160x160 path (one kernel per stage over an HBM arena; YF_160_LAYERWISE=1, kept as the
+    plain statement the banded kernels are debugged against) gives the same heads: tools/gpu_parity_160.py compares it with
+    the oracle in a fresh process, because the form is chosen when the engine is created."""
+    import subprocess, sys
+    env = dict(os.environ, YF_160_LAYERWISE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity_160.py"), "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "160x160 head ok" in r.stdout
 
 
 def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):

@@ -58,6 +58,19 @@ def pack():
     return load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
 
 
+def test_table_layout_matches_the_plan_compiled_into_the_kernels(prep):
+    """The kernels address the table blob at compile-time offsets (yf_kernels.hip.h, TablePlan); the host preparation
+    lays the blob out at run time.  Both must agree (the engine refuses to start otherwise)."""
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc")], stdout=subprocess.DEVNULL)
+    net = ctypes.CDLL(os.path.join(PKG, "lib", "libyf_network.so"))
+    plan = (ctypes.c_int32 * 43)()
+    assert net.yf_network_table_plan(plan, 43) == 43
+    ix = prep["ix"]
+    want = [d.w_off for d in ix.dense] + [d.c_off for d in ix.dense] + [d.g_off for d in ix.dw] + [ix.lut_off, ix.total_bytes]
+    assert list(plan) == want
+    assert net.yf_network_table_plan(None, 0) == 43
+
+
 def test_quantize_multiplier_agrees_with_oracle(prep, oracle):
     rng = np.random.default_rng(0)
     vals = np.concatenate([10.0 ** rng.uniform(-12, 3, 4000), [0.0, 0.5, 1.0, 0.25, 1 - 2.0**-40, 2.0**-33, 3e-12]])
