@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--det-cap", type=int, default=4, help="detection records kept (and exchanged) per frame; the count is always the true count")
     ap.add_argument("--gather-heads", action="store_true", help="also all-gather the int8 heads (882 B per frame) at N > 1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 160x160 and fp16 side configurations")
+    ap.add_argument("--clock-settle-ms", type=float, default=60.0,
+                    help="before the W warm-up steps keep the GPU busy with untimed launches of the same kernel for this long: a GPU "
+                         "that has idled runs its first ~10 ms at a lower engine clock (tools/step_probe.py), and W = 5 steps are 1 ms; 0 = off")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
@@ -224,6 +227,12 @@ def main():
                 pending[i].wait()
                 pending[i] = None
 
+    # Clock settle (untimed, reported as config.clock_settle_ms): the engine clock of an idle GPU ramps up over the first ~10 ms
+    # of work -- the first ~50 launches run ~6 % slower -- and a short warm-up (W = 5 steps = 1 ms) would leave the timed
+    # region inside that ramp.  Same kernel, same buffers, no collectives; the W warm-up steps and the K timed steps follow.
+    settled_ms = 0.0
+    while settled_ms < args.clock_settle_ms:
+        settled_ms += event_time_ms(stream, lambda: launch(0, 0), 25) * 25
     for _ in range(args.warmup):
         step()
     # One step is ONE kernel launch, so the fused kernel's average duration is the HIP-event time of the whole timed
@@ -305,7 +314,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch=4096 int8 YOLO-face 56x56x3 frames per GPU, fused LDS-resident "
                                    "forward + GPU box decode" + exch,
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
-                       "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
+                       "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
                        "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
                        "parallelism": f"batch-shard x{world}, all-gather of detections" if world > 1 else "single GPU",
                        "exchange_bytes_per_rank_per_step": rec_bytes if world > 1 else 0},
