@@ -83,11 +83,11 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 
 typedef void (*fused_fn)(const yf::NetParams);
 static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
-struct Variant { int f, nw; bool dump; bool exp; fused_fn fn; size_t lds; const char* name; };
+struct Variant { int f, nw; bool dump; bool exp; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
 
-#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW>(), \
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
-#define YF_VARIANT_X(F, NW) { F, NW, false, true, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW>(), \
+#define YF_VARIANT_X(F, NW) { F, NW, false, true, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<false>(), \
                               "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
 // production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
 const Variant k_variants[] = {
@@ -98,6 +98,7 @@ const Variant k_variants[] = {
 
 }  // namespace
 
+constexpr int PARK_REGIONS = 4;
 struct yf_engine {
   int device = 0;
   int cus = 0;
@@ -107,6 +108,7 @@ struct yf_engine {
   const Variant* var_dump = nullptr;
   void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
   char* arena160 = nullptr; long arena160_frames = 0; bool layerwise160 = false;
+  char* d_park = nullptr; size_t park_region = 0; unsigned park_next = 0;      // tail batching scratch of the fused kernel
   hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -208,6 +210,12 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     k.wgs_per_cu = occ > 0 ? occ : 1;
   }
   { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // A/B and debugging only
+  {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
+    size_t park = 0;
+    for (const Variant& v : k_variants) park = v.park > park ? v.park : park;
+    e->park_region = (size_t)e->cus * 4 * park;
+    if (park && (rc = hipMalloc((void**)&e->d_park, e->park_region * PARK_REGIONS)) != hipSuccess) return bail(rc, "hipMalloc(tail scratch)");
+  }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
   e->var = find_variant(2, 8, false);
@@ -223,6 +231,7 @@ void yf_engine_destroy(yf_engine* e) {
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_out) (void)hipFree(e->d_out);
   if (e->arena160) (void)hipFree(e->arena160);
+  if (e->d_park) (void)hipFree(e->d_park);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -278,6 +287,13 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
   long grid = (long)e->cus * per_cu;
   if (grid > groups) grid = groups;
+  prm.scratch = nullptr;
+  if (v->park) {   // tail batching: a workgroup parks one group's T15 (f frames) in HBM.  Launches rotate through PARK_REGIONS
+                   // regions so that launches of one instance overlapping on different streams never share a slot.
+    const size_t need = (size_t)grid * v->f * v->park;
+    if (need > e->park_region) { e->err = "tail scratch region too small for this kernel shape"; return YF_ENG_ERR_VARIANT; }
+    prm.scratch = e->d_park + (size_t)(e->park_next++ % PARK_REGIONS) * e->park_region;
+  }
   hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->nw * 64), v->lds, s, prm);
   HIPCHK(e, hipGetLastError());
   return YF_ENG_OK;

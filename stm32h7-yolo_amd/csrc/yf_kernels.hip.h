@@ -49,10 +49,16 @@ constexpr int LUT_BYTES = YF_N_LUT * 256 + YF_ADDLUT_BYTES;    // byte LUTs, the
 
 
 // Buf: OFF byte offset in the frame arena, logical W x H, S bytes per pixel, RS pixels per row (incl. halo),
-// PT/PL halo rows/cols in front of logical pixel (0,0).
-template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_>
+// PT/PL halo rows/cols in front of logical pixel (0,0); FS = bytes between the arenas of consecutive frames of a
+// workgroup (the 7x7 tail of the 56x56 kernel packs its frames at half the stride of the front stages).
+#if !defined(YF_H0) || YF_H0 == 56
+constexpr int BUF_FS = FRAME_BYTES;
+#else
+constexpr int BUF_FS = 0;                      // one frame per workgroup
+#endif
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = BUF_FS>
 struct Buf {
-  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_;
+  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_;
   static constexpr int P = W_ * H_;
   __device__ static __forceinline__ int at(int y, int x) { return OFF_ + ((y + PT_) * RS_ + (x + PL_)) * S_; }
   __device__ static __forceinline__ int at_p(int p) {
@@ -91,6 +97,24 @@ typedef Buf<12976,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
 typedef Buf<15328,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
 typedef Buf<15720,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
 typedef Buf<16112,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
+// The 7x7 tail (pool_25 ... conv2d_53) works on one 17 KB SET per frame: the same offsets as above, T33 on T17's slot
+// (dead after conv2d_29) and the staged head behind T26.  FS = FRAME_BYTES addresses the sets at the start of each frame's
+// arena; FS = FRAME_BYTES / 2 packs two sets per arena (tail batching: see the kernel).
+template <int FS_>
+struct TailBufs {
+  typedef Buf<    0, 14, 14, 24, 15, 1, 1, FS_> T15;
+  typedef Buf< 5408,  7,  7, 48,  7, 0, 0, FS_> T30;
+  typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T17;
+  typedef Buf< 9328,  7,  7,  8,  7, 0, 0, FS_> T18;
+  typedef Buf< 9728,  7,  7, 40,  9, 1, 1, FS_> T19;
+  typedef Buf<12976,  7,  7, 48,  7, 0, 0, FS_> T20;
+  typedef Buf<15328,  7,  7,  8,  7, 0, 0, FS_> T22;
+  typedef Buf<15720,  7,  7,  8,  7, 0, 0, FS_> T26;
+  typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T33;
+  typedef Buf<16128,  7,  7, 18,  7, 0, 0, FS_> HEAD;
+  static constexpr int END = 16128 + 882, T15_BYTES = 5408;
+  static_assert(END <= FS_, "a set fits its stride");
+};
 #else
 // Any other size: the same buffers laid out one after another in a per-frame HBM arena (nothing aliases; 64 bytes
 // of slack behind each buffer absorb the depthwise stage's harmless over-reads on masked lanes).
@@ -129,7 +153,7 @@ constexpr int FRAME_BYTES = B_T33_END;
 constexpr int OUT_FRAME_BYTES = G3 * G3 * 18;
 constexpr int IN_FRAME_BYTES = G0 * G0 * 3;
 
-enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3 };
+enum { EPI_LUT = 0, EPI_RAW = 1, EPI_ADD = 2, EPI_HEAD = 3, EPI_HEAD_LDS = 4 };   // HEAD: 18-byte pixels at out_all; HEAD_LDS: in the frame's arena (OUT)
 
 // ------------------------------------------------------------------------------------------------ arithmetic
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -351,7 +375,7 @@ YF_STAGE_FN void fill_halo(char* frames, int zp, int tid) {
     } else {
       if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
     }
-    *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B::OFF + (r * WR + c) * B::S + 4 * d) = v;
+    *reinterpret_cast<uint32_t*>(frames + f * B::FS + B::OFF + (r * WR + c) * B::S + 4 * d) = v;
   }
 }
 
@@ -370,7 +394,7 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
   for (int i = tid; i < F * (RSW + HH); i += NT) {
     const int f = i / (RSW + HH), k = i - f * (RSW + HH);
     const int idx = k < RSW ? k : (k - RSW + 1) * RSW + 3;
-    *reinterpret_cast<uint32_t*>(frames + f * FRAME_BYTES + B_IN::OFF + idx * 4) = hv;
+    *reinterpret_cast<uint32_t*>(frames + f * B_IN::FS + B_IN::OFF + idx * 4) = hv;
   }
   // frames past the end of the batch re-read the last one; everything per item is 32-bit arithmetic off one scalar base
   const long rest = n_frames - 1 - first_frame;
@@ -395,7 +419,7 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
     px.w = d2 >> 8;
     const int y = (int)((uint32_t)r / (uint32_t)WQ);
     // halo'd dword index ((y + 1) * RSW + 4 * xq + 4) with xq = r - y * WQ, RSW = 4 * WQ + 4  ->  4 * (r + y) + RSW + 4
-    *reinterpret_cast<uint4*>(frames + f * FRAME_BYTES + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
+    *reinterpret_cast<uint4*>(frames + f * B_IN::FS + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
   }
 }
 
@@ -426,9 +450,10 @@ __device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, char
     requant4<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro},
                     v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
     *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
-  } else {  // EPI_HEAD: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
+  } else {  // head: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
+    static_assert(EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "epilogue kind");
     const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-    uint16_t* dst = reinterpret_cast<uint16_t*>(out_all + f * OUT_FRAME_BYTES + p * 18 + chq);
+    uint16_t* dst = reinterpret_cast<uint16_t*>((EPI == EPI_HEAD ? out_all + f * OUT_FRAME_BYTES : fbase + OUT::OFF) + p * 18 + chq);
     dst[0] = (uint16_t)v;
     if (chq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
   }
@@ -449,7 +474,8 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
   constexpr int MT = (TOT + 63) / 64;
   constexpr int JOBS = NCH * MT;
   constexpr int KROW = 16 * KS;
-  static_assert(OUT::P == P || EPI == EPI_HEAD, "1x1 conv keeps the grid");
+  static_assert(OUT::P == P || EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "1x1 conv keeps the grid");
+  static_assert(IN::FS == OUT::FS && IN::FS == ADDB::FS, "one frame stride per stage");
   static_assert(IN::S >= 16 * (KS - 1) + BW && (BW == 4 || BW == 8 || BW == 16), "the pixel vector must cover all k-steps");
   const int g = lane >> 4, c = lane & 15;
   int j0, j1;
@@ -479,7 +505,7 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
     const int q = mt * 64 + lane;
     const int qc = min(q, TOT - 1);
     const int f = qc / P, p = qc - f * P;
-    char* fbase = frames + f * FRAME_BYTES;
+    char* fbase = frames + f * IN::FS;
     v4i b[KS];
     {
       const char* src = fbase + IN::at_p(p);
@@ -548,7 +574,7 @@ YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, cons
     const int qc = min(q, TOT - 1);
     const int f = qc / P, p = qc - f * P;
     const int oy = p / W1, ox = p - oy * W1;
-    char* fbase = frames + f * FRAME_BYTES;
+    char* fbase = frames + f * IN::FS;
     // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
     const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
@@ -591,12 +617,13 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
   constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
   constexpr int TS = IN::S, TR = IN::RS * IN::S;            // tap strides: +1 column, +1 row
   static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
+  static_assert(IN::FS == OUT::FS, "one frame stride per stage");
   static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
   const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);      // surplus lanes duplicate the last column (idempotent)
-  const int lane_in = fl * FRAME_BYTES + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
-  const int lane_out = fl * FRAME_BYTES + (g * W + xl) * OUT::S;
+  const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
+  const int lane_out = fl * IN::FS + (g * W + xl) * OUT::S;
   const bool a_on = (c >> 2) == g;                          // A row r = c belongs to row block r>>2
   int j, j1;
   job_range<JOBS, NW>(wave, j, j1);
@@ -625,7 +652,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
       const int rb = rem / NSEG, seg = rem - rb * NSEG;
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
-      char* fb = frames + fp * FL * FRAME_BYTES;
+      char* fb = frames + fp * FL * IN::FS;
       const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
 #if YF_EXP == 5    // what-if (wrong results): no LDS reads of the taps
       { const int u = (int)(uintptr_t)src; b0 = v4i{u, u + 1, u + 2, u + 3}; b1 = v4i{u + 4, u + 5, u + 6, u + 7}; b2[0] = u + 8; }
@@ -702,7 +729,7 @@ YF_STAGE_FN void pool8_h(char* frames, int tid) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
     const int y = t % IH; const int f = t / IH;
-    char* fbase = frames + f * FRAME_BYTES;
+    char* fbase = frames + f * B_T4::FS;
     const char* row = fbase + B_T4::at(y, 0) + 4 * cg;
     char* dst = fbase + B_HB::OFF + (y * OW) * 20 + 4 * cg;
     pool8_sweep<NO, B_T4::W - 1>(min(k * NO, OW - NO),
@@ -718,7 +745,7 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
     const int cg = i % 5; int t = i / 5;
     const int k = t % NCH; t /= NCH;
     const int ox = t % OW; const int f = t / OW;
-    char* fbase = frames + f * FRAME_BYTES;
+    char* fbase = frames + f * B_HB::FS;
     const char* col = fbase + B_HB::OFF + ox * 20 + 4 * cg;
     char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
     pool8_sweep<NO, B_HB::H - 1>(min(k * NO, OH - NO),
@@ -727,21 +754,22 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
   }
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
-template <int F, int NT>
+template <int F, int NT, class T15 = B_T15, class T30 = B_T30>
 YF_STAGE_FN void pool25(char* frames, int tid) {
-  constexpr int PP = B_T30::P, OW = B_T30::W, LIM = B_T15::W - 1;
+  constexpr int PP = T30::P, OW = T30::W, LIM = T15::W - 1;
+  static_assert(T15::FS == T30::FS, "one frame stride per stage");
   for (int i = tid; i < F * PP * 6; i += NT) {
     const int cg = i % 6; int t = i / 6;
     const int p = t % PP; const int f = t / PP;
     const int oy = p / OW, ox = p - oy * OW;
-    char* fbase = frames + f * FRAME_BYTES;
+    char* fbase = frames + f * T15::FS;
     SplitB m;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
-        m = m.mx(SplitB(lds_u32(fbase + B_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
-    *reinterpret_cast<uint32_t*>(fbase + B_T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
+        m = m.mx(SplitB(lds_u32(fbase + T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
+    *reinterpret_cast<uint32_t*>(fbase + T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
   }
 }
 
@@ -757,7 +785,7 @@ __device__ __forceinline__ void dump_buf(const char* frames, int8_t* dump, long 
     const int p = t % B::P; const int f = t / B::P;
     if (first_frame + f >= n_frames) continue;
     const int phys = ch0 + ch + (ch >= split ? gap : 0);
-    dump[(first_frame + f) * stride + off + (long)p * C + ch] = (int8_t)frames[f * FRAME_BYTES + B::at_p(p) + phys];
+    dump[(first_frame + f) * stride + off + (long)p * C + ch] = (int8_t)frames[f * B::FS + B::at_p(p) + phys];
   }
 }
 
@@ -782,17 +810,27 @@ struct NetParams {
   int* counts;            // [n] candidates per frame (may exceed cap)
   int cap, mode;          // YF_DECODE_PY / YF_DECODE_FW
   float w_scale, h_scale;
+  char* scratch;          // tail batching: gridDim.x * F * TailBufs::T15_BYTES bytes (a workgroup parks one group's T15 there)
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
+
+#ifndef YF_TAIL_BATCH
+#define YF_TAIL_BATCH (YF_EXP == 1)
+#endif
+template <bool DUMP> constexpr bool tail_batch() { return !DUMP && (YF_TAIL_BATCH); }
 
 template <int F, int NW, bool DUMP>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
-  constexpr int OUT_ALL_BYTES = (F * OUT_FRAME_BYTES + 15) & ~15;
+  constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
+  constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
+  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
   char* out_all = smem + LUT_BYTES;
   char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
+  long parked_first = -1;                                // first frame of the group whose T15 waits in the scratch
   const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab = prm.tab;
   int vz = 0;
@@ -911,59 +949,114 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
-    pool25<F, NT>(frames, tid_t);                                                              // pool_25 + QUANTIZE#45
-    dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), W_t, L_t, vz);   // conv2d_27
-    YF_SYNC(); YF_DUMP(B_T30, 24, Q45) YF_DUMP(B_T17, 24, T17)
+    // ---- the 7x7 tail.  BATCH: it runs once per PAIR of groups on FT = 2F frames.  Its thirteen stages are latency chains
+    // (98 pixels per group: one or two jobs per wave), so twice the jobs per stage cost far less than twice the time.  The
+    // first group of a pair parks its T15 (5.4 KB per frame) in a per-workgroup HBM scratch and skips the tail; the second
+    // group fetches it back into the odd tail sets -- set f of the tail sits at f * FRAME_BYTES / 2, so the even sets ARE the
+    // arenas' own T15 -- and runs the tail for both.  A workgroup's last group runs the tail alone when it has no partner.
+    long odd_first = -1;                          // first frame of the odd sets (the parked group), -1: none
+    if constexpr (BATCH) {
+      constexpr int V = U::T15_BYTES / 16;
+      uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * (F * V);
+      if (parked_first < 0 && grp + gridDim.x < n_groups) {
+        for (int i = tid_t; i < F * V; i += NT) {
+          const int f = i / V, k = i - f * V;
+          park[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_BYTES + 16 * k);
+        }
+        parked_first = first;
+        continue;
+      }
+      if (parked_first >= 0) {
+        for (int i = tid_t; i < F * V; i += NT) {
+          const int f = i / V, k = i - f * V;
+          *reinterpret_cast<uint4*>(frames + (2 * f + 1) * U::T15::FS + 16 * k) = park[i];
+        }
+        odd_first = parked_first;
+        parked_first = -1;
+        YF_SYNC();
+      }
+    }
+    // frame number of tail set f (BATCH: even sets = this group, odd sets = the parked one), -1 = nothing to write
+    auto frame_of = [&](int f) -> long {
+      long id = first + f;
+      if constexpr (BATCH) id = (f & 1) ? (odd_first >= 0 ? odd_first + (f >> 1) : -1) : first + (f >> 1);
+      return id < prm.n ? id : -1;
+    };
+#define YF_DUMP_T(BUF, C, OFF, ...) \
+  if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
+    pool25<FT, NT, typename U::T15, typename U::T30>(frames, tid_t);                                  // pool_25 + QUANTIZE#45
+    dw_mfma_stage<FT, NW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), W_t, L_t, vz);   // conv2d_27
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, 2, 16, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t, vz);
-    decode_prev(W_t, L_t);                                                                         // previous group's boxes
-    YF_SYNC(); YF_DUMP(B_T18, 8, T18)
+    dense_stage<FT, NW, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t, vz);
+    if constexpr (!BATCH) decode_prev(W_t, L_t);                                                    // previous group's boxes
+    YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
-    dense_stage<F, NW, 3, 1, 8, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, W_t, L_t, vz);  // conv2d_30
-    YF_SYNC(); YF_DUMP(B_T19, 40, T19)
+    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
+    dense_stage<FT, NW, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, W_t, L_t, vz);  // conv2d_30
+    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
     YF_STAGE_END()
-    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), W_t, L_t, vz);   // conv2d_32
-    YF_SYNC(); YF_DUMP(B_T20, 40, T20)
+    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), W_t, L_t, vz);   // conv2d_32
+    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T20)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, 3, 16, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t, vz);
-    YF_SYNC(); YF_DUMP(B_T22, 8, T22)
+    dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t, vz);
+    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
-    dense_stage<F, NW, 3, 1, 8, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, W_t, L_t, vz);  // conv2d_36
-    YF_SYNC(); YF_DUMP(B_T19, 40, T23)
+    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
+    dense_stage<FT, NW, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, W_t, L_t, vz);  // conv2d_36
+    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
     YF_STAGE_END()
-    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), W_t, L_t, vz);   // conv2d_38
-    YF_SYNC(); YF_DUMP(B_T20, 40, T24)
+    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), W_t, L_t, vz);   // conv2d_38
+    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T24)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, 3, 16, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t, vz);
-    YF_SYNC(); YF_DUMP(B_T26, 8, T26)
+    dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t, vz);
+    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26)
     YF_STAGE_END()
-    dense_stage<F, NW, 2, 1, 8, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44, B_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, W_t, L_t, vz);  // conv2d_42 -> concat_46
-    YF_SYNC(); YF_DUMP(B_T30, 48, T30)
+    dense_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, W_t, L_t, vz);  // conv2d_42 -> concat_46
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30)
     YF_STAGE_END()
-    fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
-    dense_stage<F, NW, 2, 3, 16, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t, vz);
-    YF_SYNC(); YF_DUMP(B_T19, 40, T31)
+    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
+    dense_stage<FT, NW, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t, vz);
+    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T31)
     YF_STAGE_END()
-    dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), W_t, L_t, vz);   // conv2d_49
-    YF_SYNC(); YF_DUMP(B_T20, 40, T32)
+    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), W_t, L_t, vz);   // conv2d_49
+    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T32)
     YF_STAGE_END()
-    dense_stage<F, NW, 2, 3, 16, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t, vz);
-    YF_SYNC(); YF_DUMP(B_T33, 32, T33)
+    dense_stage<FT, NW, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t, vz);
+    YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
     YF_STAGE_END()
-    dense_stage<F, NW, 1, 2, 16, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
-    YF_SYNC();
-    {   // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
+    if constexpr (!BATCH) {
+      dense_stage<FT, NW, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
+      YF_SYNC();
+      // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
       const long valid = min((long)F, prm.n - first);
       const int n16 = (int)(valid * (OUT_FRAME_BYTES / 2));
       uint16_t* dst = reinterpret_cast<uint16_t*>(prm.out + first * OUT_FRAME_BYTES);
       const uint16_t* srcp = reinterpret_cast<const uint16_t*>(out_all);
       for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
       prev_first = first;
+    } else {
+      dense_stage<FT, NW, 1, 2, 16, typename U::T33, typename U::HEAD, 0, 18, EPI_HEAD_LDS, 0, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
+      YF_SYNC();
+      // heads: 882 bytes per frame from its set -> HBM, 2-byte granules; the boxes of set w are decoded by wave w meanwhile
+      constexpr int H16 = OUT_FRAME_BYTES / 2;
+      for (int i = tid_t; i < FT * H16; i += NT) {
+        const int f = i / H16, k = i - f * H16;
+        const long id = frame_of(f);
+        if (id >= 0) reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES)[k] = *reinterpret_cast<const uint16_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF + 2 * k);
+      }
+      for (int f = W_t; f < FT; f += NW) {
+        const long id = frame_of(f);
+        if (prm.dets != nullptr && id >= 0) {
+          int dl = L_t;
+          asm volatile("" : "+v"(dl));
+          yfdec::decode_frame(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap);
+        }
+      }
     }
+#undef YF_DUMP_T
   }
-  {   // boxes of this workgroup's last group
+  if constexpr (!BATCH) {   // boxes of this workgroup's last group
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
   }
@@ -972,8 +1065,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #undef YF_SYNC
 }
 
-template <int F, int NW>
-constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+template <int F, int NW, bool DUMP>
+constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+template <bool DUMP>
+constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 
 #else   // YF_GENERIC
 // ------------------------------------------------------------------------------------------------ layer-by-layer form
