@@ -815,7 +815,7 @@ struct NetParams {
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
 #ifndef YF_TAIL_BATCH
-#define YF_TAIL_BATCH (YF_EXP == 1)
+#define YF_TAIL_BATCH 1
 #endif
 template <bool DUMP> constexpr bool tail_batch() { return !DUMP && (YF_TAIL_BATCH); }
 
