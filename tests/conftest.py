@@ -40,6 +40,9 @@ def golden():
 @pytest.fixture(scope="session")
 def network(yf):
     """The library's single network instance, initialised on cuda:0 (GPU tests only)."""
+    import torch
+    torch.cuda.is_available()       # let torch bring up its HIP context first: asked only after the library has initialised the
+                                    # GPU in this process, torch reports no device (seen when a single test file is run alone)
     net = yf.Network(device=0).init()
     yield net
     net.destroy()

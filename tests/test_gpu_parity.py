@@ -151,6 +151,27 @@ def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), a[perm])                # frames are independent
 
 
+def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
+    """The fused kernel parks one group's T15 per workgroup in an HBM scratch (tail batching).  Launches of one network
+    instance that overlap on different streams must not share those slots: two streams, twelve launches each of different
+    batches and different (odd) sizes, issued alternately without synchronisation; every head is compared with the oracle."""
+    torch = torch_cuda
+    sizes = [4096, 2050]
+    xs = [rnd(21 + k, sizes[k]) for k in range(2)]
+    refs = [oracle.run(x, threads=16) for x in xs]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    d_ins = [torch.from_numpy(x).cuda() for x in xs]
+    d_outs = [[torch.zeros((sizes[k], 7, 7, 18), dtype=torch.int8, device="cuda") for _ in range(12)] for k in range(2)]
+    torch.cuda.synchronize()
+    for it in range(12):
+        for k in range(2):
+            network.run_device(d_ins[k].data_ptr(), d_outs[k][it].data_ptr(), sizes[k], streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for it in range(12):
+            assert np.array_equal(d_outs[k][it].cpu().numpy(), refs[k]), (k, it)
+
+
 def test_full_size_32768_properties(network, oracle, torch_cuda):
     """BASELINE.json configs[2] size (32768 frames, here on one GPU): the batch is 8 shuffled copies of a 4096-frame
     block, so every copy must reproduce the block's heads (checked against the oracle on the block)."""
