@@ -814,6 +814,10 @@ struct NetParams {
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
+#ifndef YF_EXP_MASK
+#define YF_EXP_MASK 0
+#endif
+#define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
 #ifndef YF_TAIL_BATCH
 #define YF_TAIL_BATCH 1
 #endif
@@ -835,10 +839,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   const uint8_t* __restrict__ tab = prm.tab;
   int vz = 0;
   asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
-  // Static issue priority for the first-dispatched half of the workgroup (waves w and w + NW/2 share a SIMD): one wave of
-  // every SIMD pair runs ahead instead of both stalling on the same stage phases.  In-run A/B: -1.9 % kernel time; the
-  // opposite assignment (younger half) costs +3.5 %, per-workgroup priorities do nothing.
-#if YF_EXP != 1
+  // Static issue priority for the first-dispatched half of the workgroup (waves w and w + NW/2 share a SIMD) was worth -1.9 %
+  // in round 1 and nothing in the middle of round 2; with the tail on four frames it COSTS 1.7 % (in-run A/B, twice), so it
+  // is off.  YF_EXP_MASK bit 1 turns it back on in the experimental build.
+#if YF_TOGGLED(1)
   if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
 
@@ -900,7 +904,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const int L_f = tid_f & 63, L_m = tid_m & 63, L_t = tid_t & 63;
     const int W_f = __builtin_amdgcn_readfirstlane(tid_f >> 6), W_m = __builtin_amdgcn_readfirstlane(tid_m >> 6), W_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
     (void)lane; (void)wave;
-    YF_SYNC();                                                         // previous group's arena is dead
+#if !defined(YF_BARPROF) && !YF_TOGGLED(2)
+    // previous group's arena is dead.  LDS-only barrier: __syncthreads() would also wait for the acknowledgements of the
+    // previous group's head / detection / parking stores (vmcnt), which nothing in this group depends on
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    YF_SYNC();
+#endif
     stage_no = 0;
     int tid_s = tid0;
     asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
@@ -945,6 +955,22 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, W_m, L_m, vz);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
+    // BATCH: the parked group's T15 goes from the scratch straight into the odd tail sets by LDS-DMA (no registers), issued
+    // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through -- so that it lands during conv2d_23; the
+    // barrier behind conv2d_23 waits for it (vmcnt).  One wave-instruction moves 64 x 16 contiguous bytes.
+    if constexpr (BATCH && !YF_TOGGLED(4)) {
+      if (parked_first >= 0) {
+        constexpr int PV = TailBufs<FRAME_BYTES>::T15_BYTES / 16, WI = (PV + 63) / 64;      // vectors / wave-instructions per frame
+        const char* park = prm.scratch + (long)blockIdx.x * (F * PV * 16);
+        for (int j = W_m; j < F * WI; j += NW) {
+          const int f = j / WI, k0 = (j - f * WI) * 64;
+          if (k0 + L_m < PV)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(park + (f * PV + k0 + L_m) * 16),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(LUT_BYTES + (2 * f + 1) * U::T15::FS + 16 * k0),
+                                             16, 0, 0);
+        }
+      }
+    }
     fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
     dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
@@ -966,14 +992,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
         parked_first = first;
         continue;
       }
-      if (parked_first >= 0) {
+      if (parked_first >= 0) {                  // its T15 is already in the odd sets (LDS-DMA issued before conv2d_23)
+#if YF_TOGGLED(4)
         for (int i = tid_t; i < F * V; i += NT) {
           const int f = i / V, k = i - f * V;
           *reinterpret_cast<uint4*>(frames + (2 * f + 1) * U::T15::FS + 16 * k) = park[i];
         }
+        YF_SYNC();
+#endif
         odd_first = parked_first;
         parked_first = -1;
-        YF_SYNC();
       }
     }
     // frame number of tail set f (BATCH: even sets = this group, odd sets = the parked one), -1 = nothing to write
