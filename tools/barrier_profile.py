@@ -33,7 +33,7 @@ labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_
 # tail batching: the profiled (second) group of a workgroup fetches the parked group's T15 behind conv2d_23 and then runs the
 # tail for four frames; its interval times are per PAIR of groups
 k23 = next(i for i, nm in enumerate(labels) if nm.startswith("conv2d_23"))
-labels = labels[:k23 + 1] + ["parked T15 -> odd tail sets"] + [nm + "   [4 frames]" for nm in labels[k23 + 1:]]
+labels = labels[:k23 + 1] + [nm + "   [4 frames]" for nm in labels[k23 + 1:]]    # the parked T15 returns by LDS-DMA during conv2d_23
 print(f"{'interval ending at barrier':44s} {'work mean':>10s} {'slowest':>9s} {'wait mean':>10s}   work per wave")
 for i in range(1, nb):
     b, w = body[:, :, i], wait[:, :, i]
