@@ -32,9 +32,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------ LDS plan (bytes, one frame)
 // Buf: OFF byte offset, logical W x H, S bytes per pixel (fp16 channels, padded), RS pixels per row incl. halo, PT/PL halo
 // rows / columns in front of logical pixel (0,0).  Halos hold 0 (the ONNX graph pads with zeros).  Buffers alias by lifetime.
-template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_>
+// FS: bytes between consecutive frames of a stage (only the 7x7 tail runs on two frames: tail batching, see the kernel).
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = 0>
 struct Buf {
-  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_;
+  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_;
   static constexpr int P = W_ * H_;
   __device__ static __forceinline__ int at(int y, int x) { return OFF_ + ((y + PT_) * RS_ + (x + PL_)) * S_; }
   __device__ static __forceinline__ int at_p(int p) {
@@ -65,6 +66,21 @@ typedef Buf< 29040,  7,  7, 16,  7, 0, 0> B_T22;   // c34 + add out
 typedef Buf< 29824,  7,  7, 16,  7, 0, 0> B_T26;   // c40 + add out
 typedef Buf< 30608,  7,  7, 64,  7, 0, 0> B_T33;   // c51 out, 32 ch
 constexpr int LDS_BYTES = 76032;                    // end of B_T14, rounded up to 64
+// The 7x7 tail works on one 33.7 KB SET per frame (the offsets of B_T15 .. B_T33 above); two sets fit the arena, the second
+// one FS = LDS_BYTES / 2 behind the first.
+constexpr int TAIL_FS = LDS_BYTES / 2, TAIL_T15_BYTES = 15 * 15 * 48;
+struct TB {
+  typedef Buf<     0, 14, 14, 48, 15, 1, 1, TAIL_FS> T15;
+  typedef Buf< 10800,  7,  7, 96,  7, 0, 0, TAIL_FS> T30;
+  typedef Buf< 15504,  7,  7, 48,  7, 0, 0, TAIL_FS> T17;
+  typedef Buf< 17856,  7,  7, 16,  7, 0, 0, TAIL_FS> T18;
+  typedef Buf< 18640,  7,  7, 80,  9, 1, 1, TAIL_FS> T19;
+  typedef Buf< 25120,  7,  7, 80,  7, 0, 0, TAIL_FS> T20;
+  typedef Buf< 29040,  7,  7, 16,  7, 0, 0, TAIL_FS> T22;
+  typedef Buf< 29824,  7,  7, 16,  7, 0, 0, TAIL_FS> T26;
+  typedef Buf< 30608,  7,  7, 64,  7, 0, 0, TAIL_FS> T33;
+};
+static_assert(30608 + 7 * 7 * 64 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0, "a tail set fits half the arena");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
 static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * 30 * 16 <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
 
@@ -101,7 +117,7 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }
 template <int EPI, class OUT, int OUT_CH0, class ADDB, int COUT>
 __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_frame, int p, int chq, v4f acc, bool live) {
   if constexpr (EPI == EPI_HEAD) {
-    if (live) {
+    if (live && out_frame != nullptr) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (chq + j < COUT) out_frame[p * COUT + chq + j] = acc[j];
     }
@@ -120,11 +136,14 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
 // ------------------------------------------------------------------------------------------------ dense 1x1, lane-private
 // KS k-steps of 8 input channels (16 bytes of the pixel's fp16 vector each); TPJ passes of 4 output channels share a job's
 // pixel arithmetic and B fragments.
-template <int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB>
-__device__ __forceinline__ void dense_stage(char* lds, float* __restrict__ out_frame, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane) {
+// F frames (IN::FS apart); out_frame / out_frame1: the head's fp32 destination of frame 0 / 1 (nullptr: frame not wanted).
+template <int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int F = 1>
+__device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_frame0, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane,
+                                            float* __restrict__ out_frame1 = nullptr) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
-  constexpr int P = IN::P, MT = (P + 63) / 64, JOBS = NCH * MT, KROW = 8 * KS;
+  constexpr int P1 = IN::P, P = F * P1, MT = (P + 63) / 64, JOBS = NCH * MT, KROW = 8 * KS;
   static_assert(IN::S >= 16 * KS, "the pixel vector must cover every k-step");
+  static_assert(F == 1 || (F == 2 && IN::FS == OUT::FS && IN::FS == ADDB::FS && IN::FS > 0), "frames of a stage share one stride");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
   int j0, j1;
@@ -146,7 +165,11 @@ __device__ __forceinline__ void dense_stage(char* lds, float* __restrict__ out_f
       }
     }
     const int q = mt * 64 + lane;
-    const int p = min(q, P - 1);
+    const int qc = min(q, P - 1);
+    const int f = (F == 1) ? 0 : (qc >= P1 ? 1 : 0);
+    const int p = qc - f * P1;
+    char* lds = lds0 + f * IN::FS;
+    float* out_frame = (F == 2 && f) ? out_frame1 : out_frame0;
     const char* src = lds + IN::at_p(p);
     v8h b[KS];
 #pragma unroll
@@ -168,16 +191,19 @@ __device__ __forceinline__ void dense_stage(char* lds, float* __restrict__ out_f
 // conv1 (RGBX pixels, 8 bytes per tap) and the depthwise convs (4 channels = 8 bytes per tap and group): a k-step carries
 // two taps, nine taps take five k-steps (the last slot pair is empty: its weights are zero, its data whatever tap 8 was).
 // Jobs: 4 output rows x 16 columns (border blocks shifted inwards) x channel group.
-template <int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE>
+template <int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1>
 __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane) {
   constexpr int W = OUT::W, H = OUT::H;
+  constexpr int FL = (F == 2) ? 2 : 1;                             // two 7-wide frames side by side in the 16 lanes of a row tile
+  static_assert(F == 1 || (W <= 8 && IN::FS == OUT::FS && IN::FS > 0), "frame pairs need grids of at most 8 columns");
   constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4;
   constexpr int NG = (C + 3) / 4;                                  // output-channel groups of 4
   constexpr int JPG = NRB * NSEG, JOBS = NG * JPG;
   constexpr int DROW = STRIDE * IN::RS * IN::S, TS = IN::S, TR = IN::RS * IN::S;
   const int g = lane >> 4, c = lane & 15;
-  const int xl = min(c, W - 1);
-  const int lane_in = g * DROW + xl * STRIDE * IN::S;
+  const int fl = (FL == 2) ? (c >> 3) : 0;
+  const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);
+  const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;
   const bool a_on = (c >> 2) == g;
   int j, j1;
   job_range<JOBS, NW>(wave, j, j1);
@@ -211,20 +237,21 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       }
       const int oy = oy0 + g, ox = x0 + xl;
       uint2 v; v.x = pack2(leaky(acc[0]), leaky(acc[1])); v.y = pack2(leaky(acc[2]), leaky(acc[3]));
-      *reinterpret_cast<uint2*>(lds + OUT::at(oy, ox) + 8 * cg) = v;
+      *reinterpret_cast<uint2*>(lds + fl * OUT::FS + OUT::at(oy, ox) + 8 * cg) = v;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ zero fills
 // halo of a buffer: RING = 1-pixel border all round, otherwise top row + left column
-template <class B, bool RING, int NT>
-__device__ __forceinline__ void fill_halo(char* lds, int tid) {
+template <class B, bool RING, int NT, int F = 1>
+__device__ __forceinline__ void fill_halo(char* lds0, int tid) {
   constexpr int DW = B::S / 4;
   constexpr int HR = B::H + B::PT + (RING ? 1 : 0), WR = B::RS;
   constexpr int NPIX = RING ? (2 * WR + 2 * (HR - 2)) : (WR + HR - 1);
-  for (int i = tid; i < NPIX * DW; i += NT) {
-    const int d = i % DW, k = i / DW;
+  for (int i = tid; i < F * NPIX * DW; i += NT) {
+    const int d = i % DW, kk = i / DW, k = kk % NPIX;
+    char* lds = lds0 + (kk / NPIX) * B::FS;
     int r, c;
     if constexpr (RING) {
       if (k < WR) { r = 0; c = k; }
@@ -284,10 +311,11 @@ __device__ __forceinline__ void pool8_v(char* lds, int tid) {                 //
                         [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = v; });
   }
 }
-template <int NT>
-__device__ __forceinline__ void pool25(char* lds, int tid) {                  // T15 [14][14] x 24 ch -> pool half of concat_46
-  for (int i = tid; i < 49 * 12; i += NT) {
-    const int d = i % 12; const int p = i / 12;
+template <int NT, int F = 1, class B_T15 = yf16::B_T15, class B_T30 = yf16::B_T30>
+__device__ __forceinline__ void pool25(char* lds0, int tid) {                 // T15 [14][14] x 24 ch -> pool half of concat_46
+  for (int i = tid; i < F * 49 * 12; i += NT) {
+    const int d = i % 12; const int pp = i / 12, p = pp % 49;
+    char* lds = lds0 + (pp / 49) * B_T15::FS;
     const int oy = p / 7, ox = p - oy * 7;
     uint32_t m = 0xFC00FC00u;                                                  // -inf, -inf
 #pragma unroll
@@ -300,7 +328,7 @@ __device__ __forceinline__ void pool25(char* lds, int tid) {                  //
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-struct Params { const half_t* in; float* out; long n; const uint8_t* tab; };
+struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; };   // scratch: gridDim.x * TAIL_T15_BYTES
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params prm) {
@@ -316,6 +344,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
   // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).
   // Everything the stages store is finite fp16, so clearing the arena once per workgroup is enough.
   for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+  long parked = -1;                                               // frame whose T15 waits in the scratch
   for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));       // per-lane index arithmetic is recomputed per frame instead of parked in VGPRs for the whole kernel
@@ -365,33 +394,52 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_stage<NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
     __syncthreads();
-    pool25<NT>(lds, tid);                                                                             // pool_25 -> concat_46[0,24)
-    conv3x3_stage<NW, 2, B_T15, B_T17, 24, true>(lds, tab, conv(11), wave, lane);                     // conv2d_27 (dw, stride 2)
+    // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
+    // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
+    // the halo) in a per-workgroup HBM scratch and skips the tail; the second fetches it into tail set 1 (half the arena
+    // behind set 0, which IS this frame's own T15 .. T33) and runs the tail for both.  A workgroup's unpaired last frame runs
+    // the tail alone (set 1 holds stale finite data, its logits are not stored).
+    constexpr int PV = TAIL_T15_BYTES / 16;
+    uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * PV;
+    if (parked < 0 && fr + gridDim.x < prm.n) {
+      for (int i = tid; i < PV; i += NT) park[i] = reinterpret_cast<const uint4*>(lds)[i];
+      parked = fr;
+      continue;
+    }
+    float* out_frame1 = nullptr;
+    if (parked >= 0) {
+      for (int i = tid; i < PV; i += NT) reinterpret_cast<uint4*>(lds + TAIL_FS)[i] = park[i];
+      out_frame1 = prm.out + parked * (7 * 7 * 18);
+      parked = -1;
+      __syncthreads();
+    }
+    pool25<NT, 2, TB::T15, TB::T30>(lds, tid);                                                        // pool_25 -> concat_46[0,24)
+    conv3x3_stage<NW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave, lane);              // conv2d_27 (dw, stride 2)
     __syncthreads();
-    dense_stage<NW, 1, 3, B_T17, B_T18, 0, 8, EPI_LINEAR, B_T18>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
+    dense_stage<NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, 2>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
     __syncthreads();
-    fill_halo<B_T19, true, NT>(lds, tid);
-    dense_stage<NW, 1, 1, B_T18, B_T19, 0, 40, EPI_ACT, B_T19>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
+    fill_halo<TB::T19, true, NT, 2>(lds, tid);
+    dense_stage<NW, 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
     __syncthreads();
-    conv3x3_stage<NW, 1, B_T19, B_T20, 40, true>(lds, tab, conv(14), wave, lane);                     // conv2d_32 (dw)
+    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(14), wave, lane);              // conv2d_32 (dw)
     __syncthreads();
-    dense_stage<NW, 1, 5, B_T20, B_T22, 0, 8, EPI_ADD, B_T18>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
+    dense_stage<NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, 2>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
     __syncthreads();
-    dense_stage<NW, 1, 1, B_T22, B_T19, 0, 40, EPI_ACT, B_T19>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
+    dense_stage<NW, 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
     __syncthreads();
-    conv3x3_stage<NW, 1, B_T19, B_T20, 40, true>(lds, tab, conv(17), wave, lane);                     // conv2d_38 (dw)
+    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(17), wave, lane);              // conv2d_38 (dw)
     __syncthreads();
-    dense_stage<NW, 1, 5, B_T20, B_T26, 0, 8, EPI_ADD, B_T22>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
+    dense_stage<NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, 2>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
     __syncthreads();
-    dense_stage<NW, 1, 1, B_T26, B_T30, 24, 24, EPI_ACT, B_T30>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
+    dense_stage<NW, 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
     __syncthreads();
-    dense_stage<NW, 1, 6, B_T30, B_T19, 0, 40, EPI_ACT, B_T19>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
+    dense_stage<NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
     __syncthreads();
-    conv3x3_stage<NW, 1, B_T19, B_T20, 40, true>(lds, tab, conv(21), wave, lane);                     // conv2d_49 (dw)
+    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(21), wave, lane);              // conv2d_49 (dw)
     __syncthreads();
-    dense_stage<NW, 1, 5, B_T20, B_T33, 0, 32, EPI_ACT, B_T33>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
+    dense_stage<NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
     __syncthreads();
-    dense_stage<NW, 1, 4, B_T33, B_T33, 0, 18, EPI_HEAD, B_T33>(lds, out_frame, tab, conv(23), wave, lane);  // head: fp32 logits -> HBM
+    dense_stage<NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
   }
 }
 
@@ -403,10 +451,12 @@ namespace {
     (ctx)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return -1; } } while (0)
 }
 
+constexpr int FP16_PARK_REGIONS = 4;          // launches rotate through the regions: overlapping launches on different streams never share a slot
 struct yf_fp16 {
   int device = 0;
   int cus = 0;
   uint8_t* d_tab = nullptr;
+  char* d_park = nullptr; size_t park_region = 0; unsigned park_next = 0;
   std::string err;
 };
 
@@ -418,6 +468,7 @@ void yf_fp16_destroy(yf_fp16* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_tab) (void)hipFree(c->d_tab);
+  if (c->d_park) (void)hipFree(c->d_park);
   delete c;
 }
 
@@ -495,6 +546,8 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
       hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_BYTES) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
+  c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup
+  if (hipMalloc((void**)&c->d_park, c->park_region * FP16_PARK_REGIONS) != hipSuccess) { yf_fp16_destroy(c); return fail("allocating the fp16 tail scratch failed"); }
   *out = c;
   return 0;
 }
@@ -507,6 +560,7 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
   HIPCHK(c, hipSetDevice(c->device));
   yf16::Params prm;
   prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab;
+  prm.scratch = c->d_park + (size_t)(c->park_next++ % FP16_PARK_REGIONS) * c->park_region;
   long grid = (long)c->cus * 2;                              // two 76 KB workgroups per CU, persistent over the frames
   if (grid > n) grid = n;
   hipLaunchKernelGGL(yf16::yoloface56_f16_fused<8>, dim3((unsigned)grid), dim3(512), yf16::LDS_BYTES, (hipStream_t)stream, prm);
