@@ -151,6 +151,30 @@ def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), a[perm])                # frames are independent
 
 
+@pytest.mark.parametrize("shape", [(2, 8), (1, 4), (4, 8)])
+def test_tail_pairing_patterns(network, oracle, torch_cuda, shape):
+    """Tail batching runs the 7x7 stages once per PAIR of a workgroup's frame groups.  Batch sizes around the multiples of the
+    resident grid give workgroups with 1, 2, 3, 4 ... groups (paired, unpaired last, half-filled last group); frames are drawn
+    from a 256-frame block whose heads come from the oracle, so every head of every batch is compared."""
+    torch = torch_cuda
+    block = rnd(31, 256)
+    ref = oracle.run(block, threads=16)
+    rng = np.random.default_rng(32)
+    network.configure(*shape)
+    try:
+        for n in (511, 1023, 1024, 1025, 2047, 2049, 3071, 3073, 5001):
+            pick = rng.integers(0, 256, n)
+            d_in = torch.from_numpy(block[pick]).cuda()
+            d_out = torch.full((n + 1, 7, 7, 18), 55, dtype=torch.int8, device="cuda")
+            network.run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            assert np.array_equal(got[:n], ref[pick]), (shape, n)
+            assert (got[n] == 55).all()
+    finally:
+        network.configure(2, 8)
+
+
 def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
     """The fused kernel parks one group's T15 per workgroup in an HBM scratch (tail batching).  Launches of one network
     instance that overlap on different streams must not share those slots: two streams, twelve launches each of different
