@@ -113,6 +113,26 @@ def secondary_configs(net, dev, stream):
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
                            "kernel": "band_k1..band_k4: four launches, each a group of fused stages over row bands staged through LDS (DESIGN.md, 160x160)"}
     del d_in, d_out
+    # camera-format pipeline: 112x112 RGB565 frames -> heads + firmware-mode boxes, the frame preparation
+    # fused into the kernel's input staging (ONE launch) against the two-launch form (separate preparation kernel)
+    n = 4096
+    d_raw = torch.from_numpy(rng.integers(0, 256, (n, 112 * 112 * 2), dtype=np.uint8)).to(dev)
+    d_x = torch.zeros((n, 56, 56, 3), dtype=torch.int8, device=dev)
+    d_h = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device=dev)
+    d_d = torch.zeros((n, 4, 28), dtype=torch.uint8, device=dev)
+    d_c = torch.zeros((n,), dtype=torch.int32, device=dev)
+    one = lambda: net.run_camera_device(d_raw.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), 4, stream=sp)      # noqa: E731
+
+    def two():
+        net.prepare_rgb565_device(d_raw.data_ptr(), d_x.data_ptr(), n, sp)
+        net.run_decode_device(d_x.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), 4, 1, 1.0, 1.0, sp)
+    for _ in range(3):
+        one(); two()
+    ms1, ms2 = event_time_ms(stream, one, 20), event_time_ms(stream, two, 20)
+    out["camera_rgb565_112x112"] = {"workload": "batch=4096 camera frames (112x112 big-endian RGB565, 25 088 B each) -> int8 heads + firmware-mode boxes",
+                                    "ms_per_step": round(ms1, 4), "images_per_s": round(n / ms1 * 1e3, 1),
+                                    "two_launch_form_ms_per_step": round(ms2, 4), "two_launch_form_images_per_s": round(n / ms2 * 1e3, 1)}
+    del d_raw, d_x, d_h, d_d, d_c
     n = 4096
     net.fp16_init()
     d_in = torch.from_numpy((rng.integers(0, 256, (n, 56, 56, 3)).astype(np.float32) / 255).astype(np.float16)).to(dev)

@@ -256,6 +256,14 @@ YF_API long yf_network_all_gather_device(ai_handle network, void* nccl_comm, con
                                          size_t bytes_per_rank, void* stream);
 /* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
+/* The firmware's whole per-frame pipeline in ONE launch (stm32/User/main.c:42-54): camera frames d_rgb565 uint8[n][112][112][2]
+ * (big-endian RGB565, as OV_Frame.c leaves them in RGB_DATA; 16-byte aligned) -> resize_rgb565_uint8_112_to_56_direct +
+ * prepare_yolo_data (yoloface.c:26-93, inside the kernel's input staging: the prepared int8 frame never exists in HBM) ->
+ * ai_network_run -> heads d_heads int8[n][7][7][18] -> post_process when d_dets != NULL (records and counts as
+ * yf_network_run_decode_device; pass d_dets = NULL for heads only).  Same results as yf_network_prepare_rgb565_device followed by
+ * yf_network_run_decode_device.  Returns n or <= 0. */
+YF_API long yf_network_run_camera_device(ai_handle network, const void* d_rgb565, void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                         void* d_dets, void* d_counts, int cap, void* stream);
 /* `iters` back-to-back launches of the fused kernel on `stream`, bracketed by HIP events on that stream;
  * *ms_per_launch receives the average.  Synchronises the stream. */
 YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_out, long n, int iters, void* stream,

@@ -85,7 +85,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_destroy", "ai_network_get_info", "ai_network_get_report", "ai_network_data_weights_get",
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
-           "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_time_device",
+           "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
@@ -156,6 +156,8 @@ def load():
     lib.yf_network_run_decode_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
     lib.yf_network_prepare_rgb565_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_run_camera_device.restype = cl
+    lib.yf_network_run_camera_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_shard_range.restype = None
     lib.yf_network_shard_range.argtypes = [cl, ctypes.c_int, ctypes.c_int, ctypes.POINTER(cl), ctypes.POINTER(cl)]
     lib.yf_network_all_gather_device.restype = cl
@@ -312,6 +314,11 @@ class Network:
         """Network + box decode in one launch (heads are decoded while still in LDS)."""
         if self.lib.yf_network_run_decode_device(self.handle, d_in, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
             self._raise("yf_network_run_decode_device")
+
+    def run_camera_device(self, d_rgb565, d_heads, n, d_dets=None, d_counts=None, cap=0, mode=YF_DECODE_FW, w_scale=1.0, h_scale=1.0, stream=None):
+        """Camera frames (112x112 big-endian RGB565) -> heads (+ detection records) in one launch."""
+        if self.lib.yf_network_run_camera_device(self.handle, d_rgb565, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
+            self._raise("yf_network_run_camera_device")
 
     def prepare_rgb565_device(self, d_rgb, d_out, n, stream=None):
         if self.lib.yf_network_prepare_rgb565_device(self.handle, d_rgb, d_out, n, stream) != n:

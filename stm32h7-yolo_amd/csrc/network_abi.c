@@ -391,6 +391,13 @@ YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rg
   return finish(c, yf_engine_prepare_rgb565_device(c->engine, d_rgb565, d_out, n, stream), n);
 }
 
+YF_API long yf_network_run_camera_device(ai_handle network, const void* d_rgb565, void* d_heads, long n, int mode, float w_scale, float h_scale,
+                                         void* d_dets, void* d_counts, int cap, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_run_camera_device(c->engine, d_rgb565, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream), n);
+}
+
 YF_API long yf_network_time_device(ai_handle network, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch) {
   yf_context* c = ready(network);
   if (!c) return 0;

@@ -36,6 +36,9 @@ int  yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode
 int  yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,
                                  void* d_dets, void* d_counts, int cap, void* stream);
 int  yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream);
+/* camera frames -> heads (+ detections if d_dets != NULL) in one launch: frame preparation fused into the input staging */
+int  yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, int mode, float w_scale, float h_scale,
+                                 void* d_dets, void* d_counts, int cap, void* stream);
 /* 160x160 frames (int8 [n][160][160][3] -> [n][20][20][18]): layer-by-layer over an engine-owned HBM arena */
 int  yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n, void* stream);
 long yf_engine_dump_bytes(void);

@@ -83,17 +83,20 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 
 typedef void (*fused_fn)(const yf::NetParams);
 static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
-struct Variant { int f, nw; bool dump; bool exp; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
+struct Variant { int f, nw; bool dump; bool exp; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
 
-#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
-#define YF_VARIANT_X(F, NW) { F, NW, false, true, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<false>(), \
+#define YF_VARIANT_CAM(F, NW) { F, NW, false, false, true, (fused_fn)yf::yoloface56_fused<F, NW, false, true>, yf::lds_bytes<F, NW, false>(), \
+                                yf::scratch_bytes_per_frame_slot<false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input>" }
+#define YF_VARIANT_X(F, NW) { F, NW, false, true, false, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<false>(), \
                               "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
 // production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
 const Variant k_variants[] = {
   YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
   YF_VARIANT(2, 4, true), YF_VARIANT(2, 8, true),
   YF_VARIANT_X(2, 8),
+  YF_VARIANT_CAM(2, 8),           // camera-format input (112x112 RGB565), the shipped shape only
 };
 
 }  // namespace
@@ -117,8 +120,8 @@ struct yf_engine {
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
-static const Variant* find_variant(int f, int nw, bool dump, bool exp = false) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.exp == exp) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool exp = false, bool cam = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.exp == exp && v.cam == cam) return &v;
   return nullptr;
 }
 
@@ -316,6 +319,20 @@ int yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, lon
   HIPCHK(e, hipSetDevice(e->device));
   const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
   return launch(e, e->var, d_in, d_out, nullptr, n, (hipStream_t)stream, -1, &dec);
+}
+
+// camera frames (112x112 big-endian RGB565) -> heads (+ boxes when d_dets is given): the frame preparation runs inside the
+// fused kernel's input staging.  Only the shipped shape has this build.
+int yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, int mode, float w_scale, float h_scale,
+                                void* d_dets, void* d_counts, int cap, void* stream) {
+  if (!e || !d_rgb565 || !d_out || n < 0) return YF_ENG_ERR_ARG;
+  if (d_dets && (!d_counts || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST))) return YF_ENG_ERR_ARG;
+  if (((uintptr_t)d_rgb565 & 15) != 0) { e->err = "camera frames must be 16-byte aligned"; return YF_ENG_ERR_ARG; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const Variant* v = find_variant(e->var->f, e->var->nw, false, false, true);
+  if (!v) { e->err = "no camera-input build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
+  const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
+  return launch(e, v, d_rgb565, d_out, nullptr, n, (hipStream_t)stream, -1, d_dets ? &dec : nullptr);
 }
 
 int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {

@@ -423,6 +423,50 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
   }
 }
 
+// Camera-format input (the frame preparation fused into conv2d_1's load).  The firmware's
+// resize_rgb565_uint8_112_to_56_direct + prepare_yolo_data (yoloface.c:26-93): 112x112 big-endian RGB565 -> 2x2 box average per
+// 5/6/5 field (sum of four >> 2) -> re-packed RGB565 -> shift-expanded to 8 bits -> value - 128 as int8.  One item = four
+// output pixels of one row = two 16-byte loads (source rows 2y, 2y+1), packed-field arithmetic on pixel PAIRS, one 16-byte
+// LDS store of RGBX dwords.  (v - 128) as int8 is v ^ 0x80; ((sum >> 2) << 3) is (sum & 0x7C) << 1; green (sum >> 2) << 2 is sum & 0xFC.
+constexpr int CAM_FRAME_BYTES = 112 * 112 * 2;
+__device__ __forceinline__ uint32_t cam_pixel(uint32_t s0, uint32_t s1) {     // s0, s1: the pixel pair of rows 2y / 2y+1, halves byte-swapped to values
+  const uint32_t r = ((s0 >> 11) & 0x001F001Fu) + ((s1 >> 11) & 0x001F001Fu);
+  const uint32_t g = ((s0 >> 5) & 0x003F003Fu) + ((s1 >> 5) & 0x003F003Fu);
+  const uint32_t b = (s0 & 0x001F001Fu) + (s1 & 0x001F001Fu);
+  const uint32_t rs = r + (r >> 16), gs = g + (g >> 16), bs = b + (b >> 16);   // low halves: sums of the four pixels
+  return (((rs & 0x7Cu) << 1) | ((gs & 0xFCu) << 8) | ((bs & 0x7Cu) << 17)) ^ 0x00808080u;
+}
+template <int F, int NT>
+YF_STAGE_FN void stage_input_cam(char* frames, const uint8_t* __restrict__ cam, long first_frame, long n_frames, int zp, int tid) {
+  const uint32_t hv = (uint32_t)(zp & 255) * 0x01010101u;
+  constexpr int RSW = B_IN::RS, HH = B_IN::H, WQ = B_IN::W / 4;
+  constexpr int PER_FRAME = HH * WQ, TOTAL = F * PER_FRAME;
+  for (int i = tid; i < F * (RSW + HH); i += NT) {                 // halo: row 0 and dword column 3 of rows 1..HH
+    const int f = i / (RSW + HH), k = i - f * (RSW + HH);
+    const int idx = k < RSW ? k : (k - RSW + 1) * RSW + 3;
+    *reinterpret_cast<uint32_t*>(frames + f * B_IN::FS + B_IN::OFF + idx * 4) = hv;
+  }
+  const long rest = n_frames - 1 - first_frame;
+  const int lastf = __builtin_amdgcn_readfirstlane((int)(rest < (long)(F - 1) ? rest : (long)(F - 1)));
+  const uint8_t* base = cam + first_frame * CAM_FRAME_BYTES;
+  for (int i = tid; i < TOTAL; i += NT) {
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
+    const int r = i - f * PER_FRAME;
+    const int y = (int)((uint32_t)r / (uint32_t)WQ), xq = r - y * WQ;
+    const uint8_t* src = base + (uint32_t)(min(f, lastf) * CAM_FRAME_BYTES + (2 * y) * 224 + 16 * xq);
+    const uint4 a = *reinterpret_cast<const uint4*>(src), c = *reinterpret_cast<const uint4*>(src + 224);
+    constexpr uint32_t SWAP = 0x02030001u;                           // bytes of each 16-bit half swapped: big-endian pairs -> values
+    uint4 px;
+    px.x = cam_pixel(__builtin_amdgcn_perm(a.x, a.x, SWAP), __builtin_amdgcn_perm(c.x, c.x, SWAP));
+    px.y = cam_pixel(__builtin_amdgcn_perm(a.y, a.y, SWAP), __builtin_amdgcn_perm(c.y, c.y, SWAP));
+    px.z = cam_pixel(__builtin_amdgcn_perm(a.z, a.z, SWAP), __builtin_amdgcn_perm(c.z, c.z, SWAP));
+    px.w = cam_pixel(__builtin_amdgcn_perm(a.w, a.w, SWAP), __builtin_amdgcn_perm(c.w, c.w, SWAP));
+    *reinterpret_cast<uint4*>(frames + f * B_IN::FS + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ epilogue store
 // residual add (tflite ADD): the final requantisation's constants are the same for every channel (yf_add, device form)
 struct AddK { uint32_t mo2, zro; unsigned long c64o; int rso; };
@@ -823,7 +867,9 @@ static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit i
 #endif
 template <bool DUMP> constexpr bool tail_batch() { return !DUMP && (YF_TAIL_BATCH); }
 
-template <int F, int NW, bool DUMP>
+// CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
+// preparation runs inside the input staging (stage_input_cam).
+template <int F, int NW, bool DUMP, bool CAM = false>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
@@ -914,7 +960,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     stage_no = 0;
     int tid_s = tid0;
     asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
-    stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
+    if constexpr (CAM) stage_input_cam<F, NT>(frames, reinterpret_cast<const uint8_t*>(prm.in), first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
+    else stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
     fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()

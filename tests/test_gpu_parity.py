@@ -471,6 +471,56 @@ def test_frame_preparation_on_gpu_equals_oracle(network, oracle, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), oracle.run(ref))
 
 
+def test_camera_frames_to_detections_in_one_launch(yf, network, oracle, torch_cuda):
+    """the firmware's frame preparation fused into conv2d_1's load.  yf_network_run_camera_device takes
+    112x112 RGB565 camera frames and returns heads and firmware-mode detection records from ONE launch; both must equal the
+    oracle's prepare -> network -> decode and the library's own two-step path (separate preparation kernel)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(33)
+    n = 2051                                                     # odd: half-filled last group, unpaired tail
+    base = rng.integers(0, 256, (40, 112 * 112 * 2), dtype=np.uint8)
+    base[0] = 0
+    base[1] = 255
+    base[2, 0::2] = 0xF8; base[2, 1::2] = 0x00                   # pure red
+    base[3, 0::2] = 0x07; base[3, 1::2] = 0xE0                   # pure green
+    base[4, 0::2] = 0x00; base[4, 1::2] = 0x1F                   # pure blue
+    pick = rng.integers(0, 40, n); pick[:40] = np.arange(40)
+    raw = base[pick]
+    x_ref = np.stack([oracle.prepare_rgb565(r) for r in base])
+    h_ref = oracle.run(x_ref, threads=16)
+    cap = 8
+    d_raw = torch.from_numpy(raw).cuda()
+    d_h = torch.full((n + 1, 7, 7, 18), 9, dtype=torch.int8, device="cuda")
+    d_d = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_c = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    network.run_camera_device(d_raw.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap, yf.YF_DECODE_FW)
+    torch.cuda.synchronize()
+    heads = d_h.cpu().numpy()
+    assert np.array_equal(heads[:n], h_ref[pick])
+    assert (heads[n] == 9).all()
+    # the two-step path of this library on the same frames
+    d_x = torch.zeros((n, 56, 56, 3), dtype=torch.int8, device="cuda")
+    d_h2 = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+    d_d2 = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_c2 = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    network.prepare_rgb565_device(d_raw.data_ptr(), d_x.data_ptr(), n)
+    network.run_decode_device(d_x.data_ptr(), d_h2.data_ptr(), n, d_d2.data_ptr(), d_c2.data_ptr(), cap, yf.YF_DECODE_FW)
+    torch.cuda.synchronize()
+    assert torch.equal(d_h[:n], d_h2) and torch.equal(d_c, d_c2) and torch.equal(d_d, d_d2)
+    # records against the oracle's firmware decode of the oracle's heads
+    dets, counts = d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap), d_c.cpu().numpy()
+    for f in range(64):
+        want = oracle.decode_c(h_ref[pick[f]], f, 147)
+        assert counts[f] == len(want)
+        got = [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in dets[f, :min(cap, counts[f])]]
+        assert got == [(w[1], w[2], w[3], w[6], w[7], w[8], w[9]) for w in want][:cap]
+    # heads only
+    d_h.fill_(9)
+    network.run_camera_device(d_raw.data_ptr(), d_h.data_ptr(), 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_h.cpu().numpy()[:5], h_ref[pick[:5]])
+
+
 def test_interpreter_mirror(oracle, golden, network):
     """tflite_prediction.py:23-41 call sequence on the mirror class (shares the library's single network)."""
     ip = importlib.import_module("stm32h7-yolo_amd.interpreter")
