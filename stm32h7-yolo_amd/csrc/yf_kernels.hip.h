@@ -862,6 +862,15 @@ static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit i
 #define YF_EXP_MASK 0
 #endif
 #define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
+// Issue priority per stage (s_setprio, 0..3), stage order: staging, conv2d_1, 3, 5, 6, pool_8 h, pool_8 v, conv2d_10, 12, 13, 15,
+// 17, 19, 23, then the thirteen tail stages.  See the kernel: a workgroup's priority FALLS as its group advances.
+#ifndef YF_PRIO_LIST
+#define YF_PRIO_LIST 3,3,3,3,3,3,3,3,3,3, 2,2,2,2, 1,1,1,1,1,1, 0,0,0,0,0,0,0
+#endif
+constexpr int STAGE_PRIO[27] = {YF_PRIO_LIST};
+template <int K> __device__ __forceinline__ void stage_prio() {
+  if constexpr (K == 0 || STAGE_PRIO[K] != STAGE_PRIO[K - 1]) __builtin_amdgcn_s_setprio(STAGE_PRIO[K]);
+}
 #ifndef YF_TAIL_BATCH
 #define YF_TAIL_BATCH 1
 #endif
@@ -885,13 +894,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   const uint8_t* __restrict__ tab = prm.tab;
   int vz = 0;
   asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
-  // Static issue priority for the first-dispatched half of the workgroup (waves w and w + NW/2 share a SIMD) was worth -1.9 %
-  // in round 1 and nothing in the middle of round 2; with the tail on four frames it COSTS 1.7 % (in-run A/B, twice), so it
-  // is off.  YF_EXP_MASK bit 1 turns it back on in the experimental build.
+  // Issue priorities.  A static priority for the first-dispatched half of a workgroup was worth -1.9 % in round 1 and costs
+  // 1.7 % with the tail on four frames (YF_EXP_MASK bit 1 turns it back on in the experimental build).  What pays is a priority
+  // LADDER over a group's stages (YF_PRIO_LIST, s_setprio before a stage whenever the level changes): 3 up to conv2d_13, 2 up
+  // to conv2d_23, 1 for the first six tail stages, 0 for the rest.  The two workgroups of a CU are in different phases; the one
+  // in the VALU-bound front stages then issues ahead of the one in the latency-bound tail, which only needs the slots left
+  // over.  -6.8 % kernel time in-run (A/B 1.073 against no ladder); every placement of the three steps tried gave 6.0-7.3 %.
 #if YF_TOGGLED(1)
   if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
 
@@ -919,6 +930,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
   int stage_no = 0;
 #define YF_STAGE_END() if constexpr (DUMP) { if (++stage_no == prm.stop_stage) continue; }
+  // Priority ladder (toggle bit 8 of YF_EXP_MASK switches it OFF in the experimental build)
+#if !YF_TOGGLED(8)
+#define YF_PRIO(K) stage_prio<K>()
+#else
+#define YF_PRIO(K) do {} while (0)
+#endif
 
   // Fused box decode: the staged heads of group g stay in out_all until conv2d_53 of group g+1, so they are decoded by
   // the last F waves DURING conv2d_29 of the next group (a 4-job stage: those waves are idle there), off the critical
@@ -958,6 +975,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC();
 #endif
     stage_no = 0;
+    YF_PRIO(0);
     int tid_s = tid0;
     asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
     if constexpr (CAM) stage_input_cam<F, NT>(frames, reinterpret_cast<const uint8_t*>(prm.in), first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
@@ -965,43 +983,56 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()
+    YF_PRIO(1);
     conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), W_f, L_f, vz);                        // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
+    YF_PRIO(2);
     dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), W_f, L_f, vz);   // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
+    YF_PRIO(3);
     dense_stage<F, NW, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3>(frames, out_all, tab, load_dense(tab, YF_D_C5), no_add, W_f, L_f, vz);   // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
+    YF_PRIO(4);
     fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid_f);
     dense_stage<F, NW, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, out_all, tab, load_dense(tab, YF_D_C6), no_add, W_f, L_f, vz);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
+    YF_PRIO(5);
     pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
     YF_SYNC();
     YF_STAGE_END()
+    YF_PRIO(6);
     pool8_v<F, NT>(frames, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
+    YF_PRIO(7);
     dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), W_m, L_m, vz);   // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
+    YF_PRIO(8);
     dense_stage<F, NW, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C12), no_add, W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
+    YF_PRIO(9);
     fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid_m);
     dense_stage<F, NW, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, out_all, tab, load_dense(tab, YF_D_C13), no_add, W_m, L_m, vz);  // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
+    YF_PRIO(10);
     dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), W_m, L_m, vz);   // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
+    YF_PRIO(11);
     dense_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), W_m, L_m, vz);
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
+    YF_PRIO(12);
     dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, W_m, L_m, vz);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
+    YF_PRIO(13);
     // BATCH: the parked group's T15 goes from the scratch straight into the odd tail sets by LDS-DMA (no registers), issued
     // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through -- so that it lands during conv2d_23; the
     // barrier behind conv2d_23 waits for it (vmcnt).  One wave-instruction moves 64 x 16 contiguous bytes.
@@ -1059,47 +1090,60 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     };
 #define YF_DUMP_T(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
+    YF_PRIO(14);
     pool25<FT, NT, typename U::T15, typename U::T30>(frames, tid_t);                                  // pool_25 + QUANTIZE#45
     dw_mfma_stage<FT, NW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), W_t, L_t, vz);   // conv2d_27
     YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
+    YF_PRIO(15);
     dense_stage<FT, NW, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t, vz);
     if constexpr (!BATCH) decode_prev(W_t, L_t);                                                    // previous group's boxes
     YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
     YF_STAGE_END()
+    YF_PRIO(16);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
     dense_stage<FT, NW, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, W_t, L_t, vz);  // conv2d_30
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
     YF_STAGE_END()
+    YF_PRIO(17);
     dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), W_t, L_t, vz);   // conv2d_32
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T20)
     YF_STAGE_END()
+    YF_PRIO(18);
     dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t, vz);
     YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22)
     YF_STAGE_END()
+    YF_PRIO(19);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
     dense_stage<FT, NW, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, W_t, L_t, vz);  // conv2d_36
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
     YF_STAGE_END()
+    YF_PRIO(20);
     dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), W_t, L_t, vz);   // conv2d_38
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T24)
     YF_STAGE_END()
+    YF_PRIO(21);
     dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t, vz);
     YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26)
     YF_STAGE_END()
+    YF_PRIO(22);
     dense_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, W_t, L_t, vz);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30)
     YF_STAGE_END()
+    YF_PRIO(23);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
     dense_stage<FT, NW, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t, vz);
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T31)
     YF_STAGE_END()
+    YF_PRIO(24);
     dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), W_t, L_t, vz);   // conv2d_49
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T32)
     YF_STAGE_END()
+    YF_PRIO(25);
     dense_stage<FT, NW, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t, vz);
     YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
     YF_STAGE_END()
+    YF_PRIO(26);
     if constexpr (!BATCH) {
       dense_stage<FT, NW, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
       YF_SYNC();
@@ -1137,6 +1181,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   }
 #undef YF_DUMP
 #undef YF_STAGE_END
+#undef YF_PRIO
 #undef YF_SYNC
 }
 
