@@ -1310,6 +1310,14 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
 // halo with them and interior band edges bring real neighbour rows; the producer fills halo columns (and the first / last
 // band the top / bottom halo row) before the copy-out.
 namespace band {
+#ifndef YF_BAND_LADDER
+#define YF_BAND_LADDER 1
+#endif
+#if YF_BAND_LADDER
+#define YF_BAND_PRIO(P) __builtin_amdgcn_s_setprio(P)      // priority ladder over a band job's stages (see the 56x56 kernel)
+#else
+#define YF_BAND_PRIO(P) do {} while (0)
+#endif
 constexpr int LB = LUT_BYTES;                                   // LUTs at LDS offset 0 (absolute addressing)
 // per-frame HBM arena of the banded form (bytes); rows are padded to multiples of 16 bytes so bands move as 16-byte vectors
 constexpr int T4_RS = G1 + 4, T8_RS = G2 + 4, T15_RS = G2 + 2;   // pixels per halo'd row
@@ -1433,6 +1441,7 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     const long fr = job / K1_BANDS;
     const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    YF_BAND_PRIO(3);
     lds_barrier();                                                // previous band's buffers are dead
 #pragma unroll
     for (int k = 0; k < PER; ++k) {                               // RGB -> RGBX dwords behind the halo column
@@ -1454,13 +1463,16 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     if (a == 0) fill_dwords<NT>(frames + L1_T1::OFF, z_t1, (G1 + 2) * 8, tid);                               // T1 row -1 = halo
     if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * (G1 + 2) * 8, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
     if (a == 0 || a + K1_BH == G1) lds_barrier();
+    YF_BAND_PRIO(2);
     dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(1);
     dense_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3>(frames, nullptr, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4>(frames, nullptr, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
     fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
     lds_barrier();
+    YF_BAND_PRIO(0);
     store_rows<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);              // halo'd rows a+1 ..
     if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
   }
@@ -1509,6 +1521,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
     const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;             // first 40x40 row of the band
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
     lds_barrier();
+    YF_BAND_PRIO(3);
     { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L2_T4::OFF + ll * T4_ROW, n16, tid); }
     lds_barrier();
     if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
@@ -1537,14 +1550,17 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
       }
     }
     lds_barrier();                                                 // T6 (written next) aliases HB
+    YF_BAND_PRIO(2);
     dw_mfma_stage<F, NW, 2, L2_T4_DW, L2_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(1);
     dense_stage<F, NW, 1, 2, 16, L2_T6, L2_T7, 0, 6, EPI_RAW, 0, L2_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 3, 1, 8, L2_T7, L2_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L2_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
     fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, 0, K2_BP, z_t8, tid);
     fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, G2 + 1, K2_BP, z_t8, tid);
     lds_barrier();
+    YF_BAND_PRIO(0);
     store_rows<NT>(arena + A_P8 + p0 * (G2 * 20), frames + L2_P8::OFF, K2_BP * G2 * 20, tid);
     store_rows<NT>(arena + A_T7 + p0 * (G2 * 8), frames + L2_T7::OFF, K2_BP * G2 * 8, tid);
     store_rows<NT>(arena + A_T8 + (p0 + 1) * T8_ROW, frames + L2_T8::OFF, K2_BP * T8_ROW, tid);              // halo'd rows p0+1 ..
@@ -1603,6 +1619,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
     const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
     lds_barrier();
+    YF_BAND_PRIO(3);
     pf_commit(pre8, frames + L3_T8::OFF, N_T8, tid);
     pf_commit(pre7, frames + L3_T7::OFF, N_T7, tid);
 #pragma unroll
@@ -1621,13 +1638,16 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
     if (job + gridDim.x < jobs) fetch(job + gridDim.x);
     dw_mfma_stage<F, NW, 1, L3_T8, L3_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(2);
     dense_stage<F, NW, 1, 3, 16, L3_T9, L3_T11, 0, 6, EPI_ADD, YF_A_ADD18, L3_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 2, 1, 8, L3_T11, L3_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L3_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(1);
     dense_stage<F, NW, 2, 3, 16, L3_T14, L3_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L3_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
     fill_column<NT, T15_ROW, 24>(frames + L3_T15::OFF, 0, K3_BP, z_t15, tid);
     lds_barrier();
+    YF_BAND_PRIO(0);
     store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L3_T15::OFF, K3_BP * T15_ROW, tid);
     if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
   }
