@@ -146,7 +146,7 @@ static BandKernel k_band[4] = {
   {(const void*)yf160::band::band_k1<YF_K1_NW>,  "band_k1", YF_K1_NW * 64,  (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
   {(const void*)yf160::band::band_k2<8>,  "band_k2", 512,  (size_t)yf160::band::K2_LDS, yf160::band::K2_BANDS, 1},
   {(const void*)yf160::band::band_k3<8>,  "band_k3", 512,  (size_t)yf160::band::K3_LDS, yf160::band::K3_BANDS, 1},
-  {(const void*)yf160::band::band_k4<16>, "band_k4", 1024, (size_t)yf160::band::K4_LDS, 1, 1},
+  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
 };
 static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
   for (const BandKernel& k : k_band) {

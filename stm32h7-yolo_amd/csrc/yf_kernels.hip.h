@@ -1653,32 +1653,43 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
   }
 }
 
-// ---- K4: the 20x20 tail, whole frame ------------------------------------------------------------------------------------
-typedef Buf<LB,                                   G2, G2, 24, T15_RS, 1, 1> L4_T15;   // as in the arena
-typedef Buf<L4_T15::OFF + (G2 + 1) * T15_ROW,     G3, G3, 48, G3,     0, 0> L4_T30;
-typedef Buf<L4_T30::OFF + G3 * G3 * 48,           G3, G3, 32, G3,     0, 0> L4_T17;
-typedef Buf<L4_T17::OFF + G3 * G3 * 32,           G3, G3,  8, G3,     0, 0> L4_T18;
+// ---- K4: the 20x20 tail ------------------------------------------------------------------------------------------------
+// Two 8-wave workgroups per CU (78 KB each) instead of one 16-wave workgroup with the whole T15 (41 KB) in LDS: the tail's
+// stages are latency chains with few jobs, so two independent frames per CU with twice the jobs per wave are faster, and two
+// workgroups in different phases profit from the priority ladder.  T15 is consumed in two halves of rows (pool_25 and
+// conv2d_27 for output rows 0-9, then 10-19) through the slot that later holds T19 and the small tensors; T17 sits on T20's
+// slot (dead before conv2d_32 writes it), T33 on T19's.
+constexpr int K4_HALF = G3 / 2, K4_ROWS0 = 2 * K4_HALF + 2, K4_ROWS1 = (G2 + 1) - 2 * K4_HALF;      // T15 halo'd rows of the halves
+static_assert(G3 % 2 == 0 && K4_HALF >= 4 && K4_ROWS1 <= K4_ROWS0, "two halves of output rows");
+constexpr int K4_R1 = (G3 + 2) * (G3 + 2) * 40 + 3 * G3 * G3 * 8;                                     // T19 | T18 | T22 | T26
+static_assert(K4_ROWS0 * T15_ROW <= K4_R1, "a T15 half fits the slot of T19 and the small tensors");
+typedef Buf<LB,                                   G2, K4_ROWS0,   24, T15_RS, 0, 1> L4_T15H;  // halo'd rows of one half (halo'd row 0 at OFF)
+typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1> L4_T19;
+typedef Buf<LB + (G3 + 2) * (G3 + 2) * 40,        G3, G3,  8, G3,     0, 0> L4_T18;
 typedef Buf<L4_T18::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T22;
 typedef Buf<L4_T22::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T26;
-typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1> L4_T19;   // aliases T15 (dead after pool_25 / conv2d_27)
-typedef Buf<LB + (G3 + 2) * (G3 + 2) * 40,        G3, G3, 48, G3,     0, 0> L4_T20;   // "
-typedef Buf<L4_T17::OFF,                          G3, G3, 32, G3,     0, 0> L4_T33;   // aliases T17 (dead after conv2d_29)
-constexpr int K4_LDS = L4_T26::OFF + G3 * G3 * 8;
-static_assert(L4_T20::OFF + G3 * G3 * 48 <= L4_T30::OFF, "T19 + T20 fit in T15's slot");
+typedef Buf<LB + K4_R1,                           G3, G3, 48, G3,     0, 0> L4_T20;
+typedef Buf<L4_T20::OFF,                          G3, G3, 32, G3,     0, 0> L4_T17;   // aliases T20
+typedef Buf<L4_T20::OFF,                          G3, K4_HALF, 32, G3, 0, 0> L4_T17A; // rows 0 .. HALF-1 (conv2d_27 writes one half at a time)
+typedef Buf<L4_T20::OFF + K4_HALF * G3 * 32,      G3, K4_HALF, 32, G3, 0, 0> L4_T17B; // rows HALF .. G3-1
+typedef Buf<L4_T20::OFF + G3 * G3 * 48,           G3, G3, 48, G3,     0, 0> L4_T30;
+typedef Buf<LB,                                   G3, G3, 32, G3,     0, 0> L4_T33;   // aliases T19 (dead after conv2d_49)
+constexpr int K4_LDS = L4_T30::OFF + G3 * G3 * 48;
 
-template <int F, int NT>
-YF_STAGE_FN void pool25_band(char* frames, int tid) {        // pool25 of the fused kernel on the L4 buffers
-  constexpr int PP = L4_T30::P, OW = L4_T30::W, LIM = L4_T15::W - 1;
-  for (int i = tid; i < PP * 6; i += NT) {
+// pool_25 for output rows [oy0, oy0 + K4_HALF) from a T15 half whose first halo'd row is h0
+template <int NT>
+YF_STAGE_FN void pool25_half(char* frames, int oy0, int h0, int tid) {
+  constexpr int OW = G3, LIM = G2 - 1;
+  for (int i = tid; i < K4_HALF * OW * 6; i += NT) {
     const int cg = i % 6; const int p = i / 6;
-    const int oy = p / OW, ox = p - oy * OW;
+    const int oy = oy0 + p / OW, ox = p % OW;
     SplitB m;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
-        m = m.mx(SplitB(lds_u32(frames + L4_T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
-    *reinterpret_cast<uint32_t*>(frames + L4_T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
+        m = m.mx(SplitB(lds_u32(frames + L4_T15H::OFF + ((clampi(2 * oy - 1 + ky, 0, LIM) + 1 - h0) * T15_RS + clampi(2 * ox - 1 + kx, 0, LIM) + 1) * 24 + 4 * cg)));
+    *reinterpret_cast<uint32_t*>(frames + L4_T30::at(oy, ox) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
   }
 }
 
@@ -1700,19 +1711,28 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
                 (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   char* frames = smem;
-  constexpr int N_T15 = (G2 + 1) * T15_ROW / 16;
-  Prefetch<NT, N_T15> pre;
+  constexpr int N0 = K4_ROWS0 * T15_ROW / 16, N1 = K4_ROWS1 * T15_ROW / 16, H1 = 2 * K4_HALF;     // halves: vectors, first halo'd row of the second
+  Prefetch<NT, N0> pre;
   long fr = blockIdx.x;
-  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N_T15, tid);
+  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N0, tid);
   for (; fr < prm.n; fr += gridDim.x) {
     char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
+    const char* t15 = prm.arena + fr * (long)ARENA_BYTES + A_T15;
+    YF_BAND_PRIO(3);
     lds_barrier();
-    pf_commit(pre, frames + L4_T15::OFF, N_T15, tid);
+    pf_commit(pre, frames + L4_T15H::OFF, N0, tid);                                   // halo'd rows 0 .. ROWS0-1
     lds_barrier();
-    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N_T15, tid);
-    pool25_band<F, NT>(frames, tid);
-    dw_mfma_stage<F, NW, 2, L4_T15, L4_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
+    pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
+    pool25_half<NT>(frames, 0, 0, tid);
+    dw_mfma_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
     lds_barrier();
+    pf_commit(pre, frames + L4_T15H::OFF, N1, tid);                                   // halo'd rows H1 .. G2
+    lds_barrier();
+    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
+    pool25_half<NT>(frames, K4_HALF, H1, tid);
+    dw_mfma_stage<F, NW, 2, L4_T15H, L4_T17B, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
+    lds_barrier();
+    YF_BAND_PRIO(2);
     dense_stage<F, NW, 1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
     lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
@@ -1720,6 +1740,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
     lds_barrier();
     dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(1);
     dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
     lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
@@ -1729,6 +1750,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
     lds_barrier();
     dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
     lds_barrier();
+    YF_BAND_PRIO(0);
     dense_stage<F, NW, 2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
     lds_barrier();
     fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
