@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the fp16 side configuration (BASELINE configs[3]): 4096 frames, layer-by-layer engine.  DEV TOOL."""
+"""Throughput of the fp16 side configuration (BASELINE configs[3]): 4096 frames through the fused fp16 kernel.  DEV TOOL."""
 import importlib, sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +9,8 @@ x = (np.random.default_rng(3).integers(0, 256, (n, 56, 56, 3)).astype(np.float32
 net = yf.Network().init()
 net.fp16_init()
 d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((n, 7, 7, 18), dtype=torch.float32, device="cuda")
-for _ in range(3): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+for _ in range(60): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+for _ in range(50): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
 print(f"fp16 configuration: {dt*1e3:.3f} ms per {n} frames -> {n/dt/1e6:.2f} M frames/s")
