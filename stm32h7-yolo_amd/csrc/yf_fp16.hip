@@ -28,6 +28,7 @@ typedef _Float16 half_t;
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ LDS plan (bytes, one frame)
 // Buf: OFF byte offset, logical W x H, S bytes per pixel (fp16 channels, padded), RS pixels per row incl. halo, PT/PL halo
@@ -111,7 +112,12 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {          // v_cvt_
   const v2h h = __builtin_convertvector(v2f{a, b}, v2h);               // plain cast; the round-toward-zero form (v_cvt_pkrtz) biases
   uint32_t u; __builtin_memcpy(&u, &h, 4); return u;                   // every layer the same way and misses the tolerance
 }
-__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }
+__device__ __forceinline__ float leaky(float v) {                       // max(v, 0.1 v) as ONE v_mul and ONE v_max: fmaxf() first
+  float r;                                                              // canonicalises both operands (a v_max v, v each) under IEEE mode
+  const float t = 0.1f * v;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+  return r;
+}
 
 // four fp32 results of a pass (channels chq..chq+3 of pixel p) -> activation -> fp16 -> LDS (or fp32 logits -> HBM)
 template <int EPI, class OUT, int OUT_CH0, class ADDB, int COUT>
@@ -149,7 +155,7 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
   int j0, j1;
   job_range<JOBS, NW>(wave, j0, j1);
   int cur = -1;
-  v8h a[TPJ][KS];
+  v4i a[TPJ][KS];                    // dword vectors, bit-cast at the MFMA (see conv3x3_stage)
   for (int j = j0; j < j1; ++j) {
     const int chunk = j / MT, mt = j - chunk * MT;
     if (chunk != cur) {
@@ -159,8 +165,8 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
         const int ps = min(chunk * TPJ + tt, NP - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          a[tt][ks] = v8h{0, 0, 0, 0, 0, 0, 0, 0};
-          if (a_on) a[tt][ks] = *reinterpret_cast<const v8h*>(tab + t.w_off + ((ps * 4 + (c & 3)) * KROW + 8 * ks) * 2);
+          a[tt][ks] = v4i{0, 0, 0, 0};
+          if (a_on) a[tt][ks] = *reinterpret_cast<const v4i*>(tab + t.w_off + ((ps * 4 + (c & 3)) * KROW + 8 * ks) * 2);
         }
       }
     }
@@ -171,16 +177,16 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
     char* lds = lds0 + f * IN::FS;
     float* out_frame = (F == 2 && f) ? out_frame1 : out_frame0;
     const char* src = lds + IN::at_p(p);
-    v8h b[KS];
+    v4i b[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v8h*>(src + 16 * ks);
+    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
 #pragma unroll
     for (int tt = 0; tt < TPJ; ++tt) {
       const int ps = chunk * TPJ + tt;
       if (ps < NP) {
         v4f acc = uniform_f4(tab + t.b_off + 16 * ps);                        // bias as the accumulator's initial value
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], b[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[tt][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
         epilogue<EPI, OUT, OUT_CH0, ADDB, COUT>(lds, out_frame, p, 4 * ps, acc, q < P);
       }
     }
@@ -210,11 +216,11 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
   while (j < j1) {
     const int cg = j / JPG;
     const int jend = min(j1, (cg + 1) * JPG);
-    v8h a[5];
-#pragma unroll
+    v4i a[5];                        // A fragments as dword vectors (bit-cast at the MFMA): as half vectors the compiler re-packs
+#pragma unroll                       // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
     for (int ks = 0; ks < 5; ++ks) {
-      a[ks] = v8h{0, 0, 0, 0, 0, 0, 0, 0};
-      if (a_on) a[ks] = *reinterpret_cast<const v8h*>(tab + t.w_off + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
+      a[ks] = v4i{0, 0, 0, 0};
+      if (a_on) a[ks] = *reinterpret_cast<const v4i*>(tab + t.w_off + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
     }
     const v4f bias = uniform_f4(tab + t.b_off + 16 * cg);
     for (; j < jend; ++j) {
@@ -231,9 +237,8 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) {
         const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
-        const uint4 u = {lo.x, lo.y, hi.x, hi.y};
-        v8h b; __builtin_memcpy(&b, &u, 16);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks], b, acc, 0, 0, 0);
+        const v4i u = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[ks]), __builtin_bit_cast(v8h, u), acc, 0, 0, 0);
       }
       const int oy = oy0 + g, ox = x0 + xl;
       uint2 v; v.x = pack2(leaky(acc[0]), leaky(acc[1])); v.y = pack2(leaky(acc[2]), leaky(acc[3]));
