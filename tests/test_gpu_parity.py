@@ -519,6 +519,10 @@ def test_camera_frames_to_detections_in_one_launch(yf, network, oracle, torch_cu
     network.run_camera_device(d_raw.data_ptr(), d_h.data_ptr(), 5)
     torch.cuda.synchronize()
     assert np.array_equal(d_h.cpu().numpy()[:5], h_ref[pick[:5]])
+    # the staging loads 16-byte vectors: a misaligned frame pointer is refused with a latched error, nothing is launched
+    with pytest.raises(Exception) as ei:
+        network.run_camera_device(d_raw.data_ptr() + 2, d_h.data_ptr(), 1)
+    assert ei.value.type != 0
 
 
 def test_interpreter_mirror(oracle, golden, network):
