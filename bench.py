@@ -9,6 +9,7 @@ the 256 MB Infinity Cache), so the input bytes really come from HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...          (no launcher: starts the N ranks itself as a child torch.distributed.run, see self_launch)
 """
 import argparse
 import hashlib
@@ -39,11 +40,9 @@ FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp
 
 
 def kernel_source_hash():
-    """Identity of the running kernel build: sha256 over the device sources and build flags (works without git)."""
-    h = hashlib.sha256()
-    for f in ("yf_kernels.hip.h", "yf_engine.hip", "yf_decode.hip.h", "yf_tables.h", "Makefile"):
-        h.update(open(os.path.join(ROOT, "stm32h7-yolo_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """Identity of the RUNNING kernel build: the id baked into the loaded library (sha256 over the device sources and the
+    compiler flags they were built with, csrc/Makefile BUILD_ID) -- not a hash of whatever sources lie next to it."""
+    return importlib.import_module("stm32h7-yolo_amd").load().yf_network_build_id().decode()
 
 
 def profile_counters(kernel_name):
@@ -149,6 +148,26 @@ def secondary_configs(net, dev, stream):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU (importing torch does not); it
+    starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (one rank per
+    GPU, rendezvous on 127.0.0.1 at a free port), relays the child's output -- rank 0's single JSON line included -- and
+    returns its exit code.  With WORLD_SIZE already set by a launcher this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in child.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,12 +184,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))      # plain `python bench.py --gpus N`: start the N ranks, relay their line
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -199,53 +218,30 @@ def main():
     d_ins = [torch.from_numpy(xk).to(dev) for xk in xs]
     x = xs[0]
     cap = args.det_cap
-    # Per-rank exchange record: [detection records n x cap x 28 B | counts n x 4 B (| heads n x 882 B)] in ONE buffer, so the
-    # exchange at N > 1 is ONE all-gather per step.  Two such buffers alternate: the all-gather of step k runs on RCCL's
-    # stream while the kernel of step k+1 fills the other buffer (collective overlapped with compute).
-    off_c = (n * cap * 28 + 15) & ~15
-    off_h = (off_c + n * 4 + 15) & ~15
-    rec_bytes = off_h + (((n * 882 + 15) & ~15) if args.gather_heads else 0)
-    n_buf = 2 if world > 1 else 1
-    local = [torch.zeros((rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-    heads_local = [local[i][off_h:off_h + n * 882] if args.gather_heads else torch.zeros((n * 882,), dtype=torch.uint8, device=dev) for i in range(n_buf)]
-    gath = [torch.zeros((world * rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(n_buf)] if world > 1 else []
-    pending = [None] * n_buf
+    # Per-rank exchange record [detection records n x cap x 28 B | counts n x 4 B (| heads n x 882 B)] in ONE buffer: ONE all-gather
+    # per step at N > 1.  Two buffers alternate: the all-gather of step k runs on RCCL's stream while the kernel of step k+1 fills
+    # the other buffer (sharding.DetectionExchange holds the layout and the double-buffer protocol; the CPU gloo test runs it too).
+    ex = sharding.DetectionExchange(n, cap, world, dev, gather_heads=args.gather_heads, backend=args.backend if world > 1 else None)
+    rec_bytes, off_c = ex.rec_bytes, ex.off_c
+    local, heads_local, gath, views = ex.local, [ex.heads(i) for i in range(ex.n_buf)], ex.gathered, ex.views
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
 
-    def views(buf, r=0):
-        base = buf[r * rec_bytes:(r + 1) * rec_bytes]
-        return base[:n * cap * 28].view(n, cap, 28), base[off_c:off_c + n * 4].view(torch.int32)
-
     def launch(i, k=0):
-        p = local[i].data_ptr()
         # ONE launch per step: the fused network kernel also decodes the boxes of its frames (heads still in LDS)
-        net.run_decode_device(d_ins[k].data_ptr(), heads_local[i].data_ptr(), n, p, p + off_c, cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
+        net.run_decode_device(d_ins[k].data_ptr(), ex.heads(i).data_ptr(), n, ex.dets_ptr(i), ex.counts_ptr(i), cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
 
     step_no = 0
 
     def step():
         nonlocal step_no
-        i = step_no % n_buf
         k = step_no % N_INPUT_BATCHES
         step_no += 1
-        if pending[i] is not None:          # the gather that last read this buffer must be done before it is overwritten
-            pending[i].wait()
-            pending[i] = None
+        i = ex.acquire()                    # waits for the gather that last read buffer i
         launch(i, k)
-        if world > 1:       # every rank ends up with every rank's detection records and counts (RCCL over xGMI)
-            if args.backend == "nccl":
-                pending[i] = dist.all_gather_into_tensor(gath[i], local[i], async_op=True)
-            else:           # rehearsal: the same exchange through host copies
-                parts = [torch.empty((rec_bytes,), dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(parts, local[i].cpu())
-                gath[i].copy_(torch.cat(parts))
+        ex.exchange(i)                      # every rank ends up with every rank's detection records and counts (RCCL over xGMI)
 
-    def drain():
-        for i in range(n_buf):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+    drain = ex.drain
 
     # Clock settle (untimed, reported as config.clock_settle_ms): the engine clock of an idle GPU ramps up over the first ~10 ms
     # of work -- the first ~50 launches run ~6 % slower -- and a short warm-up (W = 5 steps = 1 ms) would leave the timed
@@ -281,6 +277,7 @@ def main():
 
     # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames), then compare
     step_no = 0
+    ex.step_no = 0
     step()
     drain()
     torch.cuda.synchronize()
@@ -310,11 +307,11 @@ def main():
                 problems.append(f"golden frame {f}: detections differ from tests/golden/golden_meta.json")
     ok_gather = True
     if world > 1:   # every rank must hold every rank's records, in rank = frame order
-        ok_gather = bool(torch.equal(gath[0][rank * rec_bytes:(rank + 1) * rec_bytes], local[0]))
-        g_counts = torch.cat([views(gath[0], r)[1] for r in range(world)])           # [n_total]
+        ok_gather = ex.check_gathered(0, rank)
+        g_counts = ex.gathered_counts(0)                                              # [n_total]
         ok_gather = ok_gather and tuple(g_counts.shape) == (n_total,) and bool(torch.equal(g_counts[a:b], d_counts))
-        g_frames = torch.cat([views(gath[0], r)[0] for r in range(world)])[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
-        first_rec = np.nonzero(torch.cat([views(gath[0], r)[1] for r in range(world)]).cpu().numpy() > 0)[0]
+        g_frames = ex.gathered_records(0)[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
+        first_rec = np.nonzero(g_counts.cpu().numpy() > 0)[0]
         # record k of rank r carries its LOCAL frame index: the global order is rank-major
         ok_gather = ok_gather and all(int(g_frames[i]) == int(i % n) for i in first_rec[:512])
         flag = torch.tensor([int(ok_gather and not problems)], device=dev if args.backend == "nccl" else "cpu")

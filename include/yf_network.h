@@ -222,7 +222,8 @@ YF_API long yf_network_run_device_dump(ai_handle network, const void* d_in, void
 YF_API long yf_network_dump_bytes(void);
 /* The network is fully convolutional; the reference ABI fixes 56x56 (network.h:48-50).  This extension also runs
  * 160x160 frames (BASELINE configs[4]): d_in int8[n][h][w][3] -> d_out int8[n][h/8][w/8][18].  56x56 takes the fused
- * LDS-resident kernel, 160x160 runs the same stage code layer by layer over an HBM arena owned by the library. */
+ * LDS-resident kernel, 160x160 runs the same stage code as four banded kernels (each a group of fused stages over row bands
+ * staged through LDS) over a per-frame HBM arena owned by the library, one arena per launch stream. */
 YF_API long yf_network_run_device_hw(ai_handle network, int height, int width, const void* d_in, void* d_out, long n, void* stream);
 /* Box decode on the GPU from device-resident heads: d_dets yf_det[n][cap], d_counts int32[n] (true count, may
  * exceed cap).  mode = YF_DECODE_PY, YF_DECODE_FW or YF_DECODE_FW_HOST. */
@@ -281,6 +282,10 @@ YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, 
 /* Text of the last HIP/runtime failure (empty string if none). */
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);
+/* Identity of the device code inside this library: the first 16 hex digits of the sha256 over the device sources and the
+ * compiler flags they were built with (csrc/Makefile, BUILD_ID).  Profiles are stamped with it; bench.py reports counters of a
+ * profile only when the stamp equals the id of the library it is running.  Host-only, no GPU. */
+YF_API const char* yf_network_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
-           "yf_network_kernel_name",
+           "yf_network_kernel_name", "yf_network_build_id",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
            "ai_platform_network_get_error", "ai_platform_network_init", "ai_platform_network_post_init",
@@ -115,8 +115,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        build()
+    if not os.environ.get("YF_LIB_PATH"):
+        build()                  # `make`: a no-op when the library is current, so a stale .so is never loaded under fresh sources
     lib = ctypes.CDLL(LIB_PATH)
     vp, cl = ctypes.c_void_p, ctypes.c_long
     lib.ai_network_create.restype = AiError
@@ -175,6 +175,8 @@ def load():
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
     lib.yf_network_kernel_name.argtypes = [vp]
+    lib.yf_network_build_id.restype = ctypes.c_char_p
+    lib.yf_network_build_id.argtypes = []
     _lib = lib
     return lib
 
@@ -343,6 +345,10 @@ class Network:
     @property
     def kernel_name(self):
         return (self.lib.yf_network_kernel_name(self.handle) or b"").decode()
+
+    @property
+    def build_id(self):
+        return (self.lib.yf_network_build_id() or b"").decode()
 
     def dump_bytes(self):
         return self.lib.yf_network_dump_bytes()

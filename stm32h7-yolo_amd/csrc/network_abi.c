@@ -9,12 +9,14 @@
  * There is NO CPU compute path in this file or behind it: without a gfx950 GPU ai_network_init fails with
  * AI_ERROR_INIT_FAILED and ai_network_run returns 0.
  */
+#define _GNU_SOURCE            /* RTLD_DEFAULT, RTLD_NOLOAD */
 #include "../../include/yf_network.h"
 #include "yf_engine.h"
 #include "yf_host_prep.h"
 #include "yf_impl.h"
 #include "yf_fp16.h"
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -329,18 +331,29 @@ YF_API void yf_network_shard_range(long n, int rank, int world, long* begin, lon
 
 /* ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream) out of librccl.so, resolved on first use */
 typedef int (*yf_nccl_all_gather_fn)(const void*, void*, size_t, int, void*, void*);
+static yf_nccl_all_gather_fn g_rccl_all_gather;
+static pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
+static void resolve_rccl(void) {
+  void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+  if (!sym) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) sym = dlsym(h, "ncclAllGather");
+  }
+  g_rccl_all_gather = (yf_nccl_all_gather_fn)sym;
+}
 YF_API long yf_network_all_gather_device(ai_handle network, void* nccl_comm, const void* d_send, void* d_recv,
                                          size_t bytes_per_rank, void* stream) {
   yf_context* c = acquire(network);
   if (!c) return 0;
   if (!nccl_comm || !d_send || !d_recv || bytes_per_rank == 0) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_INVALID_PTR, "all-gather: NULL communicator/buffer or zero size"); return 0; }
-  static yf_nccl_all_gather_fn fn;
-  if (!fn) {
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (h) fn = (yf_nccl_all_gather_fn)dlsym(h, "ncclAllGather");
-    if (!fn) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, "all-gather: librccl.so / ncclAllGather not found"); return 0; }
-  }
+  /* Resolve ncclAllGather in the RCCL instance that created the caller's communicator: first whatever the process already
+   * has (global scope, then an already loaded librccl.so.1 -- glibc matches loaded objects by SONAME, and both the ROCm and
+   * the PyTorch copy carry that one), only then load a copy.  Resolved once (pthread_once). */
+  pthread_once(&g_rccl_once, resolve_rccl);
+  const yf_nccl_all_gather_fn fn = g_rccl_all_gather;
+  if (!fn) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, "all-gather: librccl.so.1 / ncclAllGather not found"); return 0; }
   const int rc = fn(d_send, d_recv, bytes_per_rank, 0 /* ncclInt8 */, nccl_comm, stream);
   if (rc != 0) {
     char t[96]; snprintf(t, sizeof t, "ncclAllGather failed with ncclResult_t %d", rc);
@@ -439,6 +452,8 @@ YF_API const char* yf_network_last_error_text(ai_handle network) {
   if (!c && network != AI_HANDLE_NULL && g_network.state != ST_NONE) c = &g_network;
   return c ? c->err_text : "invalid handle";
 }
+
+YF_API const char* yf_network_build_id(void) { return yf_engine_build_id(); }
 
 YF_API const char* yf_network_kernel_name(ai_handle network) {
   yf_context* c = acquire(network);

@@ -8,12 +8,14 @@
  * ai_platform_network_create hands it back as the handle, every other call checks it and forwards to the fused engine.
  * The engine implements ONE graph -- the 31 c-layers of the yoloface model.  ai_platform_network_init therefore walks
  * the caller's node list (from ai_network.input_node, the way the ST runtime's scheduler does, core_common.h:101-109)
- * and compares every node -- kind, kernel, stride, padding, groups, fused non-linearity, output shape, weight count --
- * with the graph the engine was built for; any difference latches AI_ERROR_INIT_FAILED instead of silently running a
+ * and compares every node -- kind, kernel, stride, padding, groups, fused non-linearity, output shape, weight count, and
+ * the QUANTISATION of every tensor it touches (scale and zero point of inputs, pre-activation and output tensors, the
+ * per-channel filter scales; reference network.c:663-1341) -- with the graph and the tables the engine was built for; any difference latches AI_ERROR_INIT_FAILED instead of silently running a
  * different network.  Weights come from the caller's blob (ai_platform_get_weights_map's params).
  */
 #include "yf_impl.h"
 #include "st_graph_view.h"
+#include "gen/yf_model_gen.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -79,6 +81,33 @@ static const yf_expected_node k_graph[31] = {
   { 53, K_CONV,      1, 1, 1, 0, {0, 0, 0, 0},  7,  7, 18,   576},
 };
 
+/* tflite tensor ids (gen/yf_model_gen.h: yf_tensor_scale_bits / yf_tensor_zero_point, equal to network.c:663-886,1225-1341) of
+ * every node's inputs (as its chain lists them), of the pre-activation tensor of a conv with a fused LeakyReLU (ST keeps it
+ * as `scratch1`, network.c:1225-1341) and of its output; conv = index into yf_convs (per-channel filter scales) or -1. */
+typedef struct { int16_t in0, in1, pre, out, conv; } yf_expected_quant;
+static const yf_expected_quant k_quant[31] = {
+  { 0, -1, 51, 52,  0}, {52, -1, 53, 54,  1}, {54, -1, -1, 55,  2}, {55, -1, 56, 57,  3}, {57, -1, 60, 61,  4}, {61, -1, -1, 62,  5},
+  {62, -1, 63, 64,  6}, {64, -1, 65, 66,  7}, {66, -1, -1, 67,  8}, {62, 67, -1, 68, -1}, {68, -1, 69, 70,  9}, {57, -1, -1, 58, -1},
+  {58, 70, -1, 71, -1}, {71, -1, 72, 73, 10}, {73, -1, 76, 77, 11}, {77, -1, -1, 78, 12}, {78, -1, 79, 80, 13}, {80, -1, 81, 82, 14},
+  {82, -1, -1, 83, 15}, {78, 83, -1, 84, -1}, {84, -1, 85, 86, 16}, {86, -1, 87, 88, 17}, {88, -1, -1, 89, 18}, {84, 89, -1, 90, -1},
+  {90, -1, 91, 92, 19}, {73, -1, -1, 74, -1}, {74, 92, -1, 93, -1}, {93, -1, 94, 95, 20}, {95, -1, 96, 97, 21}, {97, -1, 98, 99, 22},
+  {99, -1, -1, 100, 23},
+};
+
+/* 0 = tensor t carries exactly the per-tensor quantisation of tflite tensor `id`; otherwise a description in `what` */
+static int tensor_quant_differs(const stv_tensor* t, int id, char* what, size_t n) {
+  const stv_intq_info_list* q = t ? (const stv_intq_info_list*)t->klass : NULL;
+  if (!q || q->size != 1 || !q->info || !q->info[0].scale || !q->info[0].zeropoint) { snprintf(what, n, "has no per-tensor quantisation record"); return 1; }
+  uint32_t bits; memcpy(&bits, q->info[0].scale, 4);
+  const int zp = *(const int8_t*)q->info[0].zeropoint;
+  if (bits != yf_tensor_scale_bits[id]) {
+    float want; memcpy(&want, &yf_tensor_scale_bits[id], 4);
+    snprintf(what, n, "scale %.9g, expected %.9g", (double)*q->info[0].scale, (double)want); return 1;
+  }
+  if (zp != yf_tensor_zero_point[id]) { snprintf(what, n, "zero point %d, expected %d", zp, (int)yf_tensor_zero_point[id]); return 1; }
+  return 0;
+}
+
 YF_API void forward_conv2d_integer_SSSA_ch(void* layer);
 YF_API void forward_mp_integer_INT8(void* layer);
 YF_API void forward_eltwise_integer_INT8(void* layer);
@@ -142,6 +171,35 @@ static int verify_graph(const stv_network* net, char* why, size_t n) {
     } else {
       const stv_tensor_list* ins = &node->tensors->chain[0];
       if (ins->size != 2) BAD("%u inputs, expected 2", (unsigned)ins->size);
+    }
+    {   /* quantisation of every tensor the node touches (network.c:663-1341) against the tables the engine was built from */
+      const yf_expected_quant* qe = &k_quant[i];
+      const stv_tensor_list* ins = &node->tensors->chain[0];
+      char what[160];
+      const int n_in = qe->in1 >= 0 ? 2 : 1;
+      if (ins->size < n_in || !ins->tensor) BAD("%u inputs, expected %d", (unsigned)ins->size, n_in);
+      for (int k = 0; k < n_in; ++k)
+        if (tensor_quant_differs(ins->tensor[k], k ? qe->in1 : qe->in0, what, sizeof what)) BAD("input tensor %d %s", k, what);
+      if (tensor_quant_differs(outs->tensor[0], qe->out, what, sizeof what)) BAD("output tensor %s", what);
+      if (qe->pre >= 0) {
+        const stv_tensor_list* scr = node->tensors->size >= 4 ? &node->tensors->chain[3] : NULL;
+        if (!scr || scr->size < 2 || !scr->tensor) BAD("no pre-activation (scratch1) tensor");
+        if (tensor_quant_differs(scr->tensor[1], qe->pre, what, sizeof what)) BAD("pre-activation tensor %s", what);
+      }
+      if (qe->conv >= 0) {
+        const yf_conv_desc* cd = &yf_convs[qe->conv];
+        const stv_tensor* wt = node->tensors->chain[2].tensor[0];
+        const stv_intq_info_list* q = (const stv_intq_info_list*)wt->klass;
+        if (!q || q->size != cd->cout || !q->info || !q->info[0].scale || !q->info[0].zeropoint) BAD("weight tensor has no per-channel quantisation record of %u channels", (unsigned)cd->cout);
+        for (int ch = 0; ch < cd->cout; ++ch) {
+          uint32_t bits; memcpy(&bits, &q->info[0].scale[ch], 4);
+          if (bits != cd->wscale_bits[ch]) {
+            float want; memcpy(&want, &cd->wscale_bits[ch], 4);
+            BAD("weight tensor channel %d scale %.9g, expected %.9g", ch, (double)q->info[0].scale[ch], (double)want);
+          }
+          if (((const int8_t*)q->info[0].zeropoint)[ch] != 0) BAD("weight tensor channel %d zero point %d, expected 0", ch, (int)((const int8_t*)q->info[0].zeropoint)[ch]);
+        }
+      }
     }
     const stv_node* next = (node->next == node) ? NULL : node->next;     /* network.c ends the list with a self link (:2209) */
     if (i == 30 && next) BAD("more than 31 nodes");

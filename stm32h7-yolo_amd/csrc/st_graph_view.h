@@ -9,6 +9,7 @@
  *   ai_layer_conv2d   layers_conv2d.h:27-34,76-78            ai_layer_pool         layers_pool.h:42-48
  *   ai_tensor_chain / ai_tensor_list / ai_tensor  ai_platform_interface.h:549-556,651-671
  *   ai_storage_klass (ai_shape)  ai_platform_interface.h:90-94,135     ai_shape_2d  :501-503     ai_array  :513-522
+ *   ai_intq_info / ai_intq_info_list (a tensor's `klass`: its quantisation)  ai_platform.h:479-495
  * Own text; tests/abi/graph_probe.c prints every offset used here from BOTH sets of declarations (container test:
  * tests/test_abi.py::test_graph_views_match_reference_layout). */
 #ifndef YF_ST_GRAPH_VIEW_H
@@ -19,8 +20,10 @@ typedef struct { uint32_t type_size; void* data; } stv_storage;         /* type:
 #define STV_STORAGE_SIZE(s) ((s).type_size >> 8)
 typedef struct { uint32_t data[2]; } stv_shape2d;                        /* [0] = x / width, [1] = y / height */
 typedef struct { int32_t format; uint32_t size; uint8_t* data; uint8_t* data_start; } stv_array;
+typedef struct { const float* scale; const void* zeropoint; } stv_intq_info;          /* `size` scales, `size` int8 zero points */
+typedef struct { uint16_t flags, size; const stv_intq_info* info; } stv_intq_info_list;   /* size > 1: per output channel */
 typedef struct { uint16_t id; uint8_t flags; uint8_t data_size; } stv_tensor_info;
-typedef struct { void* klass; stv_tensor_info info; stv_storage shape; stv_storage stride; stv_array* data; } stv_tensor;
+typedef struct { void* klass /* stv_intq_info_list* or NULL */; stv_tensor_info info; stv_storage shape; stv_storage stride; stv_array* data; } stv_tensor;
 typedef struct { uint16_t size, flags; stv_tensor** tensor; void* info; } stv_tensor_list;
 typedef struct { uint16_t size, flags; stv_tensor_list* chain; } stv_tensor_chain;   /* chain[0] inputs, [1] outputs, [2] weights, [3] scratch */
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include "yf_engine.h"
+#include "yf_stream_scratch.h"
 #include "yf_decode.hip.h"
 #define YF_NS yf
 #define YF_EXP 0
@@ -101,7 +102,6 @@ const Variant k_variants[] = {
 
 }  // namespace
 
-constexpr int PARK_REGIONS = 4;
 struct yf_engine {
   int device = 0;
   int cus = 0;
@@ -110,8 +110,9 @@ struct yf_engine {
   const Variant* var = nullptr;
   const Variant* var_dump = nullptr;
   void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
-  char* arena160 = nullptr; long arena160_frames = 0; bool layerwise160 = false;
-  char* d_park = nullptr; size_t park_region = 0; unsigned park_next = 0;      // tail batching scratch of the fused kernel
+  bool layerwise160 = false;
+  yf_stream_scratch arena160;                    // 160x160 per-frame HBM arena, one per launch stream (yf_stream_scratch.h)
+  yf_stream_scratch park; size_t park_region = 0;   // tail batching scratch of the fused kernel, one region per launch stream
   hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -216,8 +217,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
     for (const Variant& v : k_variants) park = v.park > park ? v.park : park;
-    e->park_region = (size_t)e->cus * 4 * park;
-    if (park && (rc = hipMalloc((void**)&e->d_park, e->park_region * PARK_REGIONS)) != hipSuccess) return bail(rc, "hipMalloc(tail scratch)");
+    e->park_region = (size_t)e->cus * 4 * park;      // allocated per stream on its first launch (launch())
   }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
@@ -233,8 +233,8 @@ void yf_engine_destroy(yf_engine* e) {
   if (e->d_tab) (void)hipFree(e->d_tab);
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_out) (void)hipFree(e->d_out);
-  if (e->arena160) (void)hipFree(e->arena160);
-  if (e->d_park) (void)hipFree(e->d_park);
+  e->arena160.release();
+  e->park.release();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -273,6 +273,10 @@ int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
 
 const char* yf_engine_error(const yf_engine* e) { return e ? e->err.c_str() : "null engine"; }
 const char* yf_engine_kernel_name(const yf_engine* e) { return e && e->var ? e->var->name : ""; }
+#ifndef YF_BUILD_ID
+#define YF_BUILD_ID "unstamped"
+#endif
+const char* yf_engine_build_id(void) { return YF_BUILD_ID; }
 long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
 
 struct DecodeArgs { void* dets; void* counts; int cap, mode; float w_scale, h_scale; };
@@ -291,11 +295,11 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   long grid = (long)e->cus * per_cu;
   if (grid > groups) grid = groups;
   prm.scratch = nullptr;
-  if (v->park) {   // tail batching: a workgroup parks one group's T15 (f frames) in HBM.  Launches rotate through PARK_REGIONS
-                   // regions so that launches of one instance overlapping on different streams never share a slot.
+  if (v->park) {   // tail batching: a workgroup parks one group's T15 (f frames) in HBM, slot = blockIdx.x.  The region belongs to
+                   // the launch STREAM: launches on one stream serialise, launches on different streams never share bytes.
     const size_t need = (size_t)grid * v->f * v->park;
     if (need > e->park_region) { e->err = "tail scratch region too small for this kernel shape"; return YF_ENG_ERR_VARIANT; }
-    prm.scratch = e->d_park + (size_t)(e->park_next++ % PARK_REGIONS) * e->park_region;
+    HIPCHK(e, e->park.get(s, e->park_region, &prm.scratch));
   }
   hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->nw * 64), v->lds, s, prm);
   HIPCHK(e, hipGetLastError());
@@ -377,12 +381,8 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
   HIPCHK(e, hipSetDevice(e->device));
   const long cap = n < 1024 ? n : 1024;                       // frames per chunk of the HBM arena
   const size_t per_frame = e->layerwise160 ? (size_t)yf160::FRAME_BYTES : (size_t)yf160::band::ARENA_BYTES;
-  if (cap > e->arena160_frames) {
-    if (e->arena160) (void)hipFree(e->arena160);
-    e->arena160 = nullptr; e->arena160_frames = 0;
-    HIPCHK(e, hipMalloc((void**)&e->arena160, (size_t)cap * per_frame));
-    e->arena160_frames = cap;
-  }
+  char* arena = nullptr;                                     // owned by the launch stream: overlapping launches never share it
+  HIPCHK(e, e->arena160.get((hipStream_t)stream, (size_t)cap * per_frame, &arena));
   for (long done = 0; done < n; done += cap) {
     const long m = (n - done) < cap ? (n - done) : cap;
     int rc;
@@ -390,13 +390,13 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
       yf160::GenParams prm;
       prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
       prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
-      prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
+      prm.n = m; prm.tab = e->d_tab; prm.arena = arena;
       rc = launch160_from<0>(e, prm, (unsigned)m, (hipStream_t)stream);
     } else {
       yf160::band::Params prm;
       prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
       prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
-      prm.n = m; prm.tab = e->d_tab; prm.arena = e->arena160;
+      prm.n = m; prm.tab = e->d_tab; prm.arena = arena;
       rc = launch160_banded(e, prm, (hipStream_t)stream);
     }
     if (rc) return rc;

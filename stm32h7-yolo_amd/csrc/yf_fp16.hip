@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include "yf_fp16.h"
+#include "yf_stream_scratch.h"
 
 namespace yf16 {
 
@@ -456,12 +457,11 @@ namespace {
     (ctx)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return -1; } } while (0)
 }
 
-constexpr int FP16_PARK_REGIONS = 4;          // launches rotate through the regions: overlapping launches on different streams never share a slot
 struct yf_fp16 {
   int device = 0;
   int cus = 0;
   uint8_t* d_tab = nullptr;
-  char* d_park = nullptr; size_t park_region = 0; unsigned park_next = 0;
+  yf_stream_scratch park; size_t park_region = 0;      // tail scratch: one region per launch stream (yf_stream_scratch.h)
   std::string err;
 };
 
@@ -473,7 +473,7 @@ void yf_fp16_destroy(yf_fp16* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_tab) (void)hipFree(c->d_tab);
-  if (c->d_park) (void)hipFree(c->d_park);
+  c->park.release();
   delete c;
 }
 
@@ -551,8 +551,7 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
       hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_BYTES) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
-  c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup
-  if (hipMalloc((void**)&c->d_park, c->park_region * FP16_PARK_REGIONS) != hipSuccess) { yf_fp16_destroy(c); return fail("allocating the fp16 tail scratch failed"); }
+  c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup; allocated per stream on first use
   *out = c;
   return 0;
 }
@@ -565,7 +564,7 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
   HIPCHK(c, hipSetDevice(c->device));
   yf16::Params prm;
   prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab;
-  prm.scratch = c->d_park + (size_t)(c->park_next++ % FP16_PARK_REGIONS) * c->park_region;
+  HIPCHK(c, c->park.get((hipStream_t)stream, c->park_region, &prm.scratch));
   long grid = (long)c->cus * 2;                              // two 76 KB workgroups per CU, persistent over the frames
   if (grid > n) grid = n;
   hipLaunchKernelGGL(yf16::yoloface56_f16_fused<8>, dim3((unsigned)grid), dim3(512), yf16::LDS_BYTES, (hipStream_t)stream, prm);

@@ -1034,8 +1034,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(13);
     // BATCH: the parked group's T15 goes from the scratch straight into the odd tail sets by LDS-DMA (no registers), issued
-    // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through -- so that it lands during conv2d_23; the
-    // barrier behind conv2d_23 waits for it (vmcnt).  One wave-instruction moves 64 x 16 contiguous bytes.
+    // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through.  The wait that guards it is the explicit
+    // s_waitcnt vmcnt(0) in front of the barrier behind conv2d_23 (this toolchain also waits at conv2d_23's first LDS access: its
+    // alias analysis cannot tell the DMA's destination from the stage's buffers, so the transfer overlaps less than it could).
+    // One wave-instruction moves 64 x 16 contiguous bytes.
     if constexpr (BATCH && !YF_TOGGLED(4)) {
       if (parked_first >= 0) {
         constexpr int PV = TailBufs<FRAME_BYTES>::T15_BYTES / 16, WI = (PV + 63) / 64;      // vectors / wave-instructions per frame
@@ -1051,6 +1053,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     }
     fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
     dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m, vz);
+    if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
     // ---- the 7x7 tail.  BATCH: it runs once per PAIR of groups on FT = 2F frames.  Its thirteen stages are latency chains

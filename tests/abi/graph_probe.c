@@ -6,7 +6,7 @@
 #include "st_graph_view.h"
 typedef stv_network ai_network; typedef stv_node ai_node; typedef stv_conv2d ai_layer_conv2d; typedef stv_pool ai_layer_pool;
 typedef stv_storage ai_storage_klass; typedef stv_shape2d ai_shape_2d; typedef stv_tensor ai_tensor; typedef stv_tensor_list ai_tensor_list;
-typedef stv_tensor_chain ai_tensor_chain; typedef stv_array ai_array;
+typedef stv_tensor_chain ai_tensor_chain; typedef stv_array ai_array; typedef stv_intq_info ai_intq_info; typedef stv_intq_info_list ai_intq_info_list;
 #define NODE(f) offsetof(stv_conv2d, n.f)
 #define AI_LAYER_CONV2D_TYPE STV_LAYER_CONV2D
 #define AI_LAYER_POOL_TYPE STV_LAYER_POOL
@@ -33,6 +33,8 @@ int main(void) {
   printf("ai_tensor_list %zu\n", sizeof(ai_tensor_list)); P(ai_tensor_list, size); P(ai_tensor_list, tensor);
   printf("ai_tensor_chain %zu\n", sizeof(ai_tensor_chain)); P(ai_tensor_chain, size); P(ai_tensor_chain, chain);
   printf("ai_array %zu\n", sizeof(ai_array)); P(ai_array, format); P(ai_array, size); P(ai_array, data);
+  printf("ai_intq_info %zu\n", sizeof(ai_intq_info)); P(ai_intq_info, scale); P(ai_intq_info, zeropoint);
+  printf("ai_intq_info_list %zu\n", sizeof(ai_intq_info_list)); P(ai_intq_info_list, flags); P(ai_intq_info_list, size); P(ai_intq_info_list, info); P(ai_tensor, klass);
   printf("types %d %d %d %d\n", (int)AI_LAYER_CONV2D_TYPE, (int)AI_LAYER_POOL_TYPE, (int)AI_LAYER_CONCAT_TYPE, (int)AI_LAYER_ELTWISE_INTEGER_TYPE);
   return 0;
 }

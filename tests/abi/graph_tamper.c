@@ -3,7 +3,9 @@
  * is changed in memory before ai_network_init.  The library must refuse to initialise (it implements exactly the yoloface
  * graph) instead of silently running its own graph.  Built only where /root/reference exists (oracle/Makefile.ref).
  *
- *   abi_graph_tamper <what>     what: none | stride | groups | pad | nl | pool | shape | order | weights
+ *   abi_graph_tamper <what>     what: none | stride | groups | pad | nl | pool | shape | order | weights | scale | zp | wscale | prescale
+ * The quantisation records of network.c are const objects; the quantisation edits therefore hang an edited COPY of a record
+ * on the tensor (its `klass` pointer), which is what a regenerated network.c with another calibration would look like.
  * prints "init ok" or "init failed type=.. code=.. : <text>".  Exit 0 = initialised, 4 = refused. */
 #include <stdio.h>
 #include <string.h>
@@ -23,6 +25,24 @@ int main(int argc, char** argv) {
   else if (!strcmp(what, "shape")) ((ai_shape_dimension*)conv2d_53_output.shape.data)[1] = 12;   /* 18 head channels -> 12 */
   else if (!strcmp(what, "order")) conv2d_3_layer.next = AI_NODE_OBJ(&conv2d_6_layer);     /* skip conv2d_5 */
   else if (!strcmp(what, "weights")) conv2d_47_weights_array.size = 1000;
+  else if (!strcmp(what, "scale") || !strcmp(what, "zp") || !strcmp(what, "prescale")) {
+    /* conv2d_23's output (scale), conv2d_30's input = conv2d_29's output (zero point), conv2d_47's pre-activation tensor */
+    static ai_float sc[1]; static ai_i8 zp[1]; static ai_intq_info info[1] = {{ sc, (ai_handle)zp }}; static ai_intq_info_list lst;
+    ai_tensor* t = !strcmp(what, "scale") ? &conv2d_23_output : !strcmp(what, "zp") ? &conv2d_29_output : &conv2d_47_scratch1;
+    const ai_intq_info_list* q = (const ai_intq_info_list*)t->klass;
+    sc[0] = q->info[0].scale[0]; zp[0] = ((const ai_i8*)q->info[0].zeropoint)[0];
+    if (!strcmp(what, "zp")) zp[0] = (ai_i8)(zp[0] + 1); else sc[0] *= 1.0000002f;        /* one float32 ulp */
+    lst.flags = q->flags; lst.size = 1; lst.info = info;
+    t->klass = (ai_klass_obj)&lst;
+  }
+  else if (!strcmp(what, "wscale")) {           /* channel 17 of conv2d_6's filter scales */
+    static ai_float sc[18]; static ai_i8 zp[18]; static ai_intq_info info[1] = {{ sc, (ai_handle)zp }}; static ai_intq_info_list lst;
+    const ai_intq_info_list* q = (const ai_intq_info_list*)conv2d_6_weights.klass;
+    for (int k = 0; k < 18; ++k) { sc[k] = q->info[0].scale[k]; zp[k] = 0; }
+    sc[17] *= 1.0000002f;
+    lst.flags = q->flags; lst.size = 18; lst.info = info;
+    conv2d_6_weights.klass = (ai_klass_obj)&lst;
+  }
   else if (strcmp(what, "none")) { fprintf(stderr, "unknown edit %s\n", what); return 2; }
 
   ai_handle network = AI_HANDLE_NULL;

@@ -199,7 +199,10 @@ def test_tampered_reference_graph_is_refused():
         pytest.skip("oracle/_ref/abi_graph_tamper was not built (needs /root/reference at build time)")
     expect = {"stride": "node 14 (id 28", "groups": "groups 1, expected 36", "pad": "padding {1,1,1,0}, expected {1,1,0,0}",
               "nl": "fused non-linearity present", "pool": "window 8x4, expected 8x8", "shape": "output shape 7x7x12, expected 7x7x18",
-              "order": "layer id 7", "weights": "weight tensor has 1000 elements, expected 1920"}
+              "order": "layer id 7", "weights": "weight tensor has 1000 elements, expected 1920",
+              # quantisation tables (network.c:663-1341): one float32 ulp of one scale, one step of one zero point
+              "scale": "node 13 (id 24, expected conv2d id 24): output tensor scale", "zp": "node 15 (id 29, expected conv2d id 29): output tensor zero point -3, expected -4",
+              "wscale": "node 3 (id 7, expected conv2d id 7): weight tensor channel 17 scale", "prescale": "node 27 (id 48, expected conv2d id 48): pre-activation tensor scale"}
     for what, text in expect.items():
         r = subprocess.run([exe, what], capture_output=True, text=True, timeout=120)
         assert r.returncode == 4, (what, r.stdout, r.stderr)

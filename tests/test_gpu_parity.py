@@ -196,6 +196,72 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
             assert np.array_equal(d_outs[k][it].cpu().numpy(), refs[k]), (k, it)
 
 
+def test_asymmetric_launches_on_several_streams(network, oracle, torch_cuda):
+    """Scratch ownership by stream (yf_stream_scratch.h).  ONE long launch on stream A (65 535 frames, ~2.7 ms) is followed,
+    without synchronisation, by five 4096-frame launches on stream B and three on stream C: with scratch regions handed out
+    round-robin per launch (the round-2 scheme) B's fourth launch would have parked its T15 tensors in the region A is still
+    using.  Then two overlapping 160x160 launches on two streams (one arena per stream) and two overlapping fp16 launches.
+    Every head is compared with the oracle (int8) / with the single-stream result (fp16)."""
+    torch = torch_cuda
+    block = rnd(31, 4096)
+    ref = oracle.run(block, threads=16)
+    rng = np.random.default_rng(32)
+    pick_a = rng.integers(0, 4096, 65535)
+    d_a = torch.from_numpy(block[pick_a]).cuda()
+    o_a = torch.zeros((65535, 7, 7, 18), dtype=torch.int8, device="cuda")
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    picks_b = [rng.integers(0, 4096, 4096) for _ in range(5)]
+    picks_c = [rng.integers(0, 4096, 2050) for _ in range(3)]
+    d_b = [torch.from_numpy(block[p]).cuda() for p in picks_b]
+    d_c = [torch.from_numpy(block[p]).cuda() for p in picks_c]
+    o_b = [torch.zeros((4096, 7, 7, 18), dtype=torch.int8, device="cuda") for _ in range(5)]
+    o_c = [torch.zeros((2050, 7, 7, 18), dtype=torch.int8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    network.run_device(d_a.data_ptr(), o_a.data_ptr(), 65535, sa.cuda_stream)
+    for k in range(5):
+        network.run_device(d_b[k].data_ptr(), o_b[k].data_ptr(), 4096, sb.cuda_stream)
+        if k < 3:
+            network.run_device(d_c[k].data_ptr(), o_c[k].data_ptr(), 2050, sc.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_a.cpu().numpy(), ref[pick_a])
+    for k in range(5):
+        assert np.array_equal(o_b[k].cpu().numpy(), ref[picks_b[k]]), k
+    for k in range(3):
+        assert np.array_equal(o_c[k].cpu().numpy(), ref[picks_c[k]]), k
+    del d_a, o_a, d_b, o_b, d_c, o_c
+    # 160x160: one arena per stream
+    blk = np.random.default_rng(33).integers(-128, 128, (8, 160, 160, 3), dtype=np.int8)
+    ref160 = oracle.run(blk, threads=16)
+    idx = [np.random.default_rng(34 + k).integers(0, 8, 700 + 37 * k) for k in range(2)]
+    d_in = [torch.from_numpy(blk[i]).cuda() for i in idx]
+    d_out = [[torch.zeros((len(i), 20, 20, 18), dtype=torch.int8, device="cuda") for _ in range(2)] for i in idx]
+    torch.cuda.synchronize()
+    for it in range(2):
+        for k, st in enumerate((sa, sb)):
+            network.run_device_hw(160, 160, d_in[k].data_ptr(), d_out[k][it].data_ptr(), len(idx[k]), st.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for it in range(2):
+            assert np.array_equal(d_out[k][it].cpu().numpy(), ref160[idx[k]]), (k, it)
+    del d_in, d_out
+    # fp16: a long launch on one stream, short ones on another; results must equal the single-stream ones bit for bit
+    network.fp16_init()
+    x16 = torch.from_numpy((np.random.default_rng(35).integers(0, 256, (4096, 56, 56, 3)).astype(np.float32) / 255).astype(np.float16)).cuda()
+    big = x16.repeat(8, 1, 1, 1).contiguous()
+    want = torch.zeros((4096, 7, 7, 18), dtype=torch.float32, device="cuda")
+    network.fp16_run_device(x16.data_ptr(), want.data_ptr(), 4096)
+    torch.cuda.synchronize()
+    o_big = torch.zeros((32768, 7, 7, 18), dtype=torch.float32, device="cuda")
+    o_small = [torch.zeros((4096, 7, 7, 18), dtype=torch.float32, device="cuda") for _ in range(5)]
+    network.fp16_run_device(big.data_ptr(), o_big.data_ptr(), 32768, sa.cuda_stream)
+    for k in range(5):
+        network.fp16_run_device(x16.data_ptr(), o_small[k].data_ptr(), 4096, sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(o_big.view(8, 4096, 7, 7, 18), want.expand(8, 4096, 7, 7, 18))
+    for k in range(5):
+        assert torch.equal(o_small[k], want), k
+
+
 def test_full_size_32768_properties(network, oracle, torch_cuda):
     """BASELINE.json configs[2] size (32768 frames, here on one GPU): the batch is 8 shuffled copies of a 4096-frame
     block, so every copy must reproduce the block's heads (checked against the oracle on the block)."""
@@ -617,15 +683,15 @@ def test_reference_yoloface_c_links_unchanged_and_runs_on_the_gpu(yf, network, o
 
 
 def test_bench_two_ranks_exchange_detections(tmp_path):
-    """The N > 1 path of bench.py end to end on ONE GPU: two fresh processes (torch.distributed.run, backend gloo: the
-    collective goes through host copies, everything else -- sharding, double-buffered record exchange, per-rank parity
-    check, rank-major record order -- is the code the 8-GPU run executes with RCCL).  The exchange is detections only:
+    """The N > 1 path of bench.py end to end on ONE GPU, entered the way a plain `python bench.py --gpus N` enters it (the
+    parent starts the ranks itself): two fresh processes, backend gloo -- the collective goes through host copies,
+    everything else (sharding, double-buffered record exchange of sharding.DetectionExchange, per-rank parity check,
+    rank-major record order) is the code the 8-GPU run executes with RCCL.  The exchange is detections only:
     fixed-capacity records + counts, <= 0.6 MB per rank per step at 4096 frames."""
     import json
     import sys
-    port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"]
+    # plain `python bench.py --gpus 2`: bench.py starts its own ranks (child torch.distributed.run) and relays rank 0's line
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

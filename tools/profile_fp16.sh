@@ -21,13 +21,15 @@ for f in glob.glob(os.path.join(out, "trace", "*kernel_stats.csv")):
         if "f16_fused" in r["Name"]:
             res["kernel"] = r["Name"]; res["trace"] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3}
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-    acc = {}
+    acc, disp = {}, {}
     for r in csv.DictReader(open(f)):
         if "f16_fused" in r.get("Kernel_Name", ""):
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            disp.setdefault(r["Counter_Name"], set()).add(r["Dispatch_Id"])
     for k, v in acc.items():
-        # one kernel dispatch = several rows (one per XCD/SE); sum per dispatch = total / launches
-        res["counters"][k] = sum(v) / 110.0
+        # one kernel dispatch = several rows (one per XCD/SE): per launch = total / distinct dispatches seen in THIS file
+        res["counters"][k] = sum(v) / len(disp[k])
+        res.setdefault("launches", {})[k] = len(disp[k])
 c = res["counters"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     res["hbm_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024      # gfx950: FETCH_SIZE counts half of a streaming read
