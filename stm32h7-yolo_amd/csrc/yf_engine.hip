@@ -183,6 +183,8 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
     for (int i = 0; i < YF_N_DENSE; ++i) same = same && (int)ix->dense[i].w_off == yf::PLAN.w_off[i] && (int)ix->dense[i].c_off == yf::PLAN.c_off[i];
     for (int i = 0; i < YF_N_DW; ++i) same = same && (int)ix->dw[i].g_off == yf::PLAN.g_off[i];
+    for (int i = 0; i < YF_N_CS; ++i)
+      same = same && (int)ix->cs_v_off[i] == yf::PLAN.vb_off[i] && (int)ix->cs_v_bytes[i] == yf::PLAN.vb_bytes[i] && (int)ix->cs_s_off[i] == yf::PLAN.sb_off[i];
     if (!same) { delete e; return fail("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG); }
   }
   if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
@@ -242,13 +244,16 @@ void yf_engine_destroy(yf_engine* e) {
 }
 
 int yf_engine_table_plan(int32_t* out, int cap) {
-  const int need = 2 * YF_N_DENSE + YF_N_DW + 2;
+  const int need = 2 * YF_N_DENSE + YF_N_DW + 2 + 3 * YF_N_CS;
   if (!out || cap < need) return need;
   int k = 0;
   for (int i = 0; i < YF_N_DENSE; ++i) out[k++] = yf::PLAN.w_off[i];
   for (int i = 0; i < YF_N_DENSE; ++i) out[k++] = yf::PLAN.c_off[i];
   for (int i = 0; i < YF_N_DW; ++i) out[k++] = yf::PLAN.g_off[i];
   out[k++] = yf::PLAN.lut_off; out[k++] = yf::PLAN.total;
+  for (int i = 0; i < YF_N_CS; ++i) out[k++] = yf::PLAN.vb_off[i];
+  for (int i = 0; i < YF_N_CS; ++i) out[k++] = yf::PLAN.vb_bytes[i];
+  for (int i = 0; i < YF_N_CS; ++i) out[k++] = yf::PLAN.sb_off[i];
   return need;
 }
 

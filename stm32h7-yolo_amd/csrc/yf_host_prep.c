@@ -273,6 +273,49 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     for (int i = 0; i < 256; ++i) L[256 * YF_L_L43Q44 + i] = q44[(int)(int8_t)l43[i] + 128];
   }
 
+  /* ---------------- constant blocks of the fused 56x56 kernel (yf_tables.h): the same numbers, regrouped ---------------- */
+  for (int cs = 0; cs < YF_N_CS && !rc; ++cs) {
+    const int di = yf_cs_dense[cs], wi = yf_cs_dw[cs], ai = yf_cs_add[cs];
+    if (di >= 0) {
+      const yf_dense* d = &ix->dense[di];
+      const size_t wbytes = (size_t)d->cout_pad4 * d->krow, np = d->cout_pad4 / 4;
+      const size_t bytes = (wbytes + np * sizeof(yf_pass_v) + (ai >= 0 ? 2048 : 0) + 15) & ~(size_t)15;
+      const size_t off = blob_alloc(&b, bytes);
+      memcpy(b.p + off, b.p + d->w_off, wbytes);
+      for (size_t p = 0; p < np; ++p) {
+        const yf_pass* src = (const yf_pass*)(b.p + d->c_off) + p;
+        yf_pass_v* dst = (yf_pass_v*)(b.p + off + wbytes) + p;
+        memcpy(dst->mult2, src->mult2, 16); memcpy(dst->zr, src->zr, 16);
+      }
+      if (ai >= 0) memcpy(b.p + off + wbytes + np * sizeof(yf_pass_v), b.p + ix->lut_off + YF_N_LUT * 256 + (size_t)ai * 2048, 2048);
+      ix->cs_v_off[cs] = (uint32_t)off; ix->cs_v_bytes[cs] = (uint32_t)bytes;
+    } else {
+      const yf_dw* d = &ix->dw[wi];
+      const size_t bytes = ((size_t)d->ngroups * YF_DWV_GROUP_BYTES + 15) & ~(size_t)15;
+      const size_t off = blob_alloc(&b, bytes);
+      for (int g = 0; g < d->ngroups; ++g) {
+        const uint8_t* src = b.p + d->g_off + (size_t)g * YF_DW_GROUP_BYTES;
+        uint8_t* dst = b.p + off + (size_t)g * YF_DWV_GROUP_BYTES;
+        memcpy(dst, src, 144);
+        const yf_pass* ps = (const yf_pass*)(src + 144);
+        memcpy(dst + 144, ps->mult2, 16); memcpy(dst + 160, ps->zr, 16);
+      }
+      ix->cs_v_off[cs] = (uint32_t)off; ix->cs_v_bytes[cs] = (uint32_t)bytes;
+    }
+  }
+  for (int cs = 0; cs < YF_N_CS && !rc; ++cs) {        /* scalar side: one compact array (stays in the scalar cache) */
+    const int di = yf_cs_dense[cs], wi = yf_cs_dw[cs];
+    const size_t np = di >= 0 ? ix->dense[di].cout_pad4 / 4 : ix->dw[wi].ngroups;
+    const size_t off = blob_alloc(&b, np * sizeof(yf_pass_s));
+    for (size_t p = 0; p < np; ++p) {
+      const yf_pass* src = di >= 0 ? (const yf_pass*)(b.p + ix->dense[di].c_off) + p
+                                   : (const yf_pass*)(b.p + ix->dw[wi].g_off + p * YF_DW_GROUP_BYTES + 144);
+      yf_pass_s* dst = (yf_pass_s*)(b.p + off) + p;
+      memcpy(dst->c64, src->c64, 32); memcpy(dst->rshift, src->rshift, 16);
+    }
+    ix->cs_s_off[cs] = (uint32_t)off;
+  }
+
   ix->in_zp = t_zp(0);
   if (rc) { free(b.p); *out_blob = NULL; return rc; }
   blob_alloc(&b, 64);                       /* zeroed tail so 16-byte reads past the last row stay in bounds */

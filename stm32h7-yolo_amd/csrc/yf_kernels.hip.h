@@ -314,10 +314,13 @@ __device__ __forceinline__ PassS load_pass_s(const uint8_t* pass) {
 // alignment, and every size in it follows from the network's architecture alone -- so the byte offsets are constants of the
 // build.  Kernels address tab + constant (no descriptor fetch in front of every stage's first table load); the engine
 // compares this plan with the index the host preparation produced and refuses to start on any difference.
-struct TablePlan { int w_off[YF_N_DENSE], c_off[YF_N_DENSE], g_off[YF_N_DW], lut_off, total; };
+struct TablePlan { int w_off[YF_N_DENSE], c_off[YF_N_DENSE], g_off[YF_N_DW], lut_off, total;
+                   int vb_off[YF_N_CS], vb_bytes[YF_N_CS], sb_off[YF_N_CS]; };     // constant blocks of the fused kernel (yf_tables.h)
 constexpr int PLAN_COUT[YF_N_DENSE] = {8, 4, 18, 6, 36, 6, 18, 24, 8, 40, 8, 40, 8, 24, 40, 32, 18};
 constexpr int PLAN_KROW[YF_N_DENSE] = {YF_CONV1_KROW, 16, 16, 32, 16, 48, 16, 48, 32, 16, 48, 16, 48, 16, 48, 48, 32};
 constexpr int PLAN_DWC[YF_N_DW] = {8, 18, 36, 24, 40, 40, 40};
+constexpr int plan_passes(int cs) { return yf_cs_dense[cs] >= 0 ? (PLAN_COUT[yf_cs_dense[cs]] + 3) / 4 : (PLAN_DWC[yf_cs_dw[cs]] + 3) / 4; }
+constexpr int plan_wbytes(int cs) { return yf_cs_dense[cs] >= 0 ? ((PLAN_COUT[yf_cs_dense[cs]] + 3) & ~3) * PLAN_KROW[yf_cs_dense[cs]] : 0; }
 constexpr TablePlan make_plan() {
   TablePlan p = {};
   int off = YF_INDEX_RESERVED;
@@ -328,6 +331,12 @@ constexpr TablePlan make_plan() {
   }
   for (int i = 0; i < YF_N_DW; ++i) { off = (off + 15) & ~15; p.g_off[i] = off; off += ((PLAN_DWC[i] + 3) / 4) * YF_DW_GROUP_BYTES; }
   off = (off + 15) & ~15; p.lut_off = off; off += YF_N_LUT * 256 + YF_ADDLUT_BYTES;
+  for (int cs = 0; cs < YF_N_CS; ++cs) {
+    const int bytes = yf_cs_dense[cs] >= 0 ? plan_wbytes(cs) + plan_passes(cs) * (int)sizeof(yf_pass_v) + (yf_cs_add[cs] >= 0 ? 2048 : 0)
+                                           : plan_passes(cs) * YF_DWV_GROUP_BYTES;
+    off = (off + 15) & ~15; p.vb_off[cs] = off; p.vb_bytes[cs] = (bytes + 15) & ~15; off += p.vb_bytes[cs];
+  }
+  for (int cs = 0; cs < YF_N_CS; ++cs) { off = (off + 15) & ~15; p.sb_off[cs] = off; off += plan_passes(cs) * (int)sizeof(yf_pass_s); }
   off = (off + 15) & ~15; off += 64;            // zeroed tail (16-byte reads past the last row stay in bounds)
   p.total = off;
   return p;
@@ -818,6 +827,343 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
 }
 
 #ifndef YF_GENERIC
+// ================================================================================================ lean stages (round 3)
+// The 56x56 fused kernel's own forms of the dense and depthwise stages.  What changes against dense_stage / dw_mfma_stage
+// (which the 160x160 kernels keep using):
+//   * a stage's constants come from an LDS RING SLOT, not from global memory: one LDS-DMA per stage (global_load_lds_dwordx4, no
+//     registers), issued one stage ahead, brings the stage's whole vector-side block (weights in A-fragment order, {2M, ZR} per
+//     pass, the residual-add tables); every wave then reads its fragments with ds_read_b128 (~100 cycles instead of a global
+//     load's ~1-2 k).  The scalar side ({C64, shift} per pass) is a compact 6.7 KB array read with scalar loads.
+//   * lanes that hold an all-zero A fragment read it from a zeroed LDS region at the same immediate offsets: no exec masking, no
+//     zero-filling moves per chunk.
+//   * stages on the 7x7 grid take ONE FRAME PER TILE (49 of 64 lanes, the same efficiency as 196 pixels in 4 linear tiles):
+//     a lane's pixel offsets are per-lane constants and a tile adds a scalar frame offset -- no per-job index arithmetic.
+//   * the depthwise stages read the offsets of a job (row block, column segment, frame pair) from a small LDS table built once
+//     per workgroup instead of deriving them with ~35 scalar instructions per job.
+#ifndef YF_V2
+#define YF_V2 (YF_EXP == 1)
+#endif
+namespace v2 {
+constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LDS offset 0 (absolute addressing, as before)
+constexpr int JT = LUT_B, JT_B = 512;                         // depthwise job tables
+constexpr int ZERO = JT + JT_B, ZERO_B = 640;                 // zeros: the A fragments of the lanes outside a row block
+constexpr int SLOT0 = ZERO + ZERO_B, SLOT_B = 2816;           // two ring slots for the constant blocks of consecutive const-stages
+constexpr int PRE_B = SLOT0 + 2 * SLOT_B;                     // the frame arenas follow
+constexpr int slot(int cs) { return SLOT0 + (cs & 1) * SLOT_B; }
+constexpr int max_block() { int m = 0; for (int i = 0; i < YF_N_CS; ++i) m = PLAN.vb_bytes[i] > m ? PLAN.vb_bytes[i] : m; return m; }
+static_assert(max_block() <= SLOT_B && SLOT0 % 16 == 0 && SLOT_B % 16 == 0, "a constant block fits a ring slot");
+// job tables of the depthwise stages (8 bytes per job of one channel group): dw3 | dw10 | dw15 | dw27 | dw32/38/49
+constexpr int JT_DW3 = 0, JT_DW10 = 224, JT_DW15 = 288, JT_DW27 = 352, JT_DW32 = 384;
+static_assert(JT_DW32 + 32 <= JT_B, "job tables fit");
+
+typedef const __attribute__((address_space(3))) v4i* lds_v4i_ptr;
+typedef const __attribute__((address_space(3))) v4u* lds_v4u_ptr;
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+typedef const __attribute__((address_space(3))) v2u* lds_u2_ptr;
+__device__ __forceinline__ v4i lds_v4i(uint32_t a) { return *(lds_v4i_ptr)a; }
+__device__ __forceinline__ v4u lds_v4u(uint32_t a) { return *(lds_v4u_ptr)a; }
+
+// LDS-DMA of const-stage CS's block into its ring slot: wave w moves bytes [1024 w, 1024 w + 1024) -- one wave-instruction of
+// 64 x 16 bytes, no registers.  The compiler does not see the transfer (inline assembly): whoever reads the slot does so behind
+// an explicit s_waitcnt vmcnt(0) + barrier (V2_SYNC in the kernel).  M0 carries the LDS destination and is restored.
+template <int CS>
+__device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, int wave, int lane) {
+  constexpr int BYTES = PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
+  if (wave < NCHUNK) {
+    const int off = wave * 1024 + lane * 16;
+    if (off < BYTES) {
+      const uint8_t* src = tab + PLAN.vb_off[CS] + off;
+      const uint32_t dst = (uint32_t)(slot(CS) + wave * 1024);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+}
+
+// floor(p / W) for p < 2048 by one multiply and one shift (checked exhaustively at compile time)
+template <int W> struct DivW {
+  static constexpr uint32_t M = (65536 + W - 1) / W;
+  static constexpr bool ok() { for (uint32_t p = 0; p < 2048; ++p) if (((p * M) >> 16) != p / W) return false; return true; }
+  static_assert(ok(), "multiply-shift division is exact on [0, 2048)");
+  __device__ static __forceinline__ int div(int p) { return (int)(((uint32_t)p * M) >> 16); }
+};
+
+// residual-add context of the lean stages: the two 256-entry int32 tables sit in the stage's ring slot at LA / LA + 1024
+template <int EPI, int LUT_ID, int LA>
+__device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char* headpix, int chq, const int (&idx)[4], const AddK& ad) {
+  if constexpr (EPI == EPI_LUT) {
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+  } else if constexpr (EPI == EPI_RAW) {
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
+  } else if constexpr (EPI == EPI_ADD) {
+    typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
+    const uint32_t o = lds_u32(addpix + chq) ^ 0x80808080u;
+    v4i sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      sum[j] = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255)) + *(lds_i32_ptr)(uint32_t)(LA + 1024 + 4 * idx[j]);
+    int r[4];
+    requant4<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro},
+                    v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
+  } else {  // head: 18 channels per pixel, 2-byte aligned
+    const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(headpix + chq);
+    dst[0] = (uint16_t)v;
+    if (chq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
+  }
+}
+
+// ---- dense 1x1 (lane-private MFMA, see dense_stage), constants from ring slot CS
+template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB, int CS>
+YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const AddK ad, int wave, int lane) {
+  constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
+  constexpr int P = IN::P, TOT = F * P;
+  constexpr bool FRAME_TILES = P <= 64;                       // one frame per tile (7x7 grid): no per-job index arithmetic
+  constexpr int MT = FRAME_TILES ? F : (TOT + 63) / 64;
+  constexpr int JOBS = NCH * MT, KROW = 16 * KS;
+  constexpr int SLOT = slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB, LA = PV + NP * (int)sizeof(yf_pass_v);
+  static_assert(yf_cs_dense[CS] >= 0 && KROW == PLAN_KROW[yf_cs_dense[CS]] && NP == plan_passes(CS), "stage and constant block agree");
+  static_assert((EPI == EPI_ADD) == (yf_cs_add[CS] >= 0), "residual-add tables travel with their stage");
+  static_assert(OUT::P == P || EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "1x1 conv keeps the grid");
+  static_assert(IN::FS == OUT::FS && IN::FS == ADDB::FS, "one frame stride per stage");
+  static_assert(IN::S >= 16 * (KS - 1) + BW && (BW == 4 || BW == 8 || BW == 16), "the pixel vector must cover all k-steps");
+  static_assert(IN::RS == IN::W && IN::PT == 0 && IN::PL == 0, "dense inputs are plain buffers");
+  static_assert(F <= 2 || FRAME_TILES, "linear tiles split at one frame boundary");
+  const int g = lane >> 4, c = lane & 15;
+  const bool a_on = (c >> 2) == g;
+  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + (c & 3) * KROW) : (uint32_t)ZERO;      // A fragments: row 4*pass + (c&3), or zeros
+  const uint32_t a_step = a_on ? (uint32_t)(TPJ * 4 * KROW) : 0u;
+  const uint8_t* sc = tab + PLAN.sb_off[CS];
+  // per-lane pixel offsets of the frame-per-tile form
+  int in_c = 0, out_c = 0, add_c = 0;
+  if constexpr (FRAME_TILES) {
+    const int p = min(lane, P - 1);                            // surplus lanes redo the last pixel (same value, same address)
+    in_c = IN::OFF + p * IN::S;
+    if constexpr (EPI == EPI_HEAD || EPI == EPI_HEAD_LDS) out_c = p * 18;
+    else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) out_c = OUT::OFF + p * OUT::S + OUT_CH0;
+    else { const int y = DivW<OUT::W>::div(p); out_c = OUT::at(y, p - y * OUT::W) + OUT_CH0; }
+    add_c = ADDB::OFF + p * ADDB::S;
+  }
+  int j0, j1;
+  job_range<JOBS, NW>(wave, j0, j1);
+  int chunk = (int)((uint32_t)j0 / (uint32_t)MT), mt = j0 - chunk * MT, left = j1 - j0;
+  while (left > 0) {
+    // ---- the chunk's constants: TPJ passes of {A fragments, 2M, ZR} from the ring slot, {C64, shift} by scalar loads
+    v4i a[TPJ][KS];
+    PassV pv[TPJ];
+    PassS ksr[TPJ];
+    const uint32_t a_addr = a_lane + (uint32_t)chunk * a_step;
+#pragma unroll
+    for (int t = 0; t < TPJ; ++t) {
+      const int ps = chunk * TPJ + t;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[t][ks] = lds_v4i(a_addr + (uint32_t)(t * 4 * KROW + 16 * ks));
+      pv[t].m2 = lds_v4u((uint32_t)(PV + ps * 32));
+      pv[t].zr = lds_v4u((uint32_t)(PV + ps * 32 + 16));
+      const uint8_t* s = sc + min(ps, NP - 1) * (int)sizeof(yf_pass_s);
+      ksr[t] = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
+    }
+    const int n = min(left, MT - mt);
+    for (int k = 0; k < n; ++k, ++mt) {
+      const char* src; char* dstpix = nullptr; const char* addpix = nullptr; char* headpix = nullptr;
+      if constexpr (FRAME_TILES) {
+        char* fbase = frames + mt * IN::FS;
+        src = fbase + in_c;
+        dstpix = fbase + out_c; addpix = fbase + add_c;
+        if constexpr (EPI == EPI_HEAD) headpix = out_all + mt * OUT_FRAME_BYTES + out_c;
+        if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + out_c;
+      } else {
+        const int q = min(mt * 64 + lane, TOT - 1);
+        const bool hi = F > 1 && q >= P;
+        const int p = hi ? q - P : q;
+        char* fbase = frames + (hi ? IN::FS : 0);
+        src = fbase + IN::OFF + p * IN::S;
+        if constexpr (EPI == EPI_HEAD) headpix = out_all + (hi ? OUT_FRAME_BYTES : 0) + p * 18;
+        else if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + p * 18;
+        else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) dstpix = fbase + OUT::OFF + p * OUT::S + OUT_CH0;
+        else { const int y = DivW<OUT::W>::div(p); dstpix = fbase + OUT::at(y, p - y * OUT::W) + OUT_CH0; }
+        if constexpr (EPI == EPI_ADD) addpix = fbase + ADDB::OFF + p * ADDB::S;
+      }
+      v4i b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
+      const char* last = src + 16 * (KS - 1);
+      if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
+      else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, any_value(), any_value()}; }
+      else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), any_value(), any_value(), any_value()};
+#pragma unroll
+      for (int t = 0; t < TPJ; ++t) {
+        const int ps = chunk * TPJ + t;
+        if (ps < NP) {                                          // uniform
+          v4i acc = {ACC0, ACC0, ACC0, ACC0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
+          int idx[4];
+          requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
+          epilogue2<EPI, LUT_ID, LA>(dstpix, addpix, headpix, ps * 4, idx, ad);
+        }
+      }
+    }
+    left -= n; ++chunk; mt = 0;
+  }
+}
+
+// ---- conv2d_1 (see conv1_stage), constants from ring slot CS
+template <int F, int NW, int CS, class IN = B_IN, class OUT = B_T1>
+YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, int wave, int lane) {
+  constexpr int P = OUT::P, W1 = OUT::W, RSW = IN::RS, TOT = F * P;
+  constexpr int MT = (TOT + 63) / 64;
+  constexpr int SLOT = slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB;
+  static_assert(F <= 2, "linear tiles split at one frame boundary");
+  const int g = lane >> 4, c = lane & 15;
+  const bool a_on = (c >> 2) == g;
+  const uint32_t a_addr = a_on ? (uint32_t)(SLOT + (c & 3) * YF_CONV1_KROW) : (uint32_t)ZERO;
+  const uint8_t* sc = tab + PLAN.sb_off[CS];
+  v4i a[2][3];
+  PassV pv[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) a[ps][ks] = lds_v4i(a_addr + (uint32_t)(ps * 4 * YF_CONV1_KROW + 16 * ks));
+    pv[ps].m2 = lds_v4u((uint32_t)(PV + ps * 32));
+    pv[ps].zr = lds_v4u((uint32_t)(PV + ps * 32 + 16));
+  }
+  int j0, j1;
+  job_range<MT, NW>(wave, j0, j1);
+  const AddK ad = {};
+  for (int mt = j0; mt < j1; ++mt) {
+    const int q = min(mt * 64 + lane, TOT - 1);
+    const bool hi = F > 1 && q >= P;
+    const int p = hi ? q - P : q;
+    const int oy = DivW<W1>::div(p), ox = p - oy * W1;
+    char* fbase = frames + (hi ? IN::FS : 0);
+    // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
+    const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
+    const v4i b1 = {(int)src[RSW + 1], (int)src[RSW + 2], (int)src[2 * RSW], (int)src[2 * RSW + 1]};
+    const v4i b2 = {(int)src[2 * RSW + 2], any_value(), any_value(), any_value()};
+    char* dstpix = fbase + OUT::at(oy, ox);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const uint8_t* s = sc + ps * (int)sizeof(yf_pass_s);
+      const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
+      v4i acc = {ACC0, ACC0, ACC0, ACC0};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][1], b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
+      int idx[4];
+      requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
+      epilogue2<EPI_LUT, YF_L_LEAKY2, 0>(dstpix, nullptr, nullptr, 4 * ps, idx, ad);
+    }
+  }
+}
+
+// ---- depthwise 3x3 (one-hot lane-private MFMA, see dw_mfma_stage): geometry of a stage instance
+template <int F, int STRIDE, class IN, class OUT>
+struct DwGeo {
+  static constexpr int W = OUT::W, H = OUT::H;
+  static constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;
+  static constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4, NFP = F / FL;
+  static constexpr int JPG = NFP * NRB * NSEG;                 // jobs per channel group
+  static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
+  static_assert(IN::FS == OUT::FS, "one frame stride per stage");
+  static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
+  // offsets (relative to the workgroup's frame arenas) of job jj: the top-left tap of lane (0,0) and its output pixel
+  __device__ static __forceinline__ uint2 job(int jj) {
+    const int fp = jj / (NRB * NSEG); int rem = jj - fp * (NRB * NSEG);
+    const int rb = rem / NSEG, seg = rem - rb * NSEG;
+    const int oy0 = min(rb * 4, H - 4);
+    const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
+    const int fb = fp * FL * IN::FS;
+    return uint2{(uint32_t)(fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
+  }
+};
+// the job table of one stage geometry, written once per workgroup (kernel prologue)
+template <int F, int STRIDE, class IN, class OUT, int JTOFF>
+__device__ __forceinline__ void fill_jobtab(char* smem, int tid) {
+  typedef DwGeo<F, STRIDE, IN, OUT> G;
+  static_assert(JTOFF % 8 == 0 && JTOFF + G::JPG * 8 <= JT_B, "job table in bounds");
+  if (tid < G::JPG) *reinterpret_cast<uint2*>(smem + JT + JTOFF + 8 * tid) = G::job(tid);
+}
+
+template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID, int CS, int JTOFF>
+YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wave, int lane) {
+  typedef DwGeo<F, STRIDE, IN, OUT> G;
+  constexpr int W = G::W, FL = G::FL, JPG = G::JPG;
+  constexpr int NG = (C + 3) / 4, JOBS = NG * JPG;
+  constexpr int DROW = STRIDE * IN::RS * IN::S;                // input bytes between consecutive output rows
+  constexpr int TS = IN::S, TR = IN::RS * IN::S;               // tap strides: +1 column, +1 row
+  constexpr int SLOT = slot(CS);
+  static_assert(yf_cs_dw[CS] >= 0 && NG == plan_passes(CS), "stage and constant block agree");
+  const int g = lane >> 4, c = lane & 15;
+  const int fl = (FL == 2) ? (c >> 3) : 0;
+  const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);      // surplus lanes duplicate the last column (idempotent)
+  const char* lane_in = frames + fl * IN::FS + g * DROW + xl * STRIDE * IN::S;     // this lane's pixel: row oy0+g, col x0+xl
+  char* lane_out = frames + fl * IN::FS + (g * W + xl) * OUT::S;
+  const bool a_on = (c >> 2) == g;
+  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + 4 * (c & 3)) : (uint32_t)ZERO;   // masked weight dwords of channel c&3: +16*tap
+  const uint32_t a_step = a_on ? (uint32_t)YF_DWV_GROUP_BYTES : 0u;
+  const uint8_t* sc = tab + PLAN.sb_off[CS];
+  int j, j1;
+  job_range<JOBS, NW>(wave, j, j1);
+  int cg = (int)((uint32_t)j / (uint32_t)JPG), jj = j - cg * JPG, left = j1 - j;
+  while (left > 0) {
+    const uint32_t wa = a_lane + (uint32_t)cg * a_step;
+    v4i a0, a1, a2 = {0, 0, 0, 0};
+    a0 = v4i{(int)*(lds_u32_ptr)(wa), (int)*(lds_u32_ptr)(wa + 16), (int)*(lds_u32_ptr)(wa + 32), (int)*(lds_u32_ptr)(wa + 48)};
+    a1 = v4i{(int)*(lds_u32_ptr)(wa + 64), (int)*(lds_u32_ptr)(wa + 80), (int)*(lds_u32_ptr)(wa + 96), (int)*(lds_u32_ptr)(wa + 112)};
+    a2[0] = (int)*(lds_u32_ptr)(wa + 128);
+    PassV pv;
+    pv.m2 = lds_v4u((uint32_t)(SLOT + cg * YF_DWV_GROUP_BYTES + 144));
+    pv.zr = lds_v4u((uint32_t)(SLOT + cg * YF_DWV_GROUP_BYTES + 160));
+    const uint8_t* s = sc + cg * (int)sizeof(yf_pass_s);
+    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
+    const char* lin = lane_in + 4 * cg;
+    char* lout = lane_out + 4 * cg;
+    auto taps = [&](int job, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
+      const v2u e = *(lds_u2_ptr)(uint32_t)(JT + JTOFF + 8 * job);
+      const char* src = lin + e[0];
+      b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
+      b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
+      b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
+      dst = lout + e[1];
+    };
+    auto conv = [&](const v4i& b0, const v4i& b1, const v4i& b2) {
+      v4i acc = {ACC0, ACC0, ACC0, ACC0};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+      return __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
+    };
+    auto finish = [&](const v4i& acc, char* dst) {
+      int idx[4];
+      requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
+      *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+    };
+    const int n = min(left, JPG - jj);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {               // two jobs in flight: the second job's tap reads and MFMAs overlap the first one's epilogue
+      v4i p0, p1, p2 = {0, any_value(), any_value(), any_value()}, q0, q1, q2 = {0, any_value(), any_value(), any_value()};
+      char *dp, *dq;
+      taps(jj + i, p0, p1, p2, dp);
+      taps(jj + i + 1, q0, q1, q2, dq);
+      const v4i ap = conv(p0, p1, p2);
+      const v4i aq = conv(q0, q1, q2);
+      finish(ap, dp);
+      finish(aq, dq);
+    }
+    if (i < n) {
+      v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
+      char* dst;
+      taps(jj + i, b0, b1, b2, dst);
+      finish(conv(b0, b1, b2), dst);
+    }
+    left -= n; ++cg; jj = 0;
+  }
+}
+}  // namespace v2
+
 // ------------------------------------------------------------------------------------------------ debug dump
 // Observer-style per-stage dump (reference observer API, ai_platform_interface.h:684-731): logical NHWC bytes.
 template <class B, int C, int F, int NT>
@@ -887,8 +1233,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
   constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
-  char* out_all = smem + LUT_BYTES;
-  char* frames = smem + LUT_BYTES + OUT_ALL_BYTES;
+#if YF_V2
+  constexpr int PRE = v2::PRE_B;                         // LUTs | depthwise job tables | zeros | two constant ring slots
+#else
+  constexpr int PRE = LUT_BYTES;                         // LUTs | residual-add tables
+#endif
+  char* out_all = smem + PRE;
+  char* frames = smem + PRE + OUT_ALL_BYTES;
   long parked_first = -1;                                // first frame of the group whose T15 waits in the scratch
   const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab = prm.tab;
@@ -903,8 +1254,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #if YF_TOGGLED(1)
   if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+#if YF_V2
+  for (int i = tid0; i < v2::LUT_B / 16; i += NT)
+    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
+  for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
+  {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
+    typedef TailBufs<tail_batch<DUMP>() ? FRAME_BYTES / 2 : FRAME_BYTES> UT;
+    constexpr int FTT = tail_batch<DUMP>() ? 2 * F : F;
+    v2::fill_jobtab<F, 1, B_T1, B_T2, v2::JT_DW3>(smem, tid0);
+    v2::fill_jobtab<F, 2, B_T4, B_T6, v2::JT_DW10>(smem, tid0);
+    v2::fill_jobtab<F, 1, B_T8, B_T9, v2::JT_DW15>(smem, tid0);
+    v2::fill_jobtab<FTT, 2, typename UT::T15, typename UT::T17, v2::JT_DW27>(smem, tid0);
+    v2::fill_jobtab<FTT, 1, typename UT::T19, typename UT::T20, v2::JT_DW32>(smem, tid0);
+  }
+#else
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
+#endif
 
   const long n_groups = (prm.n + F - 1) / F;
   const AddK no_add = {};
@@ -923,8 +1289,25 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   long long* prof_out = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 80;
 #define YF_SYNC() do { if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
                        if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
+#elif YF_V2
+  // the barrier behind a stage also publishes the LDS-DMA of the NEXT stage's constants, which the compiler does not see
+#define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #else
 #define YF_SYNC() __syncthreads()
+#endif
+  // Stage calls: the lean forms (constants from an LDS ring slot, fetched one stage ahead by YF_FETCH) or the round-2 forms
+#if YF_V2
+#define YF_FETCH(CS, WV, LN) v2::fetch_consts<CS>(tab, WV, LN)
+#define YF_CONV1(WV, LN, CS) v2::conv1_2_stage<F, NW, CS>(frames, tab, WV, LN)
+#define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
+  v2::dense2_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS>(frames, out_all, tab, AD, WV, LN)
+#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) v2::dw2_stage<FR, NW, STRIDE, IN, OUT, C, LUT, CS, v2::JTOFF>(frames, tab, WV, LN)
+#else
+#define YF_FETCH(CS, WV, LN) do {} while (0)
+#define YF_CONV1(WV, LN, CS) conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), WV, LN, vz)
+#define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
+  dense_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB>(frames, out_all, tab, load_dense(tab, DI), AD, WV, LN, vz)
+#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) dw_mfma_stage<FR, NW, STRIDE, IN, OUT, C, LUT>(frames, tab, load_dw(tab, WI), WV, LN, vz)
 #endif
 #define YF_DUMP(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
@@ -980,24 +1363,29 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
     if constexpr (CAM) stage_input_cam<F, NT>(frames, reinterpret_cast<const uint8_t*>(prm.in), first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
     else stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
+    YF_FETCH(0, W_f, L_f);                                                                            // conv2d_1's constants -> ring slot 0
     fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
     YF_SYNC();
     YF_STAGE_END()
     YF_PRIO(1);
-    conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), W_f, L_f, vz);                        // conv2d_1
+    YF_FETCH(1, W_f, L_f);
+    YF_CONV1(W_f, L_f, 0);                                                                            // conv2d_1
     YF_SYNC(); YF_DUMP(B_T1, 8, T1)
     YF_STAGE_END()
     YF_PRIO(2);
-    dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), W_f, L_f, vz);   // conv2d_3
+    YF_FETCH(2, W_f, L_f);
+    YF_DW(F, 1, B_T1, B_T2, 8, YF_L_LEAKY4, YF_W_DW3, W_f, L_f, 1, JT_DW3);                              // conv2d_3
     YF_SYNC(); YF_DUMP(B_T2, 8, T2)
     YF_STAGE_END()
     YF_PRIO(3);
-    dense_stage<F, NW, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3>(frames, out_all, tab, load_dense(tab, YF_D_C5), no_add, W_f, L_f, vz);   // conv2d_5
+    YF_FETCH(3, W_f, L_f);
+    YF_DENSE(F, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3, YF_D_C5, no_add, W_f, L_f, 2);              // conv2d_5
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
     YF_PRIO(4);
     fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid_f);
-    dense_stage<F, NW, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, out_all, tab, load_dense(tab, YF_D_C6), no_add, W_f, L_f, vz);   // conv2d_6
+    YF_FETCH(4, W_f, L_f);
+    YF_DENSE(F, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     YF_PRIO(5);
@@ -1008,28 +1396,34 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     pool8_v<F, NT>(frames, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
     YF_PRIO(7);
-    dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), W_m, L_m, vz);   // conv2d_10
+    YF_FETCH(5, W_m, L_m);
+    YF_DW(F, 2, B_T4, B_T6, 18, YF_L_LEAKY11, YF_W_DW10, W_m, L_m, 4, JT_DW10);                          // conv2d_10
     YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
     YF_PRIO(8);
-    dense_stage<F, NW, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C12), no_add, W_m, L_m, vz);
+    YF_FETCH(6, W_m, L_m);
+    YF_DENSE(F, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);            // conv2d_12
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
     YF_PRIO(9);
     fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid_m);
-    dense_stage<F, NW, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, out_all, tab, load_dense(tab, YF_D_C13), no_add, W_m, L_m, vz);  // conv2d_13
+    YF_FETCH(7, W_m, L_m);
+    YF_DENSE(F, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
     YF_PRIO(10);
-    dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), W_m, L_m, vz);   // conv2d_15
+    YF_FETCH(8, W_m, L_m);
+    YF_DW(F, 1, B_T8, B_T9, 36, YF_L_LEAKY16, YF_W_DW15, W_m, L_m, 7, JT_DW15);                          // conv2d_15
     YF_SYNC(); YF_DUMP(B_T9, 36, T9)
     YF_STAGE_END()
     YF_PRIO(11);
-    dense_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), W_m, L_m, vz);
+    YF_FETCH(9, W_m, L_m);
+    YF_DENSE(F, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, YF_D_C17, addctx(YF_A_ADD18), W_m, L_m, 8);   // conv2d_17 + eltwise_18
     YF_SYNC(); YF_DUMP(B_T11, 6, T11)
     YF_STAGE_END()
     YF_PRIO(12);
-    dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, W_m, L_m, vz);  // conv2d_19 -> concat_22
+    YF_FETCH(10, W_m, L_m);
+    YF_DENSE(F, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     YF_PRIO(13);
@@ -1046,13 +1440,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
           const int f = j / WI, k0 = (j - f * WI) * 64;
           if (k0 + L_m < PV)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(park + (f * PV + k0 + L_m) * 16),
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(LUT_BYTES + (2 * f + 1) * U::T15::FS + 16 * k0),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(PRE + (2 * f + 1) * U::T15::FS + 16 * k0),
                                              16, 0, 0);
         }
       }
     }
     fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
-    dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, W_m, L_m, vz);
+    YF_FETCH(11, W_m, L_m);
+    YF_DENSE(F, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
     if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
@@ -1095,60 +1490,72 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
     YF_PRIO(14);
     pool25<FT, NT, typename U::T15, typename U::T30>(frames, tid_t);                                  // pool_25 + QUANTIZE#45
-    dw_mfma_stage<FT, NW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), W_t, L_t, vz);   // conv2d_27
+    YF_FETCH(12, W_t, L_t);
+    YF_DW(FT, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, YF_W_DW27, W_t, L_t, 11, JT_DW27);    // conv2d_27
     YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
     YF_PRIO(15);
-    dense_stage<FT, NW, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, W_t, L_t, vz);
+    YF_FETCH(13, W_t, L_t);
+    YF_DENSE(FT, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18, YF_D_C29, no_add, W_t, L_t, 12);   // conv2d_29
     if constexpr (!BATCH) decode_prev(W_t, L_t);                                                    // previous group's boxes
     YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
     YF_STAGE_END()
     YF_PRIO(16);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
-    dense_stage<FT, NW, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, W_t, L_t, vz);  // conv2d_30
+    YF_FETCH(14, W_t, L_t);
+    YF_DENSE(FT, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
     YF_STAGE_END()
     YF_PRIO(17);
-    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), W_t, L_t, vz);   // conv2d_32
+    YF_FETCH(15, W_t, L_t);
+    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY33, YF_W_DW32, W_t, L_t, 14, JT_DW32);    // conv2d_32
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T20)
     YF_STAGE_END()
     YF_PRIO(18);
-    dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), W_t, L_t, vz);
+    YF_FETCH(16, W_t, L_t);
+    YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, YF_D_C34, addctx(YF_A_ADD35), W_t, L_t, 15);   // conv2d_34 + eltwise_35
     YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22)
     YF_STAGE_END()
     YF_PRIO(19);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
-    dense_stage<FT, NW, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, W_t, L_t, vz);  // conv2d_36
+    YF_FETCH(17, W_t, L_t);
+    YF_DENSE(FT, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
     YF_STAGE_END()
     YF_PRIO(20);
-    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), W_t, L_t, vz);   // conv2d_38
+    YF_FETCH(18, W_t, L_t);
+    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY39, YF_W_DW38, W_t, L_t, 17, JT_DW32);    // conv2d_38
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T24)
     YF_STAGE_END()
     YF_PRIO(21);
-    dense_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), W_t, L_t, vz);
+    YF_FETCH(19, W_t, L_t);
+    YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, YF_D_C40, addctx(YF_A_ADD41), W_t, L_t, 18);   // conv2d_40 + eltwise_41
     YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26)
     YF_STAGE_END()
     YF_PRIO(22);
-    dense_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, W_t, L_t, vz);  // conv2d_42 -> concat_46
+    YF_FETCH(20, W_t, L_t);
+    YF_DENSE(FT, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30)
     YF_STAGE_END()
     YF_PRIO(23);
     fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
-    dense_stage<FT, NW, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, W_t, L_t, vz);
+    YF_FETCH(21, W_t, L_t);
+    YF_DENSE(FT, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19, YF_D_C47, no_add, W_t, L_t, 20);   // conv2d_47
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T31)
     YF_STAGE_END()
     YF_PRIO(24);
-    dw_mfma_stage<FT, NW, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), W_t, L_t, vz);   // conv2d_49
+    YF_FETCH(22, W_t, L_t);
+    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY50, YF_W_DW49, W_t, L_t, 21, JT_DW32);    // conv2d_49
     YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T32)
     YF_STAGE_END()
     YF_PRIO(25);
-    dense_stage<FT, NW, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, W_t, L_t, vz);
+    YF_FETCH(23, W_t, L_t);
+    YF_DENSE(FT, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33, YF_D_C51, no_add, W_t, L_t, 22);   // conv2d_51
     YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
     YF_STAGE_END()
     YF_PRIO(26);
     if constexpr (!BATCH) {
-      dense_stage<FT, NW, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
+      YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
       YF_SYNC();
       // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
       const long valid = min((long)F, prm.n - first);
@@ -1158,7 +1565,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
       prev_first = first;
     } else {
-      dense_stage<FT, NW, 1, 2, 16, typename U::T33, typename U::HEAD, 0, 18, EPI_HEAD_LDS, 0, typename U::T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, W_t, L_t, vz);
+      YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::HEAD, 0, 18, EPI_HEAD_LDS, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
       YF_SYNC();
       // heads: 882 bytes per frame from its set -> HBM, 2-byte granules; the boxes of set w are decoded by wave w meanwhile
       constexpr int H16 = OUT_FRAME_BYTES / 2;
@@ -1182,6 +1589,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
   }
+#undef YF_FETCH
+#undef YF_CONV1
+#undef YF_DENSE
+#undef YF_DW
 #undef YF_DUMP
 #undef YF_STAGE_END
 #undef YF_PRIO
@@ -1189,7 +1600,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)LUT_BYTES + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::PRE_B : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 

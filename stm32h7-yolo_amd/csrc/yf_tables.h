@@ -88,6 +88,27 @@ enum {
  * dword.  Row layout [8 cout][3 steps][16 B]. */
 #define YF_CONV1_KROW 48
 
+/* ---- constant blocks of the 56x56 fused kernel (round 3) -----------------------------------------------------------------
+ * The 24 stages that have constants ("const-stages", execution order) each own ONE contiguous block of everything their
+ * VECTOR side needs, so that a single LDS-DMA per stage brings it into an LDS ring slot one stage ahead of its use:
+ *   dense stage : [cout_pad4 x krow weight rows][cout_pad4/4 x yf_pass_v][residual add: tables A and B, 2 x 256 x int32]
+ *   depthwise   : per group of 4 channels [9 taps x 4 masked weight dwords (144 B)][yf_pass_v]          (YF_DWV_GROUP_BYTES)
+ * and one compact array of the SCALAR side (yf_pass_s per pass / group), read with scalar loads: all of them together are
+ * 6.7 KB and stay in the scalar cache.  Same numbers as yf_pass, split by the register file they are loaded into. */
+typedef struct { uint32_t mult2[4]; uint32_t zr[4]; } yf_pass_v;                 /* 32 B */
+typedef struct { uint32_t c64[4][2]; int32_t rshift[4]; } yf_pass_s;             /* 48 B */
+#define YF_DWV_GROUP_BYTES (36 * 4 + 32)
+#define YF_N_CS 24
+/* const-stage -> index of its dense / depthwise / residual-add descriptor (-1: none) */
+#ifdef __cplusplus
+#define YF_CONST_TABLE constexpr
+#else
+#define YF_CONST_TABLE static const
+#endif
+YF_CONST_TABLE int8_t yf_cs_dense[YF_N_CS] = {0, -1, 1, 2, -1, 3, 4, -1, 5, 6, 7, -1, 8, 9, -1, 10, 11, -1, 12, 13, 14, -1, 15, 16};
+YF_CONST_TABLE int8_t yf_cs_dw[YF_N_CS]    = {-1, 0, -1, -1, 1, -1, -1, 2, -1, -1, -1, 3, -1, -1, 4, -1, -1, 5, -1, -1, -1, 6, -1, -1};
+YF_CONST_TABLE int8_t yf_cs_add[YF_N_CS]   = {-1, -1, -1, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, -1, 1, -1, -1, 2, -1, -1, -1, -1, -1};
+
 typedef struct {
   yf_dense dense[YF_N_DENSE];
   yf_dw    dw[YF_N_DW];
@@ -96,11 +117,13 @@ typedef struct {
   uint32_t total_bytes;
   int32_t  in_zp;            /* input zero point (-128): halo fill of the staged frame */
   int32_t  halo_zp[YF_N_DW]; /* zero point of each depthwise INPUT buffer: its halo fill value */
+  uint32_t cs_v_off[YF_N_CS], cs_v_bytes[YF_N_CS];   /* vector block of a const-stage (16-byte aligned, bytes a multiple of 16) */
+  uint32_t cs_s_off[YF_N_CS];                        /* its yf_pass_s array */
 } yf_table_index;
 
 /* The table blob starts with a copy of the index (so kernels fetch stage descriptors with scalar loads instead of
  * carrying ~120 dwords of kernel arguments in SGPRs). */
-#define YF_INDEX_RESERVED 768
+#define YF_INDEX_RESERVED 1024
 
 /* Channel order of concat_22's buffer T14: pool branch at [0,18), conv branch at [20,38) (4-byte aligned
  * starts so that packed 4-channel stores stay aligned); conv2d_23's k order follows it. */

@@ -11,7 +11,11 @@ import pytest
 from conftest import ROOT
 
 PKG = os.path.join(ROOT, "stm32h7-yolo_amd")
-N_DENSE, N_DW, N_ADD, N_LUT = 17, 7, 3, 19
+N_DENSE, N_DW, N_ADD, N_LUT, N_CS = 17, 7, 3, 19, 24
+# const-stages of the fused kernel in execution order: ("d", dense index) / ("w", depthwise index), residual-add index or None
+CONST_STAGES = [("d", 0, None), ("w", 0, None), ("d", 1, None), ("d", 2, None), ("w", 1, None), ("d", 3, None), ("d", 4, None), ("w", 2, None),
+                ("d", 5, 0), ("d", 6, None), ("d", 7, None), ("w", 3, None), ("d", 8, None), ("d", 9, None), ("w", 4, None), ("d", 10, 1),
+                ("d", 11, None), ("w", 5, None), ("d", 12, 2), ("d", 13, None), ("d", 14, None), ("w", 6, None), ("d", 15, None), ("d", 16, None)]
 DENSE_OPS = [1, 5, 6, 12, 13, 17, 19, 23, 29, 30, 34, 36, 40, 42, 47, 51, 53]
 DW_OPS = [3, 10, 15, 27, 32, 38, 49]
 LEAKY_LUT_IDS = {2: 0, 4: 1, 7: 2, 11: 4, 14: 5, 16: 6, 20: 7, 24: 8, 28: 10, 31: 11, 33: 12, 37: 13, 39: 14, 48: 16, 50: 17, 52: 18}
@@ -33,7 +37,8 @@ class Add(ctypes.Structure):
 
 class Index(ctypes.Structure):
     _fields_ = [("dense", Dense * N_DENSE), ("dw", Dw * N_DW), ("add", Add * N_ADD), ("lut_off", ctypes.c_uint32),
-                ("total_bytes", ctypes.c_uint32), ("in_zp", ctypes.c_int32), ("halo_zp", ctypes.c_int32 * N_DW)]
+                ("total_bytes", ctypes.c_uint32), ("in_zp", ctypes.c_int32), ("halo_zp", ctypes.c_int32 * N_DW),
+                ("cs_v_off", ctypes.c_uint32 * N_CS), ("cs_v_bytes", ctypes.c_uint32 * N_CS), ("cs_s_off", ctypes.c_uint32 * N_CS)]
 
 
 @pytest.fixture(scope="module")
@@ -63,12 +68,44 @@ def test_table_layout_matches_the_plan_compiled_into_the_kernels(prep):
     lays the blob out at run time.  Both must agree (the engine refuses to start otherwise)."""
     subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc")], stdout=subprocess.DEVNULL)
     net = ctypes.CDLL(os.path.join(PKG, "lib", "libyf_network.so"))
-    plan = (ctypes.c_int32 * 43)()
-    assert net.yf_network_table_plan(plan, 43) == 43
+    n = 43 + 3 * N_CS
+    plan = (ctypes.c_int32 * n)()
+    assert net.yf_network_table_plan(plan, n) == n
     ix = prep["ix"]
-    want = [d.w_off for d in ix.dense] + [d.c_off for d in ix.dense] + [d.g_off for d in ix.dw] + [ix.lut_off, ix.total_bytes]
+    want = [d.w_off for d in ix.dense] + [d.c_off for d in ix.dense] + [d.g_off for d in ix.dw] + [ix.lut_off, ix.total_bytes] + \
+        list(ix.cs_v_off) + list(ix.cs_v_bytes) + list(ix.cs_s_off)
     assert list(plan) == want
-    assert net.yf_network_table_plan(None, 0) == 43
+    assert net.yf_network_table_plan(None, 0) == n
+
+
+def test_constant_blocks_of_the_fused_kernel_regroup_the_same_numbers(prep):
+    """Round 3: every const-stage owns one contiguous block (weights | {mult2, zr} per pass | residual-add tables) that a single
+    LDS-DMA brings into an LDS ring slot, plus a compact array of the scalar side ({c64, rshift} per pass).  They must hold
+    exactly the bytes of the per-stage records the requantisation tests below check."""
+    ix, tab = prep["ix"], prep["tab"]
+    assert len(CONST_STAGES) == N_CS
+    for cs, (kind, i, add) in enumerate(CONST_STAGES):
+        v, vb, so = ix.cs_v_off[cs], ix.cs_v_bytes[cs], ix.cs_s_off[cs]
+        assert v % 16 == 0 and vb % 16 == 0 and so % 16 == 0 and vb <= 2816       # one ring slot of the kernel
+        if kind == "d":
+            d = ix.dense[i]
+            wb, npass = d.cout_pad4 * d.krow, d.cout_pad4 // 4
+            assert tab[v:v + wb] == tab[d.w_off:d.w_off + wb]
+            for p in range(npass):
+                rec = tab[d.c_off + 80 * p: d.c_off + 80 * (p + 1)]
+                assert tab[v + wb + 32 * p: v + wb + 32 * (p + 1)] == rec[:32]
+                assert tab[so + 48 * p: so + 48 * (p + 1)] == rec[32:]
+            if add is not None:
+                a0 = ix.lut_off + N_LUT * 256 + 2048 * add
+                assert tab[v + wb + 32 * npass: v + wb + 32 * npass + 2048] == tab[a0:a0 + 2048]
+        else:
+            d = ix.dw[i]
+            for g in range(d.ngroups):
+                rec = tab[d.g_off + 224 * g: d.g_off + 224 * (g + 1)]
+                assert tab[v + 176 * g: v + 176 * (g + 1)] == rec[:144 + 32]
+                assert tab[so + 48 * g: so + 48 * (g + 1)] == rec[144 + 32:]
+    scal = sorted(ix.cs_s_off)
+    assert scal[-1] + 48 * 10 - scal[0] <= 8192, "the scalar arrays stay compact (scalar-cache resident)"
 
 
 def test_quantize_multiplier_agrees_with_oracle(prep, oracle):
@@ -93,7 +130,7 @@ def test_mbqm_agrees_with_oracle(prep, oracle):
 def test_index_is_embedded_and_blocks_are_aligned(prep):
     ix, tab = prep["ix"], prep["tab"]
     assert tab[:ctypes.sizeof(Index)] == bytes(ix)
-    assert ctypes.sizeof(Index) <= 768
+    assert ctypes.sizeof(Index) <= 1024
     for d in ix.dense:
         assert d.w_off % 16 == 0 and d.c_off % 16 == 0 and d.krow % 16 == 0 and d.cout_pad4 % 4 == 0
     for d in ix.dw:
