@@ -24,7 +24,11 @@
 #endif
 #undef YF_LAUNDER
 #define YF_LAUNDER YF_LAUNDER_X
+#ifdef YF_V2_X              /* 0: the experimental namespace keeps the round-2 stage forms (constants from global memory) for A/B */
+#define YF_V2 YF_V2_X
+#endif
 #include "yf_kernels.hip.h"
+#undef YF_V2
 #undef YF_LAUNDER
 #undef YF_NS
 #undef YF_EXP

@@ -841,20 +841,17 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
 //   * the depthwise stages read the offsets of a job (row block, column segment, frame pair) from a small LDS table built once
 //     per workgroup instead of deriving them with ~35 scalar instructions per job.
 #ifndef YF_V2
-#define YF_V2 (YF_EXP == 1)
+#define YF_V2 1
 #endif
 namespace v2 {
 constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LDS offset 0 (absolute addressing, as before)
-constexpr int JT = LUT_B, JT_B = 512;                         // depthwise job tables
+constexpr int JT = LUT_B, JT_B = 896;                         // depthwise job tables
 constexpr int ZERO = JT + JT_B, ZERO_B = 640;                 // zeros: the A fragments of the lanes outside a row block
 constexpr int SLOT0 = ZERO + ZERO_B, SLOT_B = 2816;           // two ring slots for the constant blocks of consecutive const-stages
 constexpr int PRE_B = SLOT0 + 2 * SLOT_B;                     // the frame arenas follow
 constexpr int slot(int cs) { return SLOT0 + (cs & 1) * SLOT_B; }
 constexpr int max_block() { int m = 0; for (int i = 0; i < YF_N_CS; ++i) m = PLAN.vb_bytes[i] > m ? PLAN.vb_bytes[i] : m; return m; }
 static_assert(max_block() <= SLOT_B && SLOT0 % 16 == 0 && SLOT_B % 16 == 0, "a constant block fits a ring slot");
-// job tables of the depthwise stages (8 bytes per job of one channel group): dw3 | dw10 | dw15 | dw27 | dw32/38/49
-constexpr int JT_DW3 = 0, JT_DW10 = 224, JT_DW15 = 288, JT_DW27 = 352, JT_DW32 = 384;
-static_assert(JT_DW32 + 32 <= JT_B, "job tables fit");
 
 typedef const __attribute__((address_space(3))) v4i* lds_v4i_ptr;
 typedef const __attribute__((address_space(3))) v4u* lds_v4u_ptr;
@@ -870,6 +867,7 @@ template <int CS>
 __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, int wave, int lane) {
   constexpr int BYTES = PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
   if (wave < NCHUNK) {
+    asm volatile("" : "+v"(lane));          // the source address is two instructions: recomputed here, not parked in (spilled) VGPRs for the whole kernel
     const int off = wave * 1024 + lane * 16;
     if (off < BYTES) {
       const uint8_t* src = tab + PLAN.vb_off[CS] + off;
@@ -930,7 +928,6 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
   static_assert(IN::FS == OUT::FS && IN::FS == ADDB::FS, "one frame stride per stage");
   static_assert(IN::S >= 16 * (KS - 1) + BW && (BW == 4 || BW == 8 || BW == 16), "the pixel vector must cover all k-steps");
   static_assert(IN::RS == IN::W && IN::PT == 0 && IN::PL == 0, "dense inputs are plain buffers");
-  static_assert(F <= 2 || FRAME_TILES, "linear tiles split at one frame boundary");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
   const uint32_t a_lane = a_on ? (uint32_t)(SLOT + (c & 3) * KROW) : (uint32_t)ZERO;      // A fragments: row 4*pass + (c&3), or zeros
@@ -976,11 +973,13 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
         if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + out_c;
       } else {
         const int q = min(mt * 64 + lane, TOT - 1);
-        const bool hi = F > 1 && q >= P;
-        const int p = hi ? q - P : q;
-        char* fbase = frames + (hi ? IN::FS : 0);
+        int f = 0;
+#pragma unroll
+        for (int i = 1; i < F; ++i) f += (q >= i * P) ? 1 : 0;
+        const int p = q - f * P;
+        char* fbase = frames + f * IN::FS;
         src = fbase + IN::OFF + p * IN::S;
-        if constexpr (EPI == EPI_HEAD) headpix = out_all + (hi ? OUT_FRAME_BYTES : 0) + p * 18;
+        if constexpr (EPI == EPI_HEAD) headpix = out_all + f * OUT_FRAME_BYTES + p * 18;
         else if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + p * 18;
         else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) dstpix = fbase + OUT::OFF + p * OUT::S + OUT_CH0;
         else { const int y = DivW<OUT::W>::div(p); dstpix = fbase + OUT::at(y, p - y * OUT::W) + OUT_CH0; }
@@ -1016,7 +1015,6 @@ YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, in
   constexpr int P = OUT::P, W1 = OUT::W, RSW = IN::RS, TOT = F * P;
   constexpr int MT = (TOT + 63) / 64;
   constexpr int SLOT = slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB;
-  static_assert(F <= 2, "linear tiles split at one frame boundary");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
   const uint32_t a_addr = a_on ? (uint32_t)(SLOT + (c & 3) * YF_CONV1_KROW) : (uint32_t)ZERO;
@@ -1035,10 +1033,12 @@ YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, in
   const AddK ad = {};
   for (int mt = j0; mt < j1; ++mt) {
     const int q = min(mt * 64 + lane, TOT - 1);
-    const bool hi = F > 1 && q >= P;
-    const int p = hi ? q - P : q;
+    int f = 0;
+#pragma unroll
+    for (int i = 1; i < F; ++i) f += (q >= i * P) ? 1 : 0;
+    const int p = q - f * P;
     const int oy = DivW<W1>::div(p), ox = p - oy * W1;
-    char* fbase = frames + (hi ? IN::FS : 0);
+    char* fbase = frames + f * IN::FS;
     // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
     const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
@@ -1079,6 +1079,19 @@ struct DwGeo {
     const int fb = fp * FL * IN::FS;
     return uint2{(uint32_t)(fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
   }
+};
+// job tables of the five depthwise geometries (8 bytes per job of one channel group), laid out one after another
+template <int F, bool BATCH>
+struct JobTabs {
+  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  static constexpr int FT = BATCH ? 2 * F : F;
+  static constexpr int JT_DW3 = 0;
+  static constexpr int JT_DW10 = JT_DW3 + 8 * DwGeo<F, 1, B_T1, B_T2>::JPG;
+  static constexpr int JT_DW15 = JT_DW10 + 8 * DwGeo<F, 2, B_T4, B_T6>::JPG;
+  static constexpr int JT_DW27 = JT_DW15 + 8 * DwGeo<F, 1, B_T8, B_T9>::JPG;
+  static constexpr int JT_DW32 = JT_DW27 + 8 * DwGeo<FT, 2, typename U::T15, typename U::T17>::JPG;      // conv2d_32 / 38 / 49
+  static constexpr int END = JT_DW32 + 8 * DwGeo<FT, 1, typename U::T19, typename U::T20>::JPG;
+  static_assert(END <= JT_B, "job tables fit");
 };
 // the job table of one stage geometry, written once per workgroup (kernel prologue)
 template <int F, int STRIDE, class IN, class OUT, int JTOFF>
@@ -1259,13 +1272,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
   for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
   {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
-    typedef TailBufs<tail_batch<DUMP>() ? FRAME_BYTES / 2 : FRAME_BYTES> UT;
-    constexpr int FTT = tail_batch<DUMP>() ? 2 * F : F;
-    v2::fill_jobtab<F, 1, B_T1, B_T2, v2::JT_DW3>(smem, tid0);
-    v2::fill_jobtab<F, 2, B_T4, B_T6, v2::JT_DW10>(smem, tid0);
-    v2::fill_jobtab<F, 1, B_T8, B_T9, v2::JT_DW15>(smem, tid0);
-    v2::fill_jobtab<FTT, 2, typename UT::T15, typename UT::T17, v2::JT_DW27>(smem, tid0);
-    v2::fill_jobtab<FTT, 1, typename UT::T19, typename UT::T20, v2::JT_DW32>(smem, tid0);
+    typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
+    typedef typename JTS::U UT;
+    v2::fill_jobtab<F, 1, B_T1, B_T2, JTS::JT_DW3>(smem, tid0);
+    v2::fill_jobtab<F, 2, B_T4, B_T6, JTS::JT_DW10>(smem, tid0);
+    v2::fill_jobtab<F, 1, B_T8, B_T9, JTS::JT_DW15>(smem, tid0);
+    v2::fill_jobtab<JTS::FT, 2, typename UT::T15, typename UT::T17, JTS::JT_DW27>(smem, tid0);
+    v2::fill_jobtab<JTS::FT, 1, typename UT::T19, typename UT::T20, JTS::JT_DW32>(smem, tid0);
   }
 #else
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
@@ -1301,7 +1314,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_CONV1(WV, LN, CS) v2::conv1_2_stage<F, NW, CS>(frames, tab, WV, LN)
 #define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
   v2::dense2_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS>(frames, out_all, tab, AD, WV, LN)
-#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) v2::dw2_stage<FR, NW, STRIDE, IN, OUT, C, LUT, CS, v2::JTOFF>(frames, tab, WV, LN)
+#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) v2::dw2_stage<FR, NW, STRIDE, IN, OUT, C, LUT, CS, v2::JobTabs<F, BATCH>::JTOFF>(frames, tab, WV, LN)
 #else
 #define YF_FETCH(CS, WV, LN) do {} while (0)
 #define YF_CONV1(WV, LN, CS) conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), WV, LN, vz)
