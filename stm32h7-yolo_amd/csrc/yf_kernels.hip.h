@@ -27,6 +27,11 @@
 #ifndef YF_LAUNDER
 #define YF_LAUNDER 0
 #endif
+// A/B toggles of the experimental build (namespace yfx, YF_EXP 1): bits of YF_EXP_MASK, all off in the shipped build
+#ifndef YF_EXP_MASK
+#define YF_EXP_MASK 0
+#endif
+#define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
 namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
@@ -848,7 +853,7 @@ constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LD
 constexpr int JT = LUT_B, JT_B = 896;                         // depthwise job tables
 constexpr int ZERO = JT + JT_B, ZERO_B = 640;                 // zeros: the A fragments of the lanes outside a row block
 constexpr int SLOT0 = ZERO + ZERO_B, SLOT_B = 2816;           // two ring slots for the constant blocks of consecutive const-stages
-constexpr int PRE_B = SLOT0 + 2 * SLOT_B;                     // the frame arenas follow
+// behind the ring slots: the halo tables (size depends on the kernel shape), then the frame arenas (pre_bytes)
 constexpr int slot(int cs) { return SLOT0 + (cs & 1) * SLOT_B; }
 constexpr int max_block() { int m = 0; for (int i = 0; i < YF_N_CS; ++i) m = PLAN.vb_bytes[i] > m ? PLAN.vb_bytes[i] : m; return m; }
 static_assert(max_block() <= SLOT_B && SLOT0 % 16 == 0 && SLOT_B % 16 == 0, "a constant block fits a ring slot");
@@ -889,7 +894,7 @@ template <int W> struct DivW {
 
 // residual-add context of the lean stages: the two 256-entry int32 tables sit in the stage's ring slot at LA / LA + 1024
 template <int EPI, int LUT_ID, int LA>
-__device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char* headpix, int chq, const int (&idx)[4], const AddK& ad) {
+__device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char* headpix, int chq, int hq, const int (&idx)[4], const AddK& ad) {
   if constexpr (EPI == EPI_LUT) {
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
   } else if constexpr (EPI == EPI_RAW) {
@@ -907,9 +912,9 @@ __device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
   } else {  // head: 18 channels per pixel, 2-byte aligned
     const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-    uint16_t* dst = reinterpret_cast<uint16_t*>(headpix + chq);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(headpix + hq);
     dst[0] = (uint16_t)v;
-    if (chq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
+    if (hq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
   }
 }
 
@@ -963,12 +968,14 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
       ksr[t] = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     }
     const int n = min(left, MT - mt);
+    const int cq = chunk * TPJ * 4;                              // first channel of the chunk: rides in the pixel bases, the pass in the immediates
+    const int out_cc = out_c + cq, add_cc = add_c + cq;
     for (int k = 0; k < n; ++k, ++mt) {
       const char* src; char* dstpix = nullptr; const char* addpix = nullptr; char* headpix = nullptr;
       if constexpr (FRAME_TILES) {
         char* fbase = frames + mt * IN::FS;
         src = fbase + in_c;
-        dstpix = fbase + out_c; addpix = fbase + add_c;
+        dstpix = fbase + out_cc; addpix = fbase + add_cc;
         if constexpr (EPI == EPI_HEAD) headpix = out_all + mt * OUT_FRAME_BYTES + out_c;
         if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + out_c;
       } else {
@@ -981,9 +988,9 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
         src = fbase + IN::OFF + p * IN::S;
         if constexpr (EPI == EPI_HEAD) headpix = out_all + f * OUT_FRAME_BYTES + p * 18;
         else if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + p * 18;
-        else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) dstpix = fbase + OUT::OFF + p * OUT::S + OUT_CH0;
-        else { const int y = DivW<OUT::W>::div(p); dstpix = fbase + OUT::at(y, p - y * OUT::W) + OUT_CH0; }
-        if constexpr (EPI == EPI_ADD) addpix = fbase + ADDB::OFF + p * ADDB::S;
+        else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) dstpix = fbase + cq + OUT::OFF + p * OUT::S + OUT_CH0;
+        else { const int y = DivW<OUT::W>::div(p); dstpix = fbase + cq + OUT::at(y, p - y * OUT::W) + OUT_CH0; }
+        if constexpr (EPI == EPI_ADD) addpix = fbase + cq + ADDB::OFF + p * ADDB::S;
       }
       v4i b[KS];
 #pragma unroll
@@ -992,6 +999,30 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
       if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
       else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, any_value(), any_value()}; }
       else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), any_value(), any_value(), any_value()};
+#if YF_TOGGLED(64)
+      // phase-split: the MFMAs of all passes of the job, then their requantisations, then all LUT reads, then the stores -- the
+      // latencies (MFMA result, LUT read) are paid once per job instead of once per pass
+      if constexpr (TPJ > 1 && EPI == EPI_LUT) {
+        v4i acc[TPJ];
+#pragma unroll
+        for (int t = 0; t < TPJ; ++t) {
+          acc[t] = v4i{ACC0, ACC0, ACC0, ACC0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc[t], 0, 0, 0);
+        }
+        int idx[TPJ][4];
+#pragma unroll
+        for (int t = 0; t < TPJ; ++t) requant4<true>(acc[t], pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx[t]);
+        uint32_t by[TPJ][4];
+#pragma unroll
+        for (int t = 0; t < TPJ; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) by[t][j] = lutb<LUT_ID>(idx[t][j]);
+#pragma unroll
+        for (int t = 0; t < TPJ; ++t)
+          if (chunk * TPJ + t < NP) *reinterpret_cast<uint32_t*>(dstpix + t * 4) = join4(by[t][0], by[t][1], by[t][2], by[t][3]);
+      } else
+#endif
 #pragma unroll
       for (int t = 0; t < TPJ; ++t) {
         const int ps = chunk * TPJ + t;
@@ -1001,7 +1032,7 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
           for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
           int idx[4];
           requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
-          epilogue2<EPI, LUT_ID, LA>(dstpix, addpix, headpix, ps * 4, idx, ad);
+          epilogue2<EPI, LUT_ID, LA>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad);
         }
       }
     }
@@ -1055,7 +1086,7 @@ YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, in
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
       int idx[4];
       requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
-      epilogue2<EPI_LUT, YF_L_LEAKY2, 0>(dstpix, nullptr, nullptr, 4 * ps, idx, ad);
+      epilogue2<EPI_LUT, YF_L_LEAKY2, 0>(dstpix, nullptr, nullptr, 4 * ps, 0, idx, ad);
     }
   }
 }
@@ -1093,6 +1124,59 @@ struct JobTabs {
   static constexpr int END = JT_DW32 + 8 * DwGeo<FT, 1, typename U::T19, typename U::T20>::JPG;
   static_assert(END <= JT_B, "job tables fit");
 };
+// ---- halo fills from a table.  The halo pixels of a depthwise input (ring or top row + left column, every frame of the workgroup)
+// are a fixed list of LDS offsets: written once per workgroup as uint16 (offset / 4) tables, so that a fill is "thread i < N:
+// read entry i, store one pixel of zero points" -- two VALU instructions instead of ~20 of index arithmetic per dword.
+template <class B, bool RING, int F>
+struct HaloGeo {
+  static constexpr int HR = B::H + B::PT + (RING ? 1 : 0), WR = B::RS;
+  static constexpr int NPIX = RING ? (2 * WR + 2 * (HR - 2)) : (WR + HR - 1);
+  static constexpr int N = F * NPIX;
+  static_assert(B::S % 4 == 0 && B::OFF % 4 == 0 && B::FS % 4 == 0, "dword pixels");
+  __device__ static __forceinline__ uint32_t entry(int i) {       // byte offset (from the frame arenas) of halo pixel i
+    const int f = i / NPIX, k = i - f * NPIX;
+    int r, c;
+    if constexpr (RING) {
+      if (k < WR) { r = 0; c = k; }
+      else if (k < 2 * WR) { r = HR - 1; c = k - WR; }
+      else { const int m = k - 2 * WR; r = 1 + (m >> 1); c = (m & 1) ? WR - 1 : 0; }
+    } else {
+      if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
+    }
+    return (uint32_t)(f * B::FS + B::OFF + (r * WR + c) * B::S);
+  }
+};
+template <int F, bool BATCH>
+struct HaloTabs {
+  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  static constexpr int FT = BATCH ? 2 * F : F;
+  typedef HaloGeo<B_T1, true, F> G1; typedef HaloGeo<B_T4, false, F> G4; typedef HaloGeo<B_T8, true, F> G8;
+  typedef HaloGeo<B_T15, false, F> G15; typedef HaloGeo<typename U::T19, true, FT> G19;
+  static constexpr int H_T1 = 0, H_T4 = H_T1 + 2 * G1::N, H_T8 = H_T4 + 2 * G4::N, H_T15 = H_T8 + 2 * G8::N, H_T19 = H_T15 + 2 * G15::N;
+  static constexpr int BYTES = (H_T19 + 2 * G19::N + 15) & ~15;
+};
+constexpr int HT = SLOT0 + 2 * SLOT_B;                        // halo tables, then the frame arenas
+template <int F, bool BATCH> constexpr int pre_bytes() { return HT + HaloTabs<F, BATCH>::BYTES; }
+template <class G, int HOFF, int NT>
+__device__ __forceinline__ void build_halotab(char* smem, int tid) {
+  for (int i = tid; i < G::N; i += NT) *reinterpret_cast<uint16_t*>(smem + HT + HOFF + 2 * i) = (uint16_t)(G::entry(i) >> 2);
+}
+template <class B, class G, int HOFF>
+YF_STAGE_FN void fill_halo_t(char* frames, int zp, int tid) {
+  typedef const __attribute__((address_space(3))) uint16_t* lds_u16_ptr;
+  if (tid < G::N) {
+    const uint32_t v = (uint32_t)(zp & 255) * 0x01010101u;
+    char* p = frames + 4u * (uint32_t)*(lds_u16_ptr)(uint32_t)(HT + HOFF + 2 * tid);
+    if constexpr (B::S % 8 == 0 && B::OFF % 8 == 0 && B::FS % 8 == 0) {
+#pragma unroll
+      for (int d = 0; d < B::S / 8; ++d) *reinterpret_cast<uint2*>(p + 8 * d) = uint2{v, v};
+    } else {
+#pragma unroll
+      for (int d = 0; d < B::S / 4; ++d) *reinterpret_cast<uint32_t*>(p + 4 * d) = v;
+    }
+  }
+}
+
 // the job table of one stage geometry, written once per workgroup (kernel prologue)
 template <int F, int STRIDE, class IN, class OUT, int JTOFF>
 __device__ __forceinline__ void fill_jobtab(char* smem, int tid) {
@@ -1135,8 +1219,8 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
     const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     const char* lin = lane_in + 4 * cg;
     char* lout = lane_out + 4 * cg;
-    auto taps = [&](int job, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
-      const v2u e = *(lds_u2_ptr)(uint32_t)(JT + JTOFF + 8 * job);
+    auto entry = [&](int job) { return *(lds_u2_ptr)(uint32_t)(JT + JTOFF + 8 * min(job, JPG - 1)); };    // {src, dst} offsets of a job
+    auto taps = [&](const v2u e, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
       const char* src = lin + e[0];
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
@@ -1156,23 +1240,60 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
     };
     const int n = min(left, JPG - jj);
     int i = 0;
+    v2u e0 = entry(jj), e1 = entry(jj + 1);     // the next pair's table entries are read one iteration ahead (behind this pair's tap reads)
     for (; i + 1 < n; i += 2) {               // two jobs in flight: the second job's tap reads and MFMAs overlap the first one's epilogue
       v4i p0, p1, p2 = {0, any_value(), any_value(), any_value()}, q0, q1, q2 = {0, any_value(), any_value(), any_value()};
       char *dp, *dq;
-      taps(jj + i, p0, p1, p2, dp);
-      taps(jj + i + 1, q0, q1, q2, dq);
+      taps(e0, p0, p1, p2, dp);
+      taps(e1, q0, q1, q2, dq);
+#if !YF_TOGGLED(32)
+      e0 = entry(jj + i + 2); e1 = entry(jj + i + 3);
+#endif
       const v4i ap = conv(p0, p1, p2);
       const v4i aq = conv(q0, q1, q2);
       finish(ap, dp);
       finish(aq, dq);
+#if YF_TOGGLED(32)
+      e0 = entry(jj + i + 2); e1 = entry(jj + i + 3);
+#endif
     }
     if (i < n) {
       v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
       char* dst;
-      taps(jj + i, b0, b1, b2, dst);
+      taps(e0, b0, b1, b2, dst);
       finish(conv(b0, b1, b2), dst);
     }
     left -= n; ++cg; jj = 0;
+  }
+}
+// ---- pool_25 (4x4 stride 2 pad 1 on T15, QUANTIZE#45 -> pool half of concat_46) by COLUMNS: one item = (frame, output column,
+// channel dword) walks the 14 rows of T15 once -- per row the horizontal 4-tap maximum (clamped columns), pairs of rows
+// R[j] = max(h[2j-1], h[2j]), out[oy] = max(R[oy], R[oy+1]) -- and writes its 7 outputs.  230 VALU instructions per item instead
+// of 7 x 60 for the direct 4x4 window; FT x 42 items, i.e. a few waves' worth: the stage gives pool_25 to the first POOL25_WAVES
+// waves and conv2d_27 (which reads the same T15) to the others.
+template <int FT> constexpr int pool25_waves() { return (FT * 42 + 63) / 64; }
+template <int FT, class T15, class T30>
+YF_STAGE_FN void pool25_cols(char* frames, int item) {
+  static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7 && T15::FS == T30::FS, "pool_25 geometry");
+  const int t = DivW<6>::div(item), cg = item - 6 * t;
+  const int f = DivW<7>::div(t), ox = t - 7 * f;
+  if (f >= FT) return;
+  char* fbase = frames + f * T15::FS;
+  const char* base = fbase + T15::at(0, 0) + 4 * cg;
+  constexpr int S = T15::S, ROW = T15::RS * T15::S;
+  const int c0 = max(2 * ox - 1, 0) * S, c1 = 2 * ox * S, c2 = c1 + S, c3 = min(2 * ox + 2, 13) * S;
+  auto hrow = [&](int r) {
+    const char* p = base + r * ROW;
+    return SplitB(lds_u32(p + c0)).mx(SplitB(lds_u32(p + c1))).mx(SplitB(lds_u32(p + c2))).mx(SplitB(lds_u32(p + c3)));
+  };
+  char* dst = fbase + T30::OFF + ox * T30::S + 4 * cg;
+  SplitB prev = hrow(0);                                       // R[0] = max(h[-1 -> 0], h[0])
+#pragma unroll
+  for (int oy = 0; oy < 7; ++oy) {
+    SplitB next = hrow(2 * oy + 1);                            // R[oy+1] = max(h[2oy+1], h[2oy+2 -> 13])
+    if (2 * oy + 2 <= 13) next = next.mx(hrow(2 * oy + 2));
+    *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = lut4_raw<YF_L_Q45>(prev.mx(next));
+    prev = next;
   }
 }
 }  // namespace v2
@@ -1217,10 +1338,6 @@ struct NetParams {
 };
 static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
 
-#ifndef YF_EXP_MASK
-#define YF_EXP_MASK 0
-#endif
-#define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
 // Issue priority per stage (s_setprio, 0..3), stage order: staging, conv2d_1, 3, 5, 6, pool_8 h, pool_8 v, conv2d_10, 12, 13, 15,
 // 17, 19, 23, then the thirteen tail stages.  See the kernel: a workgroup's priority FALLS as its group advances.
 #ifndef YF_PRIO_LIST
@@ -1247,7 +1364,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
 #if YF_V2
-  constexpr int PRE = v2::PRE_B;                         // LUTs | depthwise job tables | zeros | two constant ring slots
+  constexpr int PRE = v2::pre_bytes<F, tail_batch<DUMP>()>();   // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
 #else
   constexpr int PRE = LUT_BYTES;                         // LUTs | residual-add tables
 #endif
@@ -1279,6 +1396,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     v2::fill_jobtab<F, 1, B_T8, B_T9, JTS::JT_DW15>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 2, typename UT::T15, typename UT::T17, JTS::JT_DW27>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 1, typename UT::T19, typename UT::T20, JTS::JT_DW32>(smem, tid0);
+    typedef v2::HaloTabs<F, tail_batch<DUMP>()> HTS;       // halo pixel lists of the five depthwise inputs
+    v2::build_halotab<typename HTS::G1, HTS::H_T1, NT>(smem, tid0);
+    v2::build_halotab<typename HTS::G4, HTS::H_T4, NT>(smem, tid0);
+    v2::build_halotab<typename HTS::G8, HTS::H_T8, NT>(smem, tid0);
+    v2::build_halotab<typename HTS::G15, HTS::H_T15, NT>(smem, tid0);
+    v2::build_halotab<typename HTS::G19, HTS::H_T19, NT>(smem, tid0);
   }
 #else
   for (int i = tid0; i < LUT_BYTES / 16; i += NT)
@@ -1309,6 +1432,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_SYNC() __syncthreads()
 #endif
   // Stage calls: the lean forms (constants from an LDS ring slot, fetched one stage ahead by YF_FETCH) or the round-2 forms
+#if YF_V2 && !YF_TOGGLED(128)
+#define YF_HALO(B, RING, FR, G, HOFF, WI, TID) \
+  v2::fill_halo_t<B, typename v2::HaloTabs<F, BATCH>::G, v2::HaloTabs<F, BATCH>::HOFF>(frames, load_halo_zp(tab, WI), TID)
+#else
+#define YF_HALO(B, RING, FR, G, HOFF, WI, TID) fill_halo<B, RING, FR, NT>(frames, load_halo_zp(tab, WI), TID)
+#endif
 #if YF_V2
 #define YF_FETCH(CS, WV, LN) v2::fetch_consts<CS>(tab, WV, LN)
 #define YF_CONV1(WV, LN, CS) v2::conv1_2_stage<F, NW, CS>(frames, tab, WV, LN)
@@ -1377,7 +1506,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     if constexpr (CAM) stage_input_cam<F, NT>(frames, reinterpret_cast<const uint8_t*>(prm.in), first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
     else stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
     YF_FETCH(0, W_f, L_f);                                                                            // conv2d_1's constants -> ring slot 0
-    fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid_f);
+    YF_HALO(B_T1, true, F, G1, H_T1, YF_W_DW3, tid_f);
     YF_SYNC();
     YF_STAGE_END()
     YF_PRIO(1);
@@ -1396,7 +1525,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP(B_T3, 4, T3)
     YF_STAGE_END()
     YF_PRIO(4);
-    fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid_f);
+    YF_HALO(B_T4, false, F, G4, H_T4, YF_W_DW10, tid_f);
     YF_FETCH(4, W_f, L_f);
     YF_DENSE(F, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
@@ -1419,7 +1548,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP(B_T7, 6, T7)
     YF_STAGE_END()
     YF_PRIO(9);
-    fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid_m);
+    YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
     YF_FETCH(7, W_m, L_m);
     YF_DENSE(F, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
@@ -1458,7 +1587,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
         }
       }
     }
-    fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid_m);
+    YF_HALO(B_T15, false, F, G15, H_T15, YF_W_DW27, tid_m);
     YF_FETCH(11, W_m, L_m);
     YF_DENSE(F, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
     if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
@@ -1502,9 +1631,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_DUMP_T(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
     YF_PRIO(14);
+#if YF_V2 && !YF_TOGGLED(16)
+    YF_FETCH(12, W_t, L_t);
+    {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
+      constexpr int PW = v2::pool25_waves<FT>();
+      static_assert(PW < NW, "waves left for conv2d_27");
+      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30>(frames, W_t * 64 + L_t);
+      else v2::dw2_stage<FT, NW - PW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, 11, v2::JobTabs<F, BATCH>::JT_DW27>(frames, tab, W_t - PW, L_t);
+    }
+#else
     pool25<FT, NT, typename U::T15, typename U::T30>(frames, tid_t);                                  // pool_25 + QUANTIZE#45
     YF_FETCH(12, W_t, L_t);
     YF_DW(FT, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, YF_W_DW27, W_t, L_t, 11, JT_DW27);    // conv2d_27
+#endif
     YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
     YF_PRIO(15);
@@ -1514,7 +1653,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
     YF_STAGE_END()
     YF_PRIO(16);
-    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid_t);
+    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW32, tid_t);
     YF_FETCH(14, W_t, L_t);
     YF_DENSE(FT, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
@@ -1530,7 +1669,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22)
     YF_STAGE_END()
     YF_PRIO(19);
-    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid_t);
+    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
     YF_FETCH(17, W_t, L_t);
     YF_DENSE(FT, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
@@ -1551,7 +1690,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30)
     YF_STAGE_END()
     YF_PRIO(23);
-    fill_halo<typename U::T19, true, FT, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid_t);
+    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW49, tid_t);
     YF_FETCH(21, W_t, L_t);
     YF_DENSE(FT, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19, YF_D_C47, no_add, W_t, L_t, 20);   // conv2d_47
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T31)
@@ -1602,6 +1741,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
   }
+#undef YF_HALO
 #undef YF_FETCH
 #undef YF_CONV1
 #undef YF_DENSE
@@ -1613,7 +1753,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::PRE_B : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::pre_bytes<F, tail_batch<DUMP>()>() : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 
