@@ -17,12 +17,19 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 #include "yf_fp16.h"
 #include "yf_stream_scratch.h"
 
+#ifndef YF16_SCHED
+#define YF16_SCHED 0
+#endif
+#ifndef YF16_WHATIF
+#define YF16_WHATIF 0      /* timing-only what-if builds (wrong results): 1 no weight loads, 2 no halo fills, 4 tap loads fenced before the MFMAs */
+#endif
 namespace yf16 {
 
 typedef _Float16 half_t;
@@ -52,7 +59,7 @@ typedef Buf< 40400, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch
 typedef Buf<     0, 28, 28, 16, 28, 0, 0> B_T3;    // c5 out, 4 ch in an 8-channel pixel (upper half zero)
 typedef Buf< 12544, 28, 28, 40, 29, 1, 1> B_T4;    // c6 out, 18 ch (stride 20), top/left halo for dw10
 typedef Buf< 46184, 14, 28, 36, 14, 0, 0> B_HB;    // pool_8 horizontal pass, 18 ch
-typedef Buf< 60296, 14, 14, 80, 14, 0, 0> B_T14;   // concat: pool [0,18) | conv [20,38) (8-byte aligned start), stride 40
+typedef Buf< 60304, 14, 14, 80, 14, 0, 0> B_T14;   // concat: pool [0,18) | conv [20,38) (8-byte aligned start), stride 40; 16-byte aligned pixels (conv2d_23 reads them with ds_read_b128)
 typedef Buf<     0, 14, 14, 48, 14, 0, 0> B_T6;    // dw10 out, 18 ch (stride 24)
 typedef Buf<  9408, 14, 14, 16, 14, 0, 0> B_T7;    // c12 out, 6 ch
 typedef Buf< 12544, 14, 14, 80, 16, 1, 1> B_T8;    // c13 out, 36 ch, halo ring
@@ -85,6 +92,42 @@ struct TB {
 static_assert(30608 + 7 * 7 * 64 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0, "a tail set fits half the arena");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
 static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * 30 * 16 <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
+
+// ---- weight ring.  A conv's A-operand rows come from LDS, not from global memory: stage k's first act is ONE LDS-DMA of stage
+// k+1's rows (global_load_lds_dwordx4: 64 x 16 bytes per wave-instruction, no registers), so that the next stage's waves read
+// their fragments with ds_read_b128 (~100 cycles) instead of waiting 1.5-2.5 k cycles for a global load behind every barrier
+// and every channel-group switch (what-if without those loads: -9 % kernel time at one frame per workgroup).  Blocks k and k+1
+// are the only ones alive together, so even blocks grow up from the bottom of a 5.9 KB region behind the arena and odd blocks
+// down from its top; conv2d_47's 3.8 KB (next to dw49's 3.2 KB) sits in the bytes of tail set 0 that no tail buffer uses.
+constexpr int WBYTES[24] = {640, 640, 64, 320, 1600, 384, 576, 2880, 640, 320, 1920, 1920, 384, 640, 3200, 640, 640, 3200, 640, 384, 3840, 3200, 2560, 1280};
+constexpr int RING0 = LDS_BYTES, LDS_TOTAL = 81920, RING_BYTES = LDS_TOTAL - LDS_BYTES;
+constexpr int TAIL_SET_END = 30608 + 7 * 7 * 64;
+constexpr int woff(int k) { return k == 20 ? TAIL_SET_END : (k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]); }
+constexpr bool ring_ok() {
+  for (int k = 0; k + 1 < 24; ++k) {
+    if (WBYTES[k] % 16 != 0) return false;
+    if (k == 20 || k + 1 == 20) continue;
+    if (WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
+  }
+  return WBYTES[20] <= TAIL_FS - TAIL_SET_END && TAIL_SET_END % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
+}
+static_assert(ring_ok(), "adjacent weight blocks fit the ring side by side");
+// LDS-DMA of conv K's rows into its place in the ring: wave w moves bytes [1024 w, 1024 w + 1024).  The compiler does not see
+// the transfer (inline assembly): the barrier behind every stage is preceded by an explicit s_waitcnt vmcnt(0) (SYNC in the kernel).
+template <int K>
+__device__ __forceinline__ void fetch_w(const uint8_t* __restrict__ tab, uint32_t w_off, int wave, int lane) {
+  constexpr int BYTES = WBYTES[K], NCHUNK = (BYTES + 1023) / 1024;
+  if (wave < NCHUNK) {
+    const int off = wave * 1024 + lane * 16;
+    if (off < BYTES) {
+      const uint8_t* src = tab + w_off + off;
+      const uint32_t dst = (uint32_t)(woff(K) + wave * 1024);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+}
 
 enum { EPI_ACT = 0, EPI_LINEAR = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 
@@ -144,12 +187,14 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
 // KS k-steps of 8 input channels (16 bytes of the pixel's fp16 vector each); TPJ passes of 4 output channels share a job's
 // pixel arithmetic and B fragments.
 // F frames (IN::FS apart); out_frame / out_frame1: the head's fp32 destination of frame 0 / 1 (nullptr: frame not wanted).
-template <int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int F = 1>
+template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int F = 1>
 __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_frame0, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane,
                                             float* __restrict__ out_frame1 = nullptr) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
   constexpr int P1 = IN::P, P = F * P1, MT = (P + 63) / 64, JOBS = NCH * MT, KROW = 8 * KS;
+  static_assert(WBYTES[K] == NP * 4 * KROW * 2, "stage and weight block agree");
   static_assert(IN::S >= 16 * KS, "the pixel vector must cover every k-step");
+  static_assert(IN::OFF % 16 == 0 && IN::S % 16 == 0 && IN::FS % 16 == 0, "B fragments are aligned ds_read_b128 (a misaligned one is several times slower)");
   static_assert(F == 1 || (F == 2 && IN::FS == OUT::FS && IN::FS == ADDB::FS && IN::FS > 0), "frames of a stage share one stride");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
@@ -157,20 +202,29 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
   job_range<JOBS, NW>(wave, j0, j1);
   int cur = -1;
   v4i a[TPJ][KS];                    // dword vectors, bit-cast at the MFMA (see conv3x3_stage)
+  v4f bias[TPJ];                     // per chunk, in VGPRs (see conv3x3_stage)
   for (int j = j0; j < j1; ++j) {
     const int chunk = j / MT, mt = j - chunk * MT;
-    if (chunk != cur) {
+    const bool fresh = chunk != cur;
+    if (fresh) {
       cur = chunk;
 #pragma unroll
       for (int tt = 0; tt < TPJ; ++tt) {
         const int ps = min(chunk * TPJ + tt, NP - 1);
+        bias[tt] = uniform_f4(tab + t.b_off + 16 * ps);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           a[tt][ks] = v4i{0, 0, 0, 0};
-          if (a_on) a[tt][ks] = *reinterpret_cast<const v4i*>(tab + t.w_off + ((ps * 4 + (c & 3)) * KROW + 8 * ks) * 2);
+          if (a_on) a[tt][ks] = *reinterpret_cast<const v4i*>(lds0 + woff(K) + ((ps * 4 + (c & 3)) * KROW + 8 * ks) * 2);
         }
       }
     }
+#if YF16_SCHED & 2
+    if (fresh) {                     // biases into VGPRs once per chunk, behind the fragment reads (as SGPRs every pass of every job would wait for them)
+#pragma unroll
+      for (int tt = 0; tt < TPJ; ++tt) asm volatile("" : "+v"(bias[tt]));
+    }
+#endif
     const int q = mt * 64 + lane;
     const int qc = min(q, P - 1);
     const int f = (F == 1) ? 0 : (qc >= P1 ? 1 : 0);
@@ -185,7 +239,7 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
     for (int tt = 0; tt < TPJ; ++tt) {
       const int ps = chunk * TPJ + tt;
       if (ps < NP) {
-        v4f acc = uniform_f4(tab + t.b_off + 16 * ps);                        // bias as the accumulator's initial value
+        v4f acc = bias[tt];                                                   // bias as the accumulator's initial value
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[tt][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
         epilogue<EPI, OUT, OUT_CH0, ADDB, COUT>(lds, out_frame, p, 4 * ps, acc, q < P);
@@ -198,9 +252,10 @@ __device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_
 // conv1 (RGBX pixels, 8 bytes per tap) and the depthwise convs (4 channels = 8 bytes per tap and group): a k-step carries
 // two taps, nine taps take five k-steps (the last slot pair is empty: its weights are zero, its data whatever tap 8 was).
 // Jobs: 4 output rows x 16 columns (border blocks shifted inwards) x channel group.
-template <int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1>
+template <int K, int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1>
 __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane) {
   constexpr int W = OUT::W, H = OUT::H;
+  static_assert(WBYTES[K] == ((C + 3) / 4) * 320, "stage and weight block agree");
   constexpr int FL = (F == 2) ? 2 : 1;                             // two 7-wide frames side by side in the 16 lanes of a row tile
   static_assert(F == 1 || (W <= 8 && IN::FS == OUT::FS && IN::FS > 0), "frame pairs need grids of at most 8 columns");
   constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4;
@@ -221,52 +276,93 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 #pragma unroll                       // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
     for (int ks = 0; ks < 5; ++ks) {
       a[ks] = v4i{0, 0, 0, 0};
-      if (a_on) a[ks] = *reinterpret_cast<const v4i*>(tab + t.w_off + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
+      if (a_on) a[ks] = *reinterpret_cast<const v4i*>(lds + woff(K) + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
     }
-    const v4f bias = uniform_f4(tab + t.b_off + 16 * cg);
-    for (; j < jend; ++j) {
-      const int rem = j - cg * JPG;
+    v4f bias = uniform_f4(tab + t.b_off + 16 * cg);
+    asm volatile("" : "+v"(bias));     // in VGPRs before the job loop: as SGPRs the accumulators' initial moves wait for the scalar load INSIDE it (lgkmcnt(0): every LDS read with it)
+    // one job: nine tap reads -> five MFMAs -> LeakyReLU -> fp16 -> one 8-byte store.  TWO jobs run in flight per iteration: all
+    // eighteen tap reads are issued before the first MFMA and the two accumulator chains interleave (the default schedule paired
+    // every MFMA with its own reads: five LDS round trips in a row per job, 1250 cycles per job in the stage timeline).
+    auto taps = [&](int jj, uint2 (&tp)[9], char*& dst) {
+      const int rem = jj - cg * JPG;
       const int rb = rem / NSEG, seg = rem - rb * NSEG;
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, column ox*STRIDE+kx; depthwise: channel group cg
       const char* src = lds + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
-      uint2 tp[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) tp[k] = lds_u64(src + (k / 3) * TR + (k % 3) * TS);
+      dst = lds + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg;
+    };
+    auto kstep = [&](const uint2 (&tp)[9], int ks, v4f acc) {
+      const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
+      const v4i u = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[ks]), __builtin_bit_cast(v8h, u), acc, 0, 0, 0);
+    };
+    auto finish = [&](v4f acc, char* dst) {
+      uint2 v; v.x = pack2(leaky(acc[0]), leaky(acc[1])); v.y = pack2(leaky(acc[2]), leaky(acc[3]));
+      *reinterpret_cast<uint2*>(dst) = v;
+    };
+    for (; j + 1 < jend; j += 2) {
+      uint2 tp0[9], tp1[9];
+      char *d0, *d1;
+      taps(j, tp0, d0);
+      taps(j + 1, tp1, d1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);         // the eighteen tap reads ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);         // ... then the ten MFMAs
+      v4f acc0 = bias, acc1 = bias;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) { acc0 = kstep(tp0, ks, acc0); acc1 = kstep(tp1, ks, acc1); }
+      finish(acc0, d0);
+      finish(acc1, d1);
+    }
+    if (j < jend) {
+      uint2 tp[9];
+      char* dst;
+      taps(j, tp, dst);
+      __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
       v4f acc = bias;
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {
-        const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
-        const v4i u = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[ks]), __builtin_bit_cast(v8h, u), acc, 0, 0, 0);
-      }
-      const int oy = oy0 + g, ox = x0 + xl;
-      uint2 v; v.x = pack2(leaky(acc[0]), leaky(acc[1])); v.y = pack2(leaky(acc[2]), leaky(acc[3]));
-      *reinterpret_cast<uint2*>(lds + fl * OUT::FS + OUT::at(oy, ox) + 8 * cg) = v;
+      for (int ks = 0; ks < 5; ++ks) acc = kstep(tp, ks, acc);
+      finish(acc, dst);
+      ++j;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ zero fills
-// halo of a buffer: RING = 1-pixel border all round, otherwise top row + left column
+// Halo of a buffer as CONTIGUOUS RUNS of 8- or 16-byte granules.  RING (1-pixel border all round): the top row and the first
+// pixel of row 1 are one run, the last pixel of row r and the first of row r+1 are adjacent (HR-3 runs of two pixels), the last
+// pixel of row HR-2 and the bottom row are one run.  Otherwise (top row + left column): the top row is one run, then one pixel per
+// row.  An item is one granule: a compare or two and a multiply-shift instead of the five divisions of a per-dword formulation
+// (the halo fills were 25 % of the kernel's VALU instructions).
 template <class B, bool RING, int NT, int F = 1>
 __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
-  constexpr int DW = B::S / 4;
-  constexpr int HR = B::H + B::PT + (RING ? 1 : 0), WR = B::RS;
-  constexpr int NPIX = RING ? (2 * WR + 2 * (HR - 2)) : (WR + HR - 1);
-  for (int i = tid; i < F * NPIX * DW; i += NT) {
-    const int d = i % DW, kk = i / DW, k = kk % NPIX;
-    char* lds = lds0 + (kk / NPIX) * B::FS;
-    int r, c;
-    if constexpr (RING) {
-      if (k < WR) { r = 0; c = k; }
-      else if (k < 2 * WR) { r = HR - 1; c = k - WR; }
-      else { const int m = k - 2 * WR; r = 1 + (m >> 1); c = (m & 1) ? WR - 1 : 0; }
-    } else {
-      if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
-    }
-    *reinterpret_cast<uint32_t*>(lds + B::OFF + (r * WR + c) * B::S + 4 * d) = 0u;
+#if YF16_WHATIF & 2
+  return;
+#endif
+  constexpr int S = B::S, WR = B::RS, HR = B::H + B::PT + (RING ? 1 : 0);
+  constexpr int G = (S % 16 == 0 && B::OFF % 16 == 0) ? 16 : 8, PG = S / G;       // granule bytes, granules per pixel
+  static_assert(S % G == 0 && B::OFF % G == 0 && (F == 1 || B::FS % G == 0), "granules");
+  constexpr int NA = RING ? (WR + 1) * PG : WR * PG;                  // first run
+  constexpr int NB = RING ? (HR - 3) * 2 * PG : (HR - 1) * PG;        // middle runs (two pixels / one pixel each)
+  constexpr int NC = RING ? (WR + 1) * PG : 0;                        // last run
+  constexpr int N1 = NA + NB + NC;
+  for (int i = tid; i < F * N1; i += NT) {
+    const int f = (F == 1) ? 0 : (i >= N1 ? 1 : 0);
+    const int k = i - f * N1;
+    int off;
+    if (k < NA) off = k * G;
+    else if (k < NA + NB) {
+      const int j = k - NA;
+      constexpr int RUN = RING ? 2 * PG : PG;
+      const int r = j / RUN, g = j - r * RUN;                         // compile-time divisor
+      off = RING ? ((r + 2) * WR - 1) * S + g * G : (r + 1) * WR * S + g * G;
+    } else off = ((HR - 1) * WR - 1) * S + (k - NA - NB) * G;
+    char* dst = lds0 + f * B::FS + B::OFF + off;
+    if constexpr (G == 16) *reinterpret_cast<uint4*>(dst) = uint4{0u, 0u, 0u, 0u};
+    else *reinterpret_cast<uint2*>(dst) = uint2{0u, 0u};
   }
 }
 
@@ -334,7 +430,7 @@ __device__ __forceinline__ void pool25(char* lds0, int tid) {                 //
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; };   // scratch: gridDim.x * TAIL_T15_BYTES
+struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds)
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params prm) {
@@ -350,6 +446,19 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
   // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).
   // Everything the stages store is finite fp16, so clearing the arena once per workgroup is enough.
   for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+  // the barrier behind a stage also publishes the LDS-DMA of the next stage's weights, which the compiler does not see
+#ifdef YF16_BARPROF
+  // stage timeline (tools/fp16_timeline.py): in the workgroup's second frame (the one that closes a pair and runs the tail) every wave
+  // stamps the cycle counter on arrival at and on release from each barrier: prof[wg][wave][40][2]
+  bool prof_on = false; int bar_no = 0;
+  long long* prof_out = prm.prof ? prm.prof + ((long)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 80 : nullptr;
+#define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
+    if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
+#else
+#define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#endif
+#define FETCH(K) fetch_w<K>(tab, conv(K).w_off, wave, lane)
   long parked = -1;                                               // frame whose T15 waits in the scratch
   for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
     int tid = tid0;
@@ -357,7 +466,11 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* out_frame = prm.out + fr * (7 * 7 * 18);
-    __syncthreads();                                              // previous frame's buffers are dead
+#ifdef YF16_BARPROF
+    bar_no = 0; prof_on = prof_out != nullptr && fr == (long)blockIdx.x + gridDim.x;
+#endif
+    SYNC();                                                       // previous frame's buffers are dead
+    FETCH(0);
     {   // input: fp16 [56][56][3] -> RGBX pixels with a zero top row and left column.  Two pixels (12 bytes) per item.
       const uint32_t* src = reinterpret_cast<const uint32_t*>(prm.in + fr * (56 * 56 * 3));
       for (int i = tid; i < 56 * 28; i += NT) {
@@ -371,35 +484,46 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
       fill_halo<B_IN, false, NT>(lds, tid);
       fill_halo<B_T1, true, NT>(lds, tid);
     }
-    __syncthreads();
-    conv3x3_stage<NW, 2, B_IN, B_T1, 8, false>(lds, tab, conv(0), wave, lane);                       // conv2d_1
-    __syncthreads();
-    conv3x3_stage<NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv(1), wave, lane);                        // conv2d_3 (dw)
-    __syncthreads();
-    dense_stage<NW, 1, 1, B_T2, B_T3, 0, 4, EPI_LINEAR, B_T3>(lds, nullptr, tab, conv(2), wave, lane);   // conv2d_5 (4 ch)
-    __syncthreads();
+    SYNC();
+    FETCH(1);
+    conv3x3_stage<0, NW, 2, B_IN, B_T1, 8, false>(lds, tab, conv(0), wave, lane);                    // conv2d_1
+    SYNC();
+    FETCH(2);
+    conv3x3_stage<1, NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv(1), wave, lane);                     // conv2d_3 (dw)
+    SYNC();
+    FETCH(3);
+    dense_stage<2, NW, 1, 1, B_T2, B_T3, 0, 4, EPI_LINEAR, B_T3>(lds, nullptr, tab, conv(2), wave, lane);   // conv2d_5 (4 ch)
+    SYNC();
+    FETCH(4);
     fill_halo<B_T4, false, NT>(lds, tid);
-    dense_stage<NW, 3, 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4>(lds, nullptr, tab, conv(3), wave, lane);     // conv2d_6
-    __syncthreads();
+    dense_stage<3, NW, 3, 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4>(lds, nullptr, tab, conv(3), wave, lane);     // conv2d_6
+    SYNC();
     pool8_h<NT>(lds, tid);
-    __syncthreads();
+    SYNC();
+    FETCH(5);
     pool8_v<NT>(lds, tid);                                                                            // pool_8 -> concat_22[0,18)
-    conv3x3_stage<NW, 2, B_T4, B_T6, 18, true>(lds, tab, conv(4), wave, lane);                        // conv2d_10 (dw, stride 2)
-    __syncthreads();
-    dense_stage<NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7>(lds, nullptr, tab, conv(5), wave, lane);   // conv2d_12
-    __syncthreads();
+    conv3x3_stage<4, NW, 2, B_T4, B_T6, 18, true>(lds, tab, conv(4), wave, lane);                     // conv2d_10 (dw, stride 2)
+    SYNC();
+    FETCH(6);
+    dense_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7>(lds, nullptr, tab, conv(5), wave, lane);   // conv2d_12
+    SYNC();
+    FETCH(7);
     fill_halo<B_T8, true, NT>(lds, tid);
-    dense_stage<NW, 3, 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8>(lds, nullptr, tab, conv(6), wave, lane);     // conv2d_13
-    __syncthreads();
-    conv3x3_stage<NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv(7), wave, lane);                        // conv2d_15 (dw)
-    __syncthreads();
-    dense_stage<NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7>(lds, nullptr, tab, conv(8), wave, lane);     // conv2d_17 + eltwise_18
-    __syncthreads();
-    dense_stage<NW, 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
-    __syncthreads();
+    dense_stage<6, NW, 3, 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8>(lds, nullptr, tab, conv(6), wave, lane);     // conv2d_13
+    SYNC();
+    FETCH(8);
+    conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv(7), wave, lane);                     // conv2d_15 (dw)
+    SYNC();
+    FETCH(9);
+    dense_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7>(lds, nullptr, tab, conv(8), wave, lane);     // conv2d_17 + eltwise_18
+    SYNC();
+    FETCH(10);
+    dense_stage<9, NW, 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
+    SYNC();
+    FETCH(11);
     fill_halo<B_T15, false, NT>(lds, tid);
-    dense_stage<NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
-    __syncthreads();
+    dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
+    SYNC();
     // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
     // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
     // the halo) in a per-workgroup HBM scratch and skips the tail; the second fetches it into tail set 1 (half the arena
@@ -417,36 +541,50 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
       for (int i = tid; i < PV; i += NT) reinterpret_cast<uint4*>(lds + TAIL_FS)[i] = park[i];
       out_frame1 = prm.out + parked * (7 * 7 * 18);
       parked = -1;
-      __syncthreads();
+      SYNC();
     }
+    FETCH(12);
     pool25<NT, 2, TB::T15, TB::T30>(lds, tid);                                                        // pool_25 -> concat_46[0,24)
-    conv3x3_stage<NW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave, lane);              // conv2d_27 (dw, stride 2)
-    __syncthreads();
-    dense_stage<NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, 2>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
-    __syncthreads();
+    conv3x3_stage<11, NW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave, lane);          // conv2d_27 (dw, stride 2)
+    SYNC();
+    FETCH(13);
+    dense_stage<12, NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, 2>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
+    SYNC();
+    FETCH(14);
     fill_halo<TB::T19, true, NT, 2>(lds, tid);
-    dense_stage<NW, 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
-    __syncthreads();
-    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(14), wave, lane);              // conv2d_32 (dw)
-    __syncthreads();
-    dense_stage<NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, 2>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
-    __syncthreads();
-    dense_stage<NW, 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
-    __syncthreads();
-    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(17), wave, lane);              // conv2d_38 (dw)
-    __syncthreads();
-    dense_stage<NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, 2>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
-    __syncthreads();
-    dense_stage<NW, 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
-    __syncthreads();
-    dense_stage<NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
-    __syncthreads();
-    conv3x3_stage<NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(21), wave, lane);              // conv2d_49 (dw)
-    __syncthreads();
-    dense_stage<NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
-    __syncthreads();
-    dense_stage<NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
+    dense_stage<13, NW, 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
+    SYNC();
+    FETCH(15);
+    conv3x3_stage<14, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(14), wave, lane);          // conv2d_32 (dw)
+    SYNC();
+    FETCH(16);
+    dense_stage<15, NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, 2>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
+    SYNC();
+    FETCH(17);
+    dense_stage<16, NW, 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
+    SYNC();
+    FETCH(18);
+    conv3x3_stage<17, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(17), wave, lane);          // conv2d_38 (dw)
+    SYNC();
+    FETCH(19);
+    dense_stage<18, NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, 2>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
+    SYNC();
+    FETCH(20);
+    dense_stage<19, NW, 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
+    SYNC();
+    FETCH(21);
+    dense_stage<20, NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
+    SYNC();
+    FETCH(22);
+    conv3x3_stage<21, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(21), wave, lane);          // conv2d_49 (dw)
+    SYNC();
+    FETCH(23);
+    dense_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
+    SYNC();
+    dense_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
   }
+#undef SYNC
+#undef FETCH
 }
 
 }  // namespace yf16
@@ -548,7 +686,7 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return fail(std::string("unsupported GPU ") + prop.gcnArchName); }
   c->cus = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->d_tab, blob.size()) != hipSuccess || hipMemcpy(c->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_BYTES) != hipSuccess) {
+      hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_TOTAL) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
   c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup; allocated per stream on first use
@@ -563,12 +701,26 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
   if (((uintptr_t)d_in & 3) != 0) { c->err = "fp16 input must be 4-byte aligned"; return -2; }
   HIPCHK(c, hipSetDevice(c->device));
   yf16::Params prm;
-  prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab;
+  prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab; prm.prof = nullptr;
   HIPCHK(c, c->park.get((hipStream_t)stream, c->park_region, &prm.scratch));
   long grid = (long)c->cus * 2;                              // two 76 KB workgroups per CU, persistent over the frames
   if (grid > n) grid = n;
-  hipLaunchKernelGGL(yf16::yoloface56_f16_fused<8>, dim3((unsigned)grid), dim3(512), yf16::LDS_BYTES, (hipStream_t)stream, prm);
+#ifdef YF16_BARPROF
+  if (getenv("YF16_ONE_WG_PER_CU")) grid = c->cus < n ? c->cus : n;       // dev builds: one workgroup per CU (how much do two share?)
+  const char* prof_path = getenv("YF16_PROF_OUT");               // dev builds only: the stage timeline of this launch goes to a file
+  const size_t prof_bytes = (size_t)grid * 8 * 80 * sizeof(long long);
+  if (prof_path) { HIPCHK(c, hipMalloc((void**)&prm.prof, prof_bytes)); HIPCHK(c, hipMemset(prm.prof, 0, prof_bytes)); }
+#endif
+  hipLaunchKernelGGL(yf16::yoloface56_f16_fused<8>, dim3((unsigned)grid), dim3(512), yf16::LDS_TOTAL, (hipStream_t)stream, prm);
   HIPCHK(c, hipGetLastError());
+#ifdef YF16_BARPROF
+  if (prof_path) {
+    std::vector<long long> h(prof_bytes / sizeof(long long));
+    HIPCHK(c, hipMemcpy(h.data(), prm.prof, prof_bytes, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(prof_path, "wb")) { fwrite(h.data(), 1, prof_bytes, f); fclose(f); }
+    (void)hipFree(prm.prof);
+  }
+#endif
   return 0;
 }
 
