@@ -163,6 +163,9 @@ __device__ __forceinline__ float leaky(float v) {                       // max(v
   return r;
 }
 
+// LeakyReLU of two channels, then one v_cvt_pk_f16_f32.  (On the packed halfs AFTER the conversion -- v_pk_mul_f16 by 0.1, v_pk_max_f16:
+// three instructions per pair instead of five -- the extra fp16 rounding of 0.1 h misses the tolerance and the kernel is 0.5 % faster.)
+__device__ __forceinline__ uint32_t leaky_pack2(float a, float b) { return pack2(leaky(a), leaky(b)); }
 // four fp32 results of a pass (channels chq..chq+3 of pixel p) -> activation -> fp16 -> LDS (or fp32 logits -> HBM)
 template <int EPI, class OUT, int OUT_CH0, class ADDB, int COUT>
 __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_frame, int p, int chq, v4f acc, bool live) {
@@ -177,8 +180,9 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
       v2h r0, r1; __builtin_memcpy(&r0, &r.x, 4); __builtin_memcpy(&r1, &r.y, 4);
       acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
     }
-    if constexpr (EPI == EPI_ACT) { acc[0] = leaky(acc[0]); acc[1] = leaky(acc[1]); acc[2] = leaky(acc[2]); acc[3] = leaky(acc[3]); }
-    uint2 v; v.x = pack2(acc[0], acc[1]); v.y = pack2(acc[2], acc[3]);
+    uint2 v;
+    if constexpr (EPI == EPI_ACT) { v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]); }
+    else { v.x = pack2(acc[0], acc[1]); v.y = pack2(acc[2], acc[3]); }
     *reinterpret_cast<uint2*>(lds + OUT::at_p(p) + 2 * (OUT_CH0 + chq)) = v;        // surplus lanes redo the last pixel (same value)
   }
 }
@@ -300,7 +304,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[ks]), __builtin_bit_cast(v8h, u), acc, 0, 0, 0);
     };
     auto finish = [&](v4f acc, char* dst) {
-      uint2 v; v.x = pack2(leaky(acc[0]), leaky(acc[1])); v.y = pack2(leaky(acc[2]), leaky(acc[3]));
+      uint2 v; v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]);
       *reinterpret_cast<uint2*>(dst) = v;
     };
     for (; j + 1 < jend; j += 2) {
@@ -391,7 +395,7 @@ __device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
 }
 template <int NT>
 __device__ __forceinline__ void pool8_h(char* lds, int tid) {                 // T4 [28][28] x 18 ch -> HB [28 rows][14]
-  constexpr int NO = 5, OW = 14, NCH = 3, ND = 9;                              // 9 dwords = 18 channels
+  constexpr int NO = 7, OW = 14, NCH = 2, ND = 9;                              // 9 dwords = 18 channels; 28 x 2 x 9 = 504 items: one round of the 512 threads
   for (int i = tid; i < 28 * NCH * ND; i += NT) {
     const int d = i % ND; int t = i / ND;
     const int k = t % NCH; const int y = t / NCH;
@@ -429,6 +433,36 @@ __device__ __forceinline__ void pool25(char* lds0, int tid) {                 //
   }
 }
 
+// pool_25 by COLUMNS (as in the int8 kernel): one item = (frame, output column, channel dword) walks the 14 rows of T15 once -- per row
+// the horizontal 4-tap maximum (clamped columns), pairs of rows R[j] = max(h[2j-1], h[2j]), out[oy] = max(R[oy], R[oy+1]) -- and writes
+// its 7 outputs: 56 loads per item instead of 7 x 16, no per-tap clamping.  F x 84 items: the first waves of the stage take them, the
+// others run conv2d_27, which reads the same T15.
+template <int F> constexpr int pool25_waves() { return (F * 84 + 63) / 64; }
+template <int F, class T15, class T30>
+__device__ __forceinline__ void pool25_cols(char* lds0, int item) {
+  static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7 && T15::FS == T30::FS, "pool_25 geometry");
+  if (item >= F * 84) return;
+  const int t = item / 12, d = item - 12 * t;
+  const int f = t / 7, ox = t - 7 * f;
+  char* lds = lds0 + f * T15::FS;
+  const char* base = lds + T15::at(0, 0) + 4 * d;
+  constexpr int S = T15::S, ROW = T15::RS * T15::S;
+  const int c0 = max(2 * ox - 1, 0) * S, c1 = 2 * ox * S, c2 = c1 + S, c3 = min(2 * ox + 2, 13) * S;
+  auto hrow = [&](int r) {
+    const char* p = base + r * ROW;
+    return pkmaxh(pkmaxh(lds_u32(p + c0), lds_u32(p + c1)), pkmaxh(lds_u32(p + c2), lds_u32(p + c3)));
+  };
+  char* dst = lds + T30::OFF + ox * T30::S + 4 * d;
+  uint32_t prev = hrow(0);                                     // R[0] = max(h[-1 -> 0], h[0])
+#pragma unroll
+  for (int oy = 0; oy < 7; ++oy) {
+    uint32_t next = hrow(2 * oy + 1);                          // R[oy+1] = max(h[2oy+1], h[2oy+2 -> 13])
+    if (2 * oy + 2 <= 13) next = pkmaxh(next, hrow(2 * oy + 2));
+    *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
+    prev = next;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
 struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds)
 
@@ -459,8 +493,24 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
 #define FETCH(K) fetch_w<K>(tab, conv(K).w_off, wave, lane)
+  // The next frame's input (12 bytes per item, IN_ITERS items per thread) is loaded into registers while a long stage of the current
+  // frame runs -- conv2d_23 when the frame only parks its T15, conv2d_51 when it runs the tail -- instead of behind the barrier of the
+  // staging stage, where the HBM latency was the stage's whole time (2.9 k cycles in the stage timeline).
+  constexpr int IN_ITERS = (56 * 28 + NT - 1) / NT;
+  uint32_t pin[IN_ITERS][3];
+  auto prefetch_in = [&](long frame) {
+    if (frame >= prm.n) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(prm.in + frame * (56 * 56 * 3));
+#pragma unroll
+    for (int k = 0; k < IN_ITERS; ++k) {
+      const int i = min(tid0 + k * NT, 56 * 28 - 1);
+      pin[k][0] = src[3 * i]; pin[k][1] = src[3 * i + 1]; pin[k][2] = src[3 * i + 2];
+    }
+  };
+  prefetch_in(blockIdx.x);
   long parked = -1;                                               // frame whose T15 waits in the scratch
   for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
+    const bool parks = parked < 0 && fr + gridDim.x < prm.n;     // this frame leaves after conv2d_23 (its tail runs with the next frame's)
     int tid = tid0;
     asm volatile("" : "+v"(tid));       // per-lane index arithmetic is recomputed per frame instead of parked in VGPRs for the whole kernel
     const int lane = tid & 63;
@@ -471,10 +521,13 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
 #endif
     SYNC();                                                       // previous frame's buffers are dead
     FETCH(0);
-    {   // input: fp16 [56][56][3] -> RGBX pixels with a zero top row and left column.  Two pixels (12 bytes) per item.
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(prm.in + fr * (56 * 56 * 3));
-      for (int i = tid; i < 56 * 28; i += NT) {
-        const uint32_t d0 = src[3 * i], d1 = src[3 * i + 1], d2 = src[3 * i + 2];
+    {   // input: fp16 [56][56][3] -> RGBX pixels with a zero top row and left column.  Two pixels (12 bytes) per item; the frame's
+        // dwords were loaded into registers one long stage earlier (prefetch_in)
+#pragma unroll
+      for (int k = 0; k < IN_ITERS; ++k) {
+        const int i = tid0 + k * NT;
+        if (IN_ITERS * NT != 56 * 28 && i >= 56 * 28) break;
+        const uint32_t d0 = pin[k][0], d1 = pin[k][1], d2 = pin[k][2];
         const int y = i / 28, x2 = (i - y * 28) * 2;
         uint4 px = {d0, d1 & 0xFFFFu, (d1 >> 16) | (d2 << 16), d2 >> 16};
         // pixels x2 and x2+1 of row y: halo'd pixel index (y + 1) * 57 + x2 + 1 (8 bytes each; the pair is 8-byte aligned only)
@@ -521,6 +574,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     dense_stage<9, NW, 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
     FETCH(11);
+    if (parks) prefetch_in(fr + gridDim.x);
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
     SYNC();
@@ -531,7 +585,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     // the tail alone (set 1 holds stale finite data, its logits are not stored).
     constexpr int PV = TAIL_T15_BYTES / 16;
     uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * PV;
-    if (parked < 0 && fr + gridDim.x < prm.n) {
+    if (parks) {
       for (int i = tid; i < PV; i += NT) park[i] = reinterpret_cast<const uint4*>(lds)[i];
       parked = fr;
       continue;
@@ -544,8 +598,12 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
       SYNC();
     }
     FETCH(12);
-    pool25<NT, 2, TB::T15, TB::T30>(lds, tid);                                                        // pool_25 -> concat_46[0,24)
-    conv3x3_stage<11, NW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave, lane);          // conv2d_27 (dw, stride 2)
+    {   // pool_25 -> concat_46[0,24) on the first waves (by columns), conv2d_27 (dw, stride 2) on the others: both only read T15
+      constexpr int PW = pool25_waves<2>();
+      static_assert(PW < NW, "waves left for conv2d_27");
+      if (wave < PW) pool25_cols<2, TB::T15, TB::T30>(lds, wave * 64 + lane);
+      else conv3x3_stage<11, NW - PW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave - PW, lane);
+    }
     SYNC();
     FETCH(13);
     dense_stage<12, NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, 2>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
@@ -579,6 +637,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     conv3x3_stage<21, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(21), wave, lane);          // conv2d_49 (dw)
     SYNC();
     FETCH(23);
+    prefetch_in(fr + gridDim.x);
     dense_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
     SYNC();
     dense_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
