@@ -363,9 +363,25 @@ def main():
             line["parity"] = ("bit-exact vs oracle on %d/%d frames; decoded boxes of the golden frames equal tests/golden" % (n, n)) if mism == 0 and not problems \
                 else f"MISMATCH: {mism} head bytes differ; {problems}"
             # PCIe-inclusive rate through the reference ABI (host buffers): reported, never `value`
-            t1 = time.perf_counter()
-            net.run(x)
-            line["pcie_inclusive_images_per_s"] = round(n / (time.perf_counter() - t1), 1)
+            # (the first call sizes the engine's device staging and starts its download thread: untimed; best of five after it)
+            host_heads = net.run(x)
+            if not np.array_equal(host_heads, heads):
+                problems.append("ai_network_run on host buffers differs from the device path")
+            best = float("inf")
+            for _ in range(5):          # the caller's own arrays both ways, as the firmware's static in_data / out_data
+                t1 = time.perf_counter()
+                net.run(x, out=host_heads)
+                best = min(best, time.perf_counter() - t1)
+            line["pcie_inclusive_images_per_s"] = round(n / best, 1)
+            if not args.no_secondary:   # the ABI's largest batch (ai_network_run takes a 16-bit n_batches): 65 535 frames, 617 MB of host frames
+                xl = np.tile(x, (16, 1, 1, 1))[:65535]
+                out_l = net.run(xl)
+                t1 = time.perf_counter()
+                net.run(xl, out=out_l)
+                line["pcie_inclusive_images_per_s_n65535"] = round(65535 / (time.perf_counter() - t1), 1)
+                if not np.array_equal(out_l[:n], heads) or not np.array_equal(out_l[-(65535 - 15 * n):], heads[:65535 - 15 * n]):
+                    problems.append("ai_network_run on 65535 host frames differs from the device path")
+                del xl, out_l
             # what the reference's own caller does (yoloface.c aiRun: n_batches = 1, host buffers): one frame per ai_network_run
             # (skipped with --no-secondary, which the profiling script uses: these 210 one-frame launches carry the headline kernel's
             # name and would be averaged into a rocprofv3 --stats summary of the command)

@@ -272,10 +272,14 @@ class Network:
         self.ready = True
         return self
 
-    def run(self, frames):
-        """ai_network_run on host memory: int8 [n,56,56,3] -> int8 [n,7,7,18] (yoloface.c:216-240, n_batches = n)."""
+    def run(self, frames, out=None):
+        """ai_network_run on host memory: int8 [n,56,56,3] -> int8 [n,7,7,18] (yoloface.c:216-240, n_batches = n).  `out`: the caller's
+        own result array (the firmware passes the same static out_data every call), else a fresh one."""
         x = np.ascontiguousarray(frames, dtype=np.int8).reshape(-1, IN_H, IN_W, IN_C)
-        out = np.empty((x.shape[0], OUT_H, OUT_W, OUT_C), np.int8)
+        if out is None:
+            out = np.empty((x.shape[0], OUT_H, OUT_W, OUT_C), np.int8)
+        elif out.dtype != np.int8 or not out.flags.c_contiguous or out.size != x.shape[0] * OUT_H * OUT_W * OUT_C:
+            raise ValueError("out must be a C-contiguous int8 array of n x 7 x 7 x 18")
         done = 0
         while done < x.shape[0]:                     # n_batches is 16 bit (ai_platform.h:519)
             n = min(65535, x.shape[0] - done)

@@ -4,7 +4,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include "yf_engine.h"
 #include "yf_stream_scratch.h"
 #include "yf_decode.hip.h"
@@ -98,7 +102,7 @@ struct Variant { int f, nw; bool dump; bool exp; bool cam; fused_fn fn; size_t l
                               "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
 // production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
 const Variant k_variants[] = {
-  YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
+  YF_VARIANT(1, 4, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
   YF_VARIANT(2, 4, true), YF_VARIANT(2, 8, true),
   YF_VARIANT_X(2, 8),
   YF_VARIANT_CAM(2, 8),           // camera-format input (112x112 RGB565), the shipped shape only
@@ -120,6 +124,67 @@ struct yf_engine {
   hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
+  // ---- host-buffer path (ai_network_run on the caller's arrays, yf_engine_run_host)
+  const Variant* var_small = nullptr;            // batches of at most SMALL_N frames: one frame per workgroup (lowest latency); null once a shape is configured
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};   // large batches: chunks alternate between two streams (upload of chunk k+1 behind the kernel of chunk k)
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};
+  void* h_small_in = nullptr; void* h_small_out = nullptr;   // pinned, device-mapped: tiny batches are read / written by the kernel in place (no copy submissions)
+  struct Downloader* dl = nullptr;               // worker thread: results of finished chunks go to the caller's array while later chunks upload
+};
+constexpr long SMALL_N = 512;                    // frames: below this every frame gets a workgroup of its own
+constexpr long ZERO_COPY_N = 8;                  // frames: the kernel reads the caller's frames from pinned host memory
+constexpr long PIPE_MIN_N = 2048, PIPE_CHUNK_DEFAULT = 3072, PIPE_LAST_DEFAULT = 1024;
+
+// Downloads device -> pageable host memory on a thread of their own.  A copy into pageable memory blocks the calling thread until
+// it is done; issued from the thread that also uploads, every download would hold up the next chunk's upload.
+struct Downloader {
+  struct Job { hipEvent_t ready; const void* src; void* dst; size_t bytes; };
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_idle;
+  std::deque<Job> q;
+  int pending = 0;
+  bool stop = false;
+  hipError_t status = hipSuccess;
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        j = q.front(); q.pop_front();
+      }
+      hipError_t rc = hipStreamWaitEvent(stream, j.ready, 0);
+      if (rc == hipSuccess) rc = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, stream);
+      if (rc == hipSuccess) rc = hipStreamSynchronize(stream);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != hipSuccess && status == hipSuccess) status = rc;
+        --pending; cv_idle.notify_all();
+      }
+    }
+  }
+  hipError_t start(int dev) {
+    device = dev;
+    const hipError_t rc = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (rc != hipSuccess) return rc;
+    th = std::thread([this] { loop(); });
+    return hipSuccess;
+  }
+  void submit(const Job& j) { { std::lock_guard<std::mutex> lk(mu); q.push_back(j); ++pending; } cv_job.notify_one(); }
+  hipError_t drain() { std::unique_lock<std::mutex> lk(mu); cv_idle.wait(lk, [&] { return pending == 0; }); const hipError_t rc = status; status = hipSuccess; return rc; }
+  // wait until fewer than `below` downloads are outstanding (the submitter re-uses a chunk's event two chunks later)
+  hipError_t drain_to(int below) { std::unique_lock<std::mutex> lk(mu); cv_idle.wait(lk, [&] { return pending < below; }); return status; }
+  ~Downloader() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_job.notify_all();
+    if (th.joinable()) th.join();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
 };
 
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
@@ -227,8 +292,15 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = hipStreamCreateWithFlags(&e->pipe_stream[k], hipStreamNonBlocking)) != hipSuccess) return bail(rc, "hipStreamCreateWithFlags");
+    if ((rc = hipEventCreateWithFlags(&e->pipe_ev[k], hipEventDisableTiming)) != hipSuccess) return bail(rc, "hipEventCreateWithFlags");
+  }
+  if ((rc = hipHostMalloc(&e->h_small_in, (size_t)ZERO_COPY_N * 9408, hipHostMallocMapped)) != hipSuccess ||
+      (rc = hipHostMalloc(&e->h_small_out, (size_t)ZERO_COPY_N * 882, hipHostMallocMapped)) != hipSuccess) return bail(rc, "hipHostMalloc(pinned staging)");
   e->var = find_variant(2, 8, false);
   e->var_dump = find_variant(2, 8, true);
+  e->var_small = find_variant(1, 8, false);
   *out = e;
   return YF_ENG_OK;
 }
@@ -244,6 +316,13 @@ void yf_engine_destroy(yf_engine* e) {
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e->dl;                                  // joins the download thread
+  for (int k = 0; k < 2; ++k) {
+    if (e->pipe_ev[k]) (void)hipEventDestroy(e->pipe_ev[k]);
+    if (e->pipe_stream[k]) (void)hipStreamDestroy(e->pipe_stream[k]);
+  }
+  if (e->h_small_in) (void)hipHostFree(e->h_small_in);
+  if (e->h_small_out) (void)hipHostFree(e->h_small_out);
   delete e;
 }
 
@@ -275,6 +354,7 @@ int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   const Variant* v = find_variant(f, nw, false, exp);
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
+  e->var_small = nullptr;                        /* an explicitly configured shape runs every batch size */
   e->var_dump = exp ? nullptr : find_variant(f, nw, true);   /* debug build of the SAME shape, or none: the dump / stage-timing
                                                                  entry points refuse instead of running another shape */
   return YF_ENG_OK;
@@ -289,6 +369,10 @@ const char* yf_engine_build_id(void) { return YF_BUILD_ID; }
 long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
 
 struct DecodeArgs { void* dets; void* counts; int cap, mode; float w_scale, h_scale; };
+
+// Kernel shape for a batch of n frames: up to SMALL_N frames run one frame per workgroup (every frame on a CU of its own: a 1-frame
+// batch takes 24 us instead of 34), larger batches the throughput shape.
+static const Variant* shape_for(const yf_engine* e, long n) { return (e->var_small && n <= SMALL_N) ? e->var_small : e->var; }
 
 static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out, void* d_dump, long n, hipStream_t s, int stop_stage = -1,
                   const DecodeArgs* dec = nullptr) {
@@ -322,7 +406,7 @@ int yf_engine_run_device(yf_engine* e, const void* d_in, void* d_out, void* d_du
   return launch(e, e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);      // profile build: the production variant fills d_dump with barrier waits
 #else
   if (d_dump && !e->var_dump) { e->err = "no debug (dump) build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
-  return launch(e, d_dump ? e->var_dump : e->var, d_in, d_out, d_dump, n, (hipStream_t)stream);
+  return launch(e, d_dump ? e->var_dump : shape_for(e, n), d_in, d_out, d_dump, n, (hipStream_t)stream);
 #endif
 }
 
@@ -331,7 +415,7 @@ int yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, lon
   if (!e || !d_in || !d_out || !d_dets || !d_counts || n < 0 || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST)) return YF_ENG_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
-  return launch(e, e->var, d_in, d_out, nullptr, n, (hipStream_t)stream, -1, &dec);
+  return launch(e, shape_for(e, n), d_in, d_out, nullptr, n, (hipStream_t)stream, -1, &dec);
 }
 
 // camera frames (112x112 big-endian RGB565) -> heads (+ boxes when d_dets is given): the frame preparation runs inside the
@@ -348,10 +432,29 @@ int yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out,
   return launch(e, v, d_rgb565, d_out, nullptr, n, (hipStream_t)stream, -1, d_dets ? &dec : nullptr);
 }
 
+// ai_network_run on the caller's host arrays (the reference's own call path: yoloface.c:216-240 hands in_data / out_data).
+//   n <= ZERO_COPY_N : the frames are copied into pinned, device-mapped memory and the kernel reads them -- and writes the heads --
+//                      over PCIe itself: no copy submissions, one launch, one synchronisation.
+//   n >= PIPE_MIN_N  : chunks of PIPE_CHUNK frames alternate between two streams, so the upload of chunk k+1 runs behind the
+//                      kernel of chunk k, and a worker thread downloads the heads of finished chunks meanwhile (the last chunk is
+//                      cut short: what cannot overlap anything is its kernel and its download).
+//   otherwise        : upload, one launch, download.
+// Device staging grows on the first call that needs more (never shrinks): no allocation on the call path after that.
 int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {
   if (!e || !h_in || n < 0) return YF_ENG_ERR_ARG;        /* h_out may be NULL (ai_network_forward) */
   if (n == 0) return YF_ENG_OK;
   HIPCHK(e, hipSetDevice(e->device));
+  if (n <= ZERO_COPY_N) {
+    memcpy(e->h_small_in, h_in, (size_t)n * 9408);
+    void *d_i = nullptr, *d_o = nullptr;
+    HIPCHK(e, hipHostGetDevicePointer(&d_i, e->h_small_in, 0));
+    HIPCHK(e, hipHostGetDevicePointer(&d_o, e->h_small_out, 0));
+    const int rc = launch(e, shape_for(e, n), d_i, d_o, nullptr, n, e->own_stream);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->own_stream));
+    if (h_out) memcpy(h_out, e->h_small_out, (size_t)n * 882);
+    return YF_ENG_OK;
+  }
   if (n > e->stage_cap) {
     if (e->d_in) (void)hipFree(e->d_in);
     if (e->d_out) (void)hipFree(e->d_out);
@@ -360,11 +463,50 @@ int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {
     HIPCHK(e, hipMalloc(&e->d_out, (size_t)n * 882));
     e->stage_cap = n;
   }
-  HIPCHK(e, hipMemcpyAsync(e->d_in, h_in, (size_t)n * 9408, hipMemcpyHostToDevice, e->own_stream));
-  const int rc = launch(e, e->var, e->d_in, e->d_out, nullptr, n, e->own_stream);
-  if (rc) return rc;
-  if (h_out) HIPCHK(e, hipMemcpyAsync(h_out, e->d_out, (size_t)n * 882, hipMemcpyDeviceToHost, e->own_stream));
-  HIPCHK(e, hipStreamSynchronize(e->own_stream));
+  if (n < PIPE_MIN_N) {
+    HIPCHK(e, hipMemcpyAsync(e->d_in, h_in, (size_t)n * 9408, hipMemcpyHostToDevice, e->own_stream));
+    const int rc = launch(e, shape_for(e, n), e->d_in, e->d_out, nullptr, n, e->own_stream);
+    if (rc) return rc;
+    if (h_out) HIPCHK(e, hipMemcpyAsync(h_out, e->d_out, (size_t)n * 882, hipMemcpyDeviceToHost, e->own_stream));
+    HIPCHK(e, hipStreamSynchronize(e->own_stream));
+    return YF_ENG_OK;
+  }
+  if (h_out && !e->dl) {
+    e->dl = new Downloader();
+    const hipError_t rc = e->dl->start(e->device);
+    if (rc != hipSuccess) { delete e->dl; e->dl = nullptr; e->err = std::string("download stream: ") + hipGetErrorString(rc); return YF_ENG_ERR_HIP; }
+  }
+  static const long PIPE_CHUNK = [] { const char* v = getenv("YF_PIPE_CHUNK"); const long c = v ? atol(v) : 0; return c >= 256 ? c : PIPE_CHUNK_DEFAULT; }();   // tuning knobs
+  static const long PIPE_LAST = [] { const char* v = getenv("YF_PIPE_LAST"); const long c = v ? atol(v) : 0; return c >= 64 ? c : PIPE_LAST_DEFAULT; }();
+  int rc = YF_ENG_OK;
+  hipError_t hrc = hipSuccess;
+  long done = 0;
+  for (int k = 0; done < n && rc == YF_ENG_OK && hrc == hipSuccess; ++k) {
+    long c = n - done < PIPE_CHUNK ? n - done : PIPE_CHUNK;
+    if (c == n - done && c > 2 * PIPE_LAST) c -= PIPE_LAST;              // the batch ends with a short chunk
+    hipStream_t st = e->pipe_stream[k & 1];
+    const char* src = (const char*)h_in + done * 9408;
+    char* d_i = (char*)e->d_in + done * 9408;
+    char* d_o = (char*)e->d_out + done * 882;
+    // the previous use of this stream's event (chunk k-2) has been consumed by the download stream's wait before its copy ran; with
+    // two events in flight and in-order downloads, re-recording here cannot overtake a pending wait only if that download is done:
+    if (h_out && k >= 2) { const hipError_t r = e->dl->drain_to(2); if (r != hipSuccess) { hrc = r; break; } }
+    hrc = hipMemcpyAsync(d_i, src, (size_t)c * 9408, hipMemcpyHostToDevice, st);
+    if (hrc != hipSuccess) break;
+    rc = launch(e, e->var, d_i, d_o, nullptr, c, st);
+    if (rc != YF_ENG_OK) break;
+    if (h_out) {
+      hrc = hipEventRecord(e->pipe_ev[k & 1], st);
+      if (hrc != hipSuccess) break;
+      e->dl->submit(Downloader::Job{e->pipe_ev[k & 1], d_o, (char*)h_out + done * 882, (size_t)c * 882});
+    }
+    done += c;
+  }
+  // everything issued is waited for, whatever happened above: the caller's arrays must not be touched after this returns
+  const hipError_t d_rc = e->dl && h_out ? e->dl->drain() : hipSuccess;
+  const hipError_t s0 = hipStreamSynchronize(e->pipe_stream[0]), s1 = hipStreamSynchronize(e->pipe_stream[1]);
+  if (rc != YF_ENG_OK) return rc;
+  for (hipError_t r : {hrc, d_rc, s0, s1}) if (r != hipSuccess) { e->err = std::string("pipelined host run: ") + hipGetErrorString(r); return YF_ENG_ERR_HIP; }
   return YF_ENG_OK;
 }
 
