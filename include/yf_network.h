@@ -211,7 +211,9 @@ enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anc
 
 /* Select GPU (default 0 / $LOCAL_RANK is NOT read here; the caller decides).  Call before ai_network_init. */
 YF_API int  yf_network_set_device(ai_handle network, int device);
-/* Kernel variant: frames per workgroup (1,2,4) and waves per workgroup (4,8). 0 keeps the default. */
+/* Kernel variant: frames per workgroup (1,2,4) and waves per workgroup (4,8); 0 keeps the current value.  Without a call the choice
+ * is automatic -- the throughput shape <2,8>, and batches of up to 512 frames one frame per workgroup (<1,8>: a 1-frame batch takes
+ * 24 us instead of 34) -- and frames_per_wg = -1 returns to that.  A configured shape runs every batch size. */
 YF_API int  yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg);
 /* Device-resident batch: d_in int8[n][56][56][3], d_out int8[n][7][7][18], both in HBM, d_in 4-byte aligned.
  * stream is a hipStream_t (NULL = default stream); asynchronous.  Returns n or <= 0 (error latched). */
@@ -282,6 +284,8 @@ YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, 
 /* Text of the last HIP/runtime failure (empty string if none). */
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);
+/* Name of the kernel shape a batch of n frames runs (see yf_network_configure). */
+YF_API const char* yf_network_kernel_name_for(ai_handle network, long n);
 /* Identity of the device code inside this library: the first 16 hex digits of the sha256 over the device sources and the
  * compiler flags they were built with (csrc/Makefile, BUILD_ID).  Profiles are stamped with it; bench.py reports counters of a
  * profile only when the stamp equals the id of the library it is running.  Host-only, no GPU. */

@@ -87,7 +87,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
-           "yf_network_kernel_name", "yf_network_build_id",
+           "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
            "ai_platform_network_get_error", "ai_platform_network_init", "ai_platform_network_post_init",
@@ -175,6 +175,8 @@ def load():
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
     lib.yf_network_kernel_name.argtypes = [vp]
+    lib.yf_network_kernel_name_for.restype = ctypes.c_char_p
+    lib.yf_network_kernel_name_for.argtypes = [vp, ctypes.c_long]
     lib.yf_network_build_id.restype = ctypes.c_char_p
     lib.yf_network_build_id.argtypes = []
     _lib = lib
@@ -349,6 +351,10 @@ class Network:
     @property
     def kernel_name(self):
         return (self.lib.yf_network_kernel_name(self.handle) or b"").decode()
+
+    def kernel_name_for(self, n):
+        """the kernel shape a batch of n frames runs (automatic choice unless configure() fixed one)"""
+        return (self.lib.yf_network_kernel_name_for(self.handle, n) or b"").decode()
 
     @property
     def build_id(self):

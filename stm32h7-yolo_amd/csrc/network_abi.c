@@ -269,6 +269,11 @@ YF_API int yf_network_set_device(ai_handle network, int device) {
 YF_API int yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg) {
   yf_context* c = acquire(network);
   if (!c) return -1;
+  if (frames_per_wg < 0) {                       /* automatic: the shipped throughput shape, small batches one frame per workgroup */
+    if (c->state == ST_READY) (void)yf_engine_configure(c->engine, -1, -1);
+    c->cfg_frames = c->cfg_waves = 0;
+    return 0;
+  }
   /* validate first: a rejected shape must not poison the stored configuration (every later ai_network_init would fail) */
   const int f = frames_per_wg > 0 ? frames_per_wg : (c->cfg_frames > 0 ? c->cfg_frames : 2);
   const int w = waves_per_wg > 0 ? waves_per_wg : (c->cfg_waves > 0 ? c->cfg_waves : 8);
@@ -458,4 +463,9 @@ YF_API const char* yf_network_build_id(void) { return yf_engine_build_id(); }
 YF_API const char* yf_network_kernel_name(ai_handle network) {
   yf_context* c = acquire(network);
   return (c && c->engine) ? yf_engine_kernel_name(c->engine) : "";
+}
+
+YF_API const char* yf_network_kernel_name_for(ai_handle network, long n) {
+  yf_context* c = acquire(network);
+  return (c && c->engine) ? yf_engine_kernel_name_for(c->engine, n) : "";
 }

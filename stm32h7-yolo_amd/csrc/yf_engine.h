@@ -22,6 +22,7 @@ int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);
 int  yf_engine_table_plan(int32_t* out, int cap);
 const char* yf_engine_error(const yf_engine* e);
 const char* yf_engine_kernel_name(const yf_engine* e);
+const char* yf_engine_kernel_name_for(const yf_engine* e, long n);   /* the shape a batch of n frames runs */
 const char* yf_engine_build_id(void);
 
 /* device-resident batch; d_dump may be NULL */

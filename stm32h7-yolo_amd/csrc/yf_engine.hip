@@ -190,6 +190,7 @@ struct Downloader {
 #define HIPCHK(e_, call) do { hipError_t rc_ = (call); if (rc_ != hipSuccess) { \
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
+static const Variant* shape_for(const yf_engine* e, long n);
 static const Variant* find_variant(int f, int nw, bool dump, bool exp = false, bool cam = false) {
   for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.exp == exp && v.cam == cam) return &v;
   return nullptr;
@@ -347,6 +348,10 @@ int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) {
 
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
+  if (frames_per_wg < 0) {                       /* back to the automatic choice: throughput shape, small batches one frame per workgroup */
+    e->var = find_variant(2, 8, false); e->var_dump = find_variant(2, 8, true); e->var_small = find_variant(1, 8, false);
+    return YF_ENG_OK;
+  }
   /* frames_per_wg + 200 selects the experimental (YF_EXP) build of the same shape */
   const bool exp = frames_per_wg >= 200;
   if (exp) frames_per_wg -= 200;
@@ -362,6 +367,7 @@ int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
 
 const char* yf_engine_error(const yf_engine* e) { return e ? e->err.c_str() : "null engine"; }
 const char* yf_engine_kernel_name(const yf_engine* e) { return e && e->var ? e->var->name : ""; }
+const char* yf_engine_kernel_name_for(const yf_engine* e, long n) { return e && e->var ? shape_for(e, n)->name : ""; }
 #ifndef YF_BUILD_ID
 #define YF_BUILD_ID "unstamped"
 #endif
