@@ -210,6 +210,15 @@ static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned gr
 
 // 160x160, banded form: four kernels, each fusing a group of stages over row bands staged through LDS
 struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; int wgs_per_cu; };
+#ifndef YF_K1_NW
+#define YF_K1_NW 8
+#endif
+#define YF_K1_NW_ YF_K1_NW
+static BandKernel k_band_fused[3] = {            // round 3: K2 and K3 fused (three tensors cross HBM instead of five)
+  {(const void*)yf160::band::band_k1<YF_K1_NW_>, "band_k1", YF_K1_NW_ * 64, (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
+  {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS, 1},
+  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
+};
 static BandKernel k_band[4] = {
 #ifndef YF_K1_NW
 #define YF_K1_NW 8
@@ -219,8 +228,12 @@ static BandKernel k_band[4] = {
   {(const void*)yf160::band::band_k3<8>,  "band_k3", 512,  (size_t)yf160::band::K3_LDS, yf160::band::K3_BANDS, 1},
   {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
 };
+static bool g_split_k23 = false;                 // YF_160_SPLIT_K23=1: the round-2 form with separate band_k2 / band_k3 (A/B, debugging)
 static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
-  for (const BandKernel& k : k_band) {
+  const BandKernel* list = g_split_k23 ? k_band : k_band_fused;
+  const int count = g_split_k23 ? 4 : 3;
+  for (int i = 0; i < count; ++i) {
+    const BandKernel& k = list[i];
     const long jobs = prm.n * k.jobs_per_frame;
     const long full = (long)e->cus * k.wgs_per_cu;           // persistent grid: every workgroup resident, jobs grid-strided
     const unsigned grid = (unsigned)(jobs < full ? jobs : full);
@@ -275,7 +288,8 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     if ((rc = hipFuncGetAttributes(&at, (const void*)yf160::generic_stage_kernel<1, 8>)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
     if (at.sharedSizeBytes != 0) { delete e; return fail("generic stage kernel has static LDS", YF_ENG_ERR_HIP); }
   }
-  for (BandKernel& k : k_band) {
+  { const char* sp = getenv("YF_160_SPLIT_K23"); g_split_k23 = sp && sp[0] == '1'; }
+  auto prepare_band = [&](BandKernel& k) -> int {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, k.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
     if (at.sharedSizeBytes != 0) { delete e; return fail(std::string(k.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP); }
@@ -284,7 +298,10 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     int occ = 0;
     if ((rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, (int)k.threads, k.lds)) != hipSuccess) return bail(rc, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
     k.wgs_per_cu = occ > 0 ? occ : 1;
-  }
+    return YF_ENG_OK;
+  };
+  for (BandKernel& k : k_band) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
+  for (BandKernel& k : k_band_fused) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
   { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // A/B and debugging only
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;

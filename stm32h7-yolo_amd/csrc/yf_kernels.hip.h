@@ -2220,6 +2220,126 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
   }
 }
 
+// ---- K23: K2 and K3 fused (round 3) ------------------------------------------------------------------------------------
+// One band job = 8 rows of the 40x40 grid through pool_8 .. conv2d_23: T4 rows in, T15 rows out; the pooled half of concat_22, T7 and T8
+// never leave the chip (three tensors cross HBM instead of five: 0.73 -> 0.49 MB per frame).  conv2d_15's 3x3 window needs T8 rows
+// p0-1 .. p0+8, so conv2d_10 / 12 / 13 run on TEN rows per band (the T4 rows they need, 2p0-3 .. 2p0+17, are inside the 22 rows the
+// pool already loads); rows outside the image are computed from whatever the LDS holds and then overwritten with the halo.
+// LDS: [LUTs][T4 22 rows -> T8 10 rows | T9][HB 22 rows -> T6 10 rows | T7 10 rows -> T11 | T15][T14 8 rows] = 79 KB, two per CU.
+constexpr int K23_BP = 8, K23_BANDS = G2 / K23_BP, K23_NR = 2 * K23_BP + 6, K23_NM = K23_BP + 2;      // pooled rows, T4 rows, T6/T7/T8 rows
+static_assert(G2 % K23_BP == 0 && K23_BP % 4 == 0, "band height must divide the grid; the vertical pool pass sweeps 4 rows");
+constexpr int K23_RA = LB, K23_RA_BYTES = K23_NR * T4_ROW;                                  // region A: T4, later T8 | T9
+constexpr int K23_RH = K23_RA + K23_RA_BYTES, K23_RH_BYTES = K23_NR * G2 * 20;               // region H: HB, later T6 | T7, later T11 | T15
+constexpr int K23_R14 = K23_RH + K23_RH_BYTES;                                              // concat_22 rows of the band
+typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4;       // local row l = T4 row 2p0-3+l
+typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4_DW;    // conv2d_10's view: output row t (T6 row p0-1+t) reads local rows 2t .. 2t+2
+typedef Buf<K23_RH,                              G2, K23_NR, 20, G2,     0, 0> L23_HB;
+typedef Buf<K23_RH,                              G2, K23_NM, 32, G2,     0, 0> L23_T6;       // aliases HB (dead after the vertical pool pass)
+typedef Buf<K23_RH + K23_NM * G2 * 32,           G2, K23_NM,  8, G2,     0, 0> L23_T7;       // rows p0-1 .. p0+8
+typedef Buf<L23_T7::OFF + G2 * 8,                G2, K23_BP,  8, G2,     0, 0> L23_T7C;      // rows p0 .. p0+7: the residual input of eltwise_18
+typedef Buf<K23_RA,                              G2, K23_NM, 36, T8_RS,  0, 1> L23_T8;       // aliases T4 (dead after conv2d_10); halo'd rows p0 .. p0+9
+typedef Buf<K23_RA + K23_NM * T8_ROW,            G2, K23_BP, 48, G2,     0, 0> L23_T9;
+typedef Buf<K23_RH,                              G2, K23_BP,  8, G2,     0, 0> L23_T11;      // aliases T6 (dead after conv2d_12)
+typedef Buf<K23_R14,                             G2, K23_BP, 48, G2,     0, 0> L23_T14;
+typedef Buf<K23_RH + K23_BP * G2 * 8,            G2, K23_BP, 24, T15_RS, 0, 1> L23_T15;      // behind T11, on T6's old bytes
+constexpr int K23_LDS = K23_R14 + K23_BP * G2 * 48;
+static_assert(K23_NM * G2 * 32 + K23_NM * G2 * 8 <= K23_RH_BYTES && K23_NM * T8_ROW + K23_BP * G2 * 48 <= K23_RA_BYTES, "aliases fit");
+static_assert(K23_BP * G2 * 8 + K23_BP * T15_ROW <= K23_NM * G2 * 32, "T11 | T15 fit T6's bytes (T7 behind them stays alive until conv2d_17)");
+static_assert(K23_LDS <= 81920 && K23_RA % 16 == 0 && K23_RH % 16 == 0 && K23_R14 % 16 == 0 && L23_T9::OFF % 16 == 0 && L23_T15::OFF % 16 == 0, "two workgroups per CU, aligned buffers");
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  auto addctx = [&](int k) {
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
+  };
+  const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15)), z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
+  char* frames = smem;
+  const long jobs = prm.n * K23_BANDS;
+  Prefetch<NT, K23_NR * T4_ROW / 16> pre;
+  // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
+  auto range = [&](long job, const char*& src, int& lo_local, int& n16) {
+    const long fr = job / K23_BANDS;
+    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;
+    const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K23_NR, G1 + 1);
+    src = prm.arena + fr * (long)ARENA_BYTES + A_T4 + lo * T4_ROW;
+    lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
+  };
+  long job = blockIdx.x;
+  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
+  for (; job < jobs; job += gridDim.x) {
+    const long fr = job / K23_BANDS;
+    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;           // first 40x40 row of the band
+    char* arena = prm.arena + fr * (long)ARENA_BYTES;
+    lds_barrier();
+    YF_BAND_PRIO(3);
+    { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L23_T4::OFF + ll * T4_ROW, n16, tid); }
+    lds_barrier();
+    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
+    {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
+      constexpr int NO = 5, NCH = G2 / NO;
+      static_assert(G2 % NO == 0, "sweeps of 5 outputs");
+      for (int i = tid; i < K23_NR * NCH * 5; i += NT) {
+        const int cg = i % 5; int t = i / 5;
+        const int k = t % NCH; const int l = t / NCH;
+        const char* row = frames + L23_T4::OFF + l * T4_ROW + 20 + 4 * cg;                // pixel 0 sits behind the halo column
+        char* dst = frames + L23_HB::OFF + l * (G2 * 20) + 4 * cg;
+        pool8_sweep<NO, G1 - 1>(k * NO, [&](int x) { return lds_u32(row + x * 20); },
+                                [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
+      }
+    }
+    lds_barrier();
+    {   // vertical pass + QUANTIZE#21 straight into the pooled half of the band's concat_22 rows
+      constexpr int NO = 4, NSW = K23_BP / NO;
+      for (int i = tid; i < NSW * G2 * 5; i += NT) {
+        const int cg = i % 5; int t = i / 5;
+        const int ox = t % G2; const int sw = t / G2;
+        const char* col = frames + L23_HB::OFF + ox * 20 + 4 * cg;
+        char* dst = frames + L23_T14::OFF + ox * 48 + 4 * cg;
+        pool8_sweep<NO, G1 - 1>(p0 + sw * NO, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
+                                [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 48)) = lut4_raw<YF_L_Q21>(v); });
+      }
+    }
+    lds_barrier();                                                 // T6 (written next) aliases HB
+    YF_BAND_PRIO(2);
+    dw_mfma_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);      // ten rows
+    lds_barrier();
+    dense_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
+    lds_barrier();
+    dense_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
+    fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
+    fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
+    lds_barrier();
+    if (p0 == 0) fill_dwords<NT>(frames + L23_T8::OFF, z_t8, T8_ROW, tid);                                       // T8 row -1 = halo
+    if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
+    if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
+    YF_BAND_PRIO(1);
+    dw_mfma_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
+    lds_barrier();
+    dense_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
+    lds_barrier();
+    dense_stage<F, NW, 2, 1, 8, L23_T11, L23_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L23_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
+    lds_barrier();
+    YF_BAND_PRIO(0);
+    dense_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
+    fill_column<NT, T15_ROW, 24>(frames + L23_T15::OFF, 0, K23_BP, z_t15, tid);
+    lds_barrier();
+    store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L23_T15::OFF, K23_BP * T15_ROW, tid);
+    if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
+  }
+}
+
 // ---- K4: the 20x20 tail ------------------------------------------------------------------------------------------------
 // Two 8-wave workgroups per CU (78 KB each) instead of one 16-wave workgroup with the whole T15 (41 KB) in LDS: the tail's
 // stages are latency chains with few jobs, so two independent frames per CU with twice the jobs per wave are faster, and two

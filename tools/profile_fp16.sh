@@ -34,6 +34,12 @@ c = res["counters"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     res["hbm_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024      # gfx950: FETCH_SIZE counts half of a streaming read
     res["algorithmic_bytes_per_launch"] = 4096 * (56 * 56 * 3 * 2 + 7 * 7 * 18 * 4)
+try:    # stamp: the id of the library the profile was taken with (bench.py reports these counters only for the same build)
+    import importlib
+    sys.path.insert(0, os.getcwd())
+    res["source_hash"] = importlib.import_module("stm32h7-yolo_amd").load().yf_network_build_id().decode()
+except Exception as e:
+    res["source_hash"] = None
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -8,7 +8,7 @@ import sys
 
 
 def short(name):
-    for k in ("band_k1", "band_k2", "band_k3", "band_k4"):
+    for k in ("band_k1", "band_k23", "band_k2", "band_k3", "band_k4"):
         if k in name:
             return k
     if "generic_stage_kernel" in name:
@@ -19,11 +19,16 @@ def short(name):
 def main():
     out = sys.argv[1]
     res = {}
-    for f in glob.glob(os.path.join(out, "trace", "*kernel_stats.csv")):
+    # kernel time of the FULL-BATCH launches (1024 frames): the command also runs a 6-frame parity batch, which the --stats
+    # average would mix in
+    for f in glob.glob(os.path.join(out, "trace", "*kernel_trace.csv")):
+        per = {}
         for r in csv.DictReader(open(f)):
-            k = short(r["Name"])
-            if k:
-                res.setdefault(k, {})["trace"] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3}
+            k = short(r["Kernel_Name"])
+            if k and int(r["Grid_Size_X"]) >= 256 * 512:
+                per.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for k, v in per.items():
+            res.setdefault(k, {})["trace"] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v)}
     for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         if not os.path.isdir(d):
             continue
@@ -48,6 +53,13 @@ def main():
     res["total"] = {"kernel_us_sum": tot["us"], "fetch_bytes_raw": tot["fetch_raw"], "write_bytes": tot["write"],
                     "hbm_bytes_per_batch": 2 * tot["fetch_raw"] + tot["write"], "frames": 1024,
                     "hbm_bytes_per_frame": (2 * tot["fetch_raw"] + tot["write"]) / 1024, "algorithmic_bytes_per_frame": 160 * 160 * 3 + 20 * 20 * 18}
+    try:    # stamp: the id of the library the profile was taken with (bench.py reports these counters only for the same build)
+        import importlib
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        res["total"]["source_hash"] = importlib.import_module("stm32h7-yolo_amd").load().yf_network_build_id().decode()
+    except Exception as e:      # noqa: BLE001
+        res["total"]["source_hash"] = None
+        print("no build id:", e)
     json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
