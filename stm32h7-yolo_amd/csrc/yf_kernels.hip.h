@@ -32,6 +32,7 @@
 #define YF_EXP_MASK 0
 #endif
 #define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
+#define YF_ROW_SKEW (YF_TOGGLED(256) ? 0 : 4)      /* bytes; the experimental build with mask bit 256 runs without the skew (A/B) */
 namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
@@ -61,11 +62,15 @@ constexpr int BUF_FS = FRAME_BYTES;
 #else
 constexpr int BUF_FS = 0;                      // one frame per workgroup
 #endif
-template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = BUF_FS>
+// SK: extra bytes per row (row pitch ROWB = RS * S + SK).  The depthwise tap reads put lane (g, c) of a 32-lane half on row g, column c:
+// with 8- or 40-byte pixels a row's 16 lanes cover the 16 even LDS banks, and an even row pitch (in dwords) puts the next row on the
+// same banks -- a 2-way conflict on every tap read.  One dword of skew per row makes the pitch odd: rows alternate between the even
+// and the odd banks and the reads are conflict-free (T1: conv2d_3's input; T19: the input of conv2d_32 / 38 / 49).
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = BUF_FS, int SK_ = 0>
 struct Buf {
-  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_;
-  static constexpr int P = W_ * H_;
-  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + ((y + PT_) * RS_ + (x + PL_)) * S_; }
+  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_, SK = SK_;
+  static constexpr int P = W_ * H_, ROWB = RS_ * S_ + SK_;
+  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + (y + PT_) * ROWB + (x + PL_) * S_; }
   __device__ static __forceinline__ int at_p(int p) {
     if constexpr (RS_ == W_ && PT_ == 0 && PL_ == 0) return OFF_ + p * S_;
     else { const int y = p / W_; return at(y, p - y * W_); }
@@ -82,8 +87,8 @@ static_assert(G0 % 8 == 0 && G3 >= 4, "input size must be a multiple of 8 and at
 // LDS-resident plan for 56x56 (hand-placed, buffers alias by lifetime)
 //                 OFF    W   H   S  RS PT PL
 typedef Buf<    0, 56, 56,  4, 60, 1, 4> B_IN;    // RGBX dwords, top halo row, halo column at dword 3
-typedef Buf<13696, 28, 28,  8, 30, 1, 1> B_T1;    // conv2d_1 out (+LeakyReLU), halo ring for dw3
-typedef Buf<20896, 28, 28,  8, 28, 0, 0> B_T2;    // conv2d_3 out
+typedef Buf<13696, 28, 28,  8, 30, 1, 1, BUF_FS, YF_ROW_SKEW> B_T1;    // conv2d_1 out (+LeakyReLU), halo ring for dw3; 30 rows of 244 bytes
+typedef Buf<21024, 28, 28,  8, 28, 0, 0> B_T2;    // conv2d_3 out
 typedef Buf<16832, 28, 28,  4, 28, 0, 0> B_T3;    // conv2d_5 out
 typedef Buf<    0, 28, 28, 20, 29, 1, 1> B_T4;    // conv2d_6 out, top/left halo for dw10
 typedef Buf<16832, 14, 28, 20, 14, 0, 0> B_HB;    // pool_8 horizontal pass [28 rows][14]
@@ -97,11 +102,11 @@ typedef Buf<    0, 14, 14, 24, 15, 1, 1> B_T15;   // conv2d_23 out, top/left hal
 typedef Buf< 5408,  7,  7, 48,  7, 0, 0> B_T30;   // concat_46: pool [0,24) | conv [24,48)
 typedef Buf< 7760,  7,  7, 32,  7, 0, 0> B_T17;   // conv2d_27 out
 typedef Buf< 9328,  7,  7,  8,  7, 0, 0> B_T18;   // conv2d_29 out
-typedef Buf< 9728,  7,  7, 40,  9, 1, 1> B_T19;   // conv2d_30/36/47 out, halo ring (three lifetimes)
-typedef Buf<12976,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
-typedef Buf<15328,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
-typedef Buf<15720,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
-typedef Buf<16112,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
+typedef Buf< 9728,  7,  7, 40,  9, 1, 1, BUF_FS, YF_ROW_SKEW> B_T19;   // conv2d_30/36/47 out, halo ring (three lifetimes); 9 rows of 364 bytes
+typedef Buf<13008,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
+typedef Buf<15360,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
+typedef Buf<15752,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
+typedef Buf<16144,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
 // The 7x7 tail (pool_25 ... conv2d_53) works on one 17 KB SET per frame: the same offsets as above, T33 on T17's slot
 // (dead after conv2d_29) and the staged head behind T26.  FS = FRAME_BYTES addresses the sets at the start of each frame's
 // arena; FS = FRAME_BYTES / 2 packs two sets per arena (tail batching: see the kernel).
@@ -111,13 +116,14 @@ struct TailBufs {
   typedef Buf< 5408,  7,  7, 48,  7, 0, 0, FS_> T30;
   typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T17;
   typedef Buf< 9328,  7,  7,  8,  7, 0, 0, FS_> T18;
-  typedef Buf< 9728,  7,  7, 40,  9, 1, 1, FS_> T19;
-  typedef Buf<12976,  7,  7, 48,  7, 0, 0, FS_> T20;
-  typedef Buf<15328,  7,  7,  8,  7, 0, 0, FS_> T22;
-  typedef Buf<15720,  7,  7,  8,  7, 0, 0, FS_> T26;
+  typedef Buf< 9728,  7,  7, 40,  9, 1, 1, FS_, YF_ROW_SKEW> T19;
+  typedef Buf<13008,  7,  7, 48,  7, 0, 0, FS_> T20;
+  typedef Buf<15360,  7,  7,  8,  7, 0, 0, FS_> T22;
+  typedef Buf<15752,  7,  7,  8,  7, 0, 0, FS_> T26;
   typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T33;
-  typedef Buf<16128,  7,  7, 18,  7, 0, 0, FS_> HEAD;
-  static constexpr int END = 16128 + 882, T15_BYTES = 5408;
+  typedef Buf<16160,  7,  7, 18,  7, 0, 0, FS_> HEAD;
+  static constexpr int END = 16160 + 882, T15_BYTES = 5408;
+  static_assert(T19::OFF + 9 * T19::ROWB <= T20::OFF && T20::OFF + 49 * 48 <= T22::OFF && T26::OFF + 49 * 8 <= HEAD::OFF, "tail buffers do not overlap");
   static_assert(END <= FS_, "a set fits its stride");
 };
 #else
@@ -389,7 +395,7 @@ YF_STAGE_FN void fill_halo(char* frames, int zp, int tid) {
     } else {
       if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
     }
-    *reinterpret_cast<uint32_t*>(frames + f * B::FS + B::OFF + (r * WR + c) * B::S + 4 * d) = v;
+    *reinterpret_cast<uint32_t*>(frames + f * B::FS + B::OFF + r * B::ROWB + c * B::S + 4 * d) = v;
   }
 }
 
@@ -672,8 +678,8 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
   constexpr int NFP = F / FL;
   constexpr int JPG = NFP * NRB * NSEG;                     // jobs per channel group
   constexpr int JOBS = NG * JPG;
-  constexpr int DROW = STRIDE * IN::RS * IN::S;             // input bytes between consecutive output rows
-  constexpr int TS = IN::S, TR = IN::RS * IN::S;            // tap strides: +1 column, +1 row
+  constexpr int DROW = STRIDE * IN::ROWB;                   // input bytes between consecutive output rows
+  constexpr int TS = IN::S, TR = IN::ROWB;                  // tap strides: +1 column, +1 row
   static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
   static_assert(IN::FS == OUT::FS, "one frame stride per stage");
   static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
@@ -711,7 +717,7 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       char* fb = frames + fp * FL * IN::FS;
-      const char* src = fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + 4 * cg + lane_in;
+      const char* src = fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + 4 * cg + lane_in;
 #if YF_EXP == 5    // what-if (wrong results): no LDS reads of the taps
       { const int u = (int)(uintptr_t)src; b0 = v4i{u, u + 1, u + 2, u + 3}; b1 = v4i{u + 4, u + 5, u + 6, u + 7}; b2[0] = u + 8; }
 #else
@@ -1108,7 +1114,7 @@ struct DwGeo {
     const int oy0 = min(rb * 4, H - 4);
     const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
     const int fb = fp * FL * IN::FS;
-    return uint2{(uint32_t)(fb + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
+    return uint2{(uint32_t)(fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
   }
 };
 // job tables of the five depthwise geometries (8 bytes per job of one channel group), laid out one after another
@@ -1143,7 +1149,7 @@ struct HaloGeo {
     } else {
       if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
     }
-    return (uint32_t)(f * B::FS + B::OFF + (r * WR + c) * B::S);
+    return (uint32_t)(f * B::FS + B::OFF + r * B::ROWB + c * B::S);
   }
 };
 template <int F, bool BATCH>
@@ -1190,8 +1196,8 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
   typedef DwGeo<F, STRIDE, IN, OUT> G;
   constexpr int W = G::W, FL = G::FL, JPG = G::JPG;
   constexpr int NG = (C + 3) / 4, JOBS = NG * JPG;
-  constexpr int DROW = STRIDE * IN::RS * IN::S;                // input bytes between consecutive output rows
-  constexpr int TS = IN::S, TR = IN::RS * IN::S;               // tap strides: +1 column, +1 row
+  constexpr int DROW = STRIDE * IN::ROWB;                      // input bytes between consecutive output rows
+  constexpr int TS = IN::S, TR = IN::ROWB;                     // tap strides: +1 column, +1 row
   constexpr int SLOT = slot(CS);
   static_assert(yf_cs_dw[CS] >= 0 && NG == plan_passes(CS), "stage and constant block agree");
   const int g = lane >> 4, c = lane & 15;
@@ -1280,7 +1286,7 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
   if (f >= FT) return;
   char* fbase = frames + f * T15::FS;
   const char* base = fbase + T15::at(0, 0) + 4 * cg;
-  constexpr int S = T15::S, ROW = T15::RS * T15::S;
+  constexpr int S = T15::S, ROW = T15::ROWB;
   const int c0 = max(2 * ox - 1, 0) * S, c1 = 2 * ox * S, c2 = c1 + S, c3 = min(2 * ox + 2, 13) * S;
   auto hrow = [&](int r) {
     const char* p = base + r * ROW;
