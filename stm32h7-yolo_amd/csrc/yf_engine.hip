@@ -28,6 +28,10 @@
 #endif
 #undef YF_LAUNDER
 #define YF_LAUNDER YF_LAUNDER_X
+#ifdef YF_PRIO_LIST_X       /* another priority ladder for the experimental namespace (A/B) */
+#undef YF_PRIO_LIST
+#define YF_PRIO_LIST YF_PRIO_LIST_X
+#endif
 #ifdef YF_V2_X              /* 0: the experimental namespace keeps the round-2 stage forms (constants from global memory) for A/B */
 #define YF_V2 YF_V2_X
 #endif
