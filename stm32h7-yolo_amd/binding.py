@@ -7,6 +7,7 @@ The library has no CPU compute path: without a gfx950 GPU `init()` raises.
 """
 import ctypes
 import os
+import sys
 import subprocess
 import weakref
 
@@ -110,6 +111,29 @@ def build(force=False):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process can drive the GPU through ONE HIP/HSA runtime only.  PyTorch-ROCm ships its own copy (torch/lib/libamdhip64.so) and
+    loads it by path; libyf_network.so asks for `libamdhip64.so.7` by name.  If PyTorch comes first, that name resolves to PyTorch's copy
+    and all is well; if this library came first, /opt/rocm's copy would be loaded, PyTorch would add its own, and whichever initialises
+    second finds no device ("no ROCm-capable device is detected" / "No HIP GPUs are available").  So when PyTorch is installed and not
+    yet imported, its runtime is pre-loaded here; a C caller, or a Python process without PyTorch, uses /opt/rocm's."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the library (building it first if the .so is missing) and declare the prototypes."""
     global _lib
@@ -117,6 +141,7 @@ def load():
         return _lib
     if not os.environ.get("YF_LIB_PATH"):
         build()                  # `make`: a no-op when the library is current, so a stale .so is never loaded under fresh sources
+    _one_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     vp, cl = ctypes.c_void_p, ctypes.c_long
     lib.ai_network_create.restype = AiError

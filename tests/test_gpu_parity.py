@@ -101,6 +101,17 @@ def b_make(x):
     return b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, x.shape[0], x.ctypes.data)
 
 
+@pytest.mark.parametrize("order", ["lib_first", "lib_init_first", "torch_first"])
+def test_library_and_pytorch_in_either_order(order):
+    """One process, one HIP runtime: the binding pre-loads PyTorch's copy of libamdhip64 when PyTorch is installed, so the library may be
+    loaded (and even initialised) before `import torch` -- __graft_entry__.build() followed by smoke() in one process is that order."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "order_probe.py"), order], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "init ok" in out.stdout and "failed" not in out.stdout, out.stdout + out.stderr
+    if order != "torch_first":
+        assert "cuda available True" in out.stdout
+
+
 def test_golden_fixtures(network, golden):
     heads = network.run(golden["inputs"])
     assert np.array_equal(heads, golden["heads"])
