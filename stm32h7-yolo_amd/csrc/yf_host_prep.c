@@ -243,7 +243,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
 
   /* ---------------- LUTs ---------------- */
   if (!rc) {
-    ix->lut_off = (uint32_t)blob_alloc(&b, (size_t)YF_N_LUT * 256 + YF_ADDLUT_BYTES);
+    ix->lut_off = (uint32_t)blob_alloc(&b, (size_t)YF_N_LUT * 256 + YF_ADDLUT_BYTES + YF_DBG_LUT_BYTES);
     uint8_t* L = b.p + ix->lut_off;
     int32_t* AL = (int32_t*)(L + YF_N_LUT * 256);            /* [add][A|B][256] */
     for (int s = 0; s < YF_N_ADD; ++s) {
@@ -271,6 +271,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     build_leaky_lut(91, 92, l43);                            /* LEAKY_RELU #43 */
     build_requant_lut(92, 102, q44);                         /* QUANTIZE #44 */
     for (int i = 0; i < 256; ++i) L[256 * YF_L_L43Q44 + i] = q44[(int)(int8_t)l43[i] + 128];
+    memcpy(L + YF_N_LUT * 256 + YF_ADDLUT_BYTES, l43, 256);   /* LEAKY_RELU #43 alone: the debug builds' per-node dump (tensor 92 is never materialised otherwise) */
   }
 
   /* ---------------- constant blocks of the fused 56x56 kernel (yf_tables.h): the same numbers, regrouped ---------------- */

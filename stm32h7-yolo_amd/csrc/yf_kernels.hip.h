@@ -341,7 +341,7 @@ constexpr TablePlan make_plan() {
     off = (off + 15) & ~15; p.c_off[i] = off; off += (cp / 4) * (int)sizeof(yf_pass);
   }
   for (int i = 0; i < YF_N_DW; ++i) { off = (off + 15) & ~15; p.g_off[i] = off; off += ((PLAN_DWC[i] + 3) / 4) * YF_DW_GROUP_BYTES; }
-  off = (off + 15) & ~15; p.lut_off = off; off += YF_N_LUT * 256 + YF_ADDLUT_BYTES;
+  off = (off + 15) & ~15; p.lut_off = off; off += YF_N_LUT * 256 + YF_ADDLUT_BYTES + YF_DBG_LUT_BYTES;
   for (int cs = 0; cs < YF_N_CS; ++cs) {
     const int bytes = yf_cs_dense[cs] >= 0 ? plan_wbytes(cs) + plan_passes(cs) * (int)sizeof(yf_pass_v) + (yf_cs_add[cs] >= 0 ? 2048 : 0)
                                            : plan_passes(cs) * YF_DWV_GROUP_BYTES;
@@ -801,7 +801,7 @@ YF_STAGE_FN void pool8_h(char* frames, int tid) {
                                  [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
   }
 }
-template <int F, int NT>
+template <int F, int NT, bool STASH = false>      // STASH (debug builds): the raw pooled value goes to the still unwritten conv half of concat_22
 YF_STAGE_FN void pool8_v(char* frames, int tid) {
   constexpr int NO = 5, OW = B_HB::W, OH = B_T14::H, NCH = (OH + NO - 1) / NO;   // the last chunk shifted up
   static_assert(OH >= NO, "column shorter than one sweep");
@@ -814,7 +814,10 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
     char* dst = fbase + B_T14::OFF + ox * B_T14::S + 4 * cg;
     pool8_sweep<NO, B_HB::H - 1>(min(k * NO, OH - NO),
                                  [&](int r) { return lds_u32(col + r * (OW * 20)); },
-                                 [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4_raw<YF_L_Q21>(v); });
+                                 [&](int oy, const SplitB& v) {
+                                   *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = lut4_raw<YF_L_Q21>(v);
+                                   if constexpr (STASH) *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S) + YF_T14_CONV_BASE) = v.merge();
+                                 });
   }
 }
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
@@ -899,14 +902,21 @@ template <int W> struct DivW {
 };
 
 // residual-add context of the lean stages: the two 256-entry int32 tables sit in the stage's ring slot at LA / LA + 1024
-template <int EPI, int LUT_ID, int LA>
-__device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char* headpix, int chq, int hq, const int (&idx)[4], const AddK& ad) {
+template <int EPI, int LUT_ID, int LA, int STASH_LUT = -1>
+__device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char* headpix, int chq, int hq, const int (&idx)[4], const AddK& ad,
+                                          char* stashpix = nullptr) {
   if constexpr (EPI == EPI_LUT) {
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+    if constexpr (STASH_LUT >= 0) {          // debug builds: the same indices through another table (absolute LDS address) to the stash
+      if (stashpix) *reinterpret_cast<uint32_t*>(stashpix + chq) =
+          join4(*(lds_u8_ptr)(uint32_t)(STASH_LUT + idx[0]), *(lds_u8_ptr)(uint32_t)(STASH_LUT + idx[1]),
+                *(lds_u8_ptr)(uint32_t)(STASH_LUT + idx[2]), *(lds_u8_ptr)(uint32_t)(STASH_LUT + idx[3]));
+    }
   } else if constexpr (EPI == EPI_RAW) {
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
   } else if constexpr (EPI == EPI_ADD) {
     typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
+    if (stashpix) *reinterpret_cast<uint32_t*>(stashpix + chq) = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;   // debug builds: the convolution's own output
     const uint32_t o = lds_u32(addpix + chq) ^ 0x80808080u;
     v4i sum;
 #pragma unroll
@@ -925,7 +935,10 @@ __device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char
 }
 
 // ---- dense 1x1 (lane-private MFMA, see dense_stage), constants from ring slot CS
-template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB, int CS>
+// STASH_OFF >= 0 (debug builds, residual-add stages): the convolution's own requantised output of pixel p also goes to byte
+// STASH_OFF + p * STASH_S of the frame's arena (the per-node observer wants the tensor the fused add never materialises)
+template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB, int CS,
+          int STASH_OFF = -1, int STASH_S = 0, int STASH_LUT = -1>
 YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const AddK ad, int wave, int lane) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
   constexpr int P = IN::P, TOT = F * P;
@@ -945,7 +958,8 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
   const uint32_t a_step = a_on ? (uint32_t)(TPJ * 4 * KROW) : 0u;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
   // per-lane pixel offsets of the frame-per-tile form
-  int in_c = 0, out_c = 0, add_c = 0;
+  int in_c = 0, out_c = 0, add_c = 0, stash_c = 0;
+  static_assert(STASH_OFF < 0 || EPI == EPI_ADD || (EPI == EPI_LUT && STASH_LUT >= 0), "a stash is the pre-add convolution output or a second LUT's view");
   if constexpr (FRAME_TILES) {
     const int p = min(lane, P - 1);                            // surplus lanes redo the last pixel (same value, same address)
     in_c = IN::OFF + p * IN::S;
@@ -953,6 +967,7 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
     else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) out_c = OUT::OFF + p * OUT::S + OUT_CH0;
     else { const int y = DivW<OUT::W>::div(p); out_c = OUT::at(y, p - y * OUT::W) + OUT_CH0; }
     add_c = ADDB::OFF + p * ADDB::S;
+    if constexpr (STASH_OFF >= 0) stash_c = STASH_OFF + p * STASH_S;
   }
   int j0, j1;
   job_range<JOBS, NW>(wave, j0, j1);
@@ -977,11 +992,12 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
     const int cq = chunk * TPJ * 4;                              // first channel of the chunk: rides in the pixel bases, the pass in the immediates
     const int out_cc = out_c + cq, add_cc = add_c + cq;
     for (int k = 0; k < n; ++k, ++mt) {
-      const char* src; char* dstpix = nullptr; const char* addpix = nullptr; char* headpix = nullptr;
+      const char* src; char* dstpix = nullptr; const char* addpix = nullptr; char* headpix = nullptr; char* stashpix = nullptr;
       if constexpr (FRAME_TILES) {
         char* fbase = frames + mt * IN::FS;
         src = fbase + in_c;
         dstpix = fbase + out_cc; addpix = fbase + add_cc;
+        if constexpr (STASH_OFF >= 0) stashpix = fbase + stash_c + cq;
         if constexpr (EPI == EPI_HEAD) headpix = out_all + mt * OUT_FRAME_BYTES + out_c;
         if constexpr (EPI == EPI_HEAD_LDS) headpix = fbase + OUT::OFF + out_c;
       } else {
@@ -997,6 +1013,7 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
         else if constexpr (OUT::RS == OUT::W && OUT::PT == 0 && OUT::PL == 0) dstpix = fbase + cq + OUT::OFF + p * OUT::S + OUT_CH0;
         else { const int y = DivW<OUT::W>::div(p); dstpix = fbase + cq + OUT::at(y, p - y * OUT::W) + OUT_CH0; }
         if constexpr (EPI == EPI_ADD) addpix = fbase + cq + ADDB::OFF + p * ADDB::S;
+        if constexpr (STASH_OFF >= 0) stashpix = fbase + cq + STASH_OFF + p * STASH_S;
       }
       v4i b[KS];
 #pragma unroll
@@ -1038,7 +1055,7 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
           for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
           int idx[4];
           requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
-          epilogue2<EPI, LUT_ID, LA>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad);
+          epilogue2<EPI, LUT_ID, LA, STASH_LUT>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad, stashpix);
         }
       }
     }
@@ -1278,7 +1295,7 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
 // of 7 x 60 for the direct 4x4 window; FT x 42 items, i.e. a few waves' worth: the stage gives pool_25 to the first POOL25_WAVES
 // waves and conv2d_27 (which reads the same T15) to the others.
 template <int FT> constexpr int pool25_waves() { return (FT * 42 + 63) / 64; }
-template <int FT, class T15, class T30>
+template <int FT, class T15, class T30, bool STASH = false>      // STASH (debug builds): raw pooled value -> the conv half of concat_46
 YF_STAGE_FN void pool25_cols(char* frames, int item) {
   static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7 && T15::FS == T30::FS, "pool_25 geometry");
   const int t = DivW<6>::div(item), cg = item - 6 * t;
@@ -1298,7 +1315,9 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
   for (int oy = 0; oy < 7; ++oy) {
     SplitB next = hrow(2 * oy + 1);                            // R[oy+1] = max(h[2oy+1], h[2oy+2 -> 13])
     if (2 * oy + 2 <= 13) next = next.mx(hrow(2 * oy + 2));
-    *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = lut4_raw<YF_L_Q45>(prev.mx(next));
+    const SplitB mxv = prev.mx(next);
+    *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = lut4_raw<YF_L_Q45>(mxv);
+    if constexpr (STASH) *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S) + 24) = mxv.merge();
     prev = next;
   }
 }
@@ -1324,7 +1343,13 @@ struct DumpOffsets {   // byte offsets of each fused stage's tensor inside one f
          T8 = T7 + 1176, T9 = T8 + 7056, T11 = T9 + 7056, T14 = T11 + 1176, T15 = T14 + 7056, Q45 = T15 + 4704,
          T17 = Q45 + 1176, T18 = T17 + 1176, T19 = T18 + 392, T20 = T19 + 1960, T22 = T20 + 1960, T23 = T22 + 392,
          T24 = T23 + 1960, T26 = T24 + 1960, T30 = T26 + 392, T31 = T30 + 2352, T32 = T31 + 1960, T33 = T32 + 1960,
-         TOTAL = T33 + 1568 };
+         // tensors that the fused stages never materialise, dumped for the per-node observer (platform_abi.c): the raw max-pools (ST's
+         // pool nodes carry their input's quantisation; the kernel applies QUANTIZE in the same pass) and the convolutions in front of
+         // the residual adds (the add is part of their epilogue).  Debug builds park them in bytes of the concat buffers that are still
+         // unwritten at that point (the conv halves) and dump them from there.
+         // ... and LEAKY_RELU #43's output (production composes it with QUANTIZE #44 into one LUT)
+         P8 = T33 + 1568, C17 = P8 + 3528, P25 = C17 + 1176, C34 = P25 + 1176, C40 = C34 + 392, L43 = C40 + 392,
+         TOTAL = L43 + 1176 };
 };
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -1394,6 +1419,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   for (int i = tid0; i < v2::LUT_B / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
   for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
+  constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + F * FRAME_BYTES;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
+  if constexpr (DUMP) { if (tid0 < YF_DBG_LUT_BYTES / 16) reinterpret_cast<uint4*>(smem + DBG_LUT)[tid0] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off + YF_N_LUT * 256 + YF_ADDLUT_BYTES)[tid0]; }
   {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
     typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
     typedef typename JTS::U UT;
@@ -1541,12 +1568,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC();
     YF_STAGE_END()
     YF_PRIO(6);
-    pool8_v<F, NT>(frames, tid_m);                                                             // pool_8 (v) + QUANTIZE#21
+    pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
     YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
     YF_PRIO(7);
     YF_FETCH(5, W_m, L_m);
     YF_DW(F, 2, B_T4, B_T6, 18, YF_L_LEAKY11, YF_W_DW10, W_m, L_m, 4, JT_DW10);                          // conv2d_10
-    YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T6, 18, T6)
+    YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T14, 18, P8, YF_T14_CONV_BASE) YF_DUMP(B_T6, 18, T6)
     YF_STAGE_END()
     YF_PRIO(8);
     YF_FETCH(6, W_m, L_m);
@@ -1566,8 +1593,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(11);
     YF_FETCH(9, W_m, L_m);
+#if YF_V2
+    if constexpr (DUMP)   // debug builds: conv2d_17's own output is parked in the (still unwritten) conv half of concat_22 for the dump
+      v2::dense2_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, 8, B_T14::OFF + YF_T14_CONV_BASE, B_T14::S>(frames, out_all, tab, addctx(YF_A_ADD18), W_m, L_m);
+    else
+#endif
     YF_DENSE(F, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, YF_D_C17, addctx(YF_A_ADD18), W_m, L_m, 8);   // conv2d_17 + eltwise_18
-    YF_SYNC(); YF_DUMP(B_T11, 6, T11)
+    YF_SYNC(); YF_DUMP(B_T11, 6, T11) YF_DUMP(B_T14, 6, C17, YF_T14_CONV_BASE)
     YF_STAGE_END()
     YF_PRIO(12);
     YF_FETCH(10, W_m, L_m);
@@ -1642,7 +1674,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
       constexpr int PW = v2::pool25_waves<FT>();
       static_assert(PW < NW, "waves left for conv2d_27");
-      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30>(frames, W_t * 64 + L_t);
+      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30, DUMP>(frames, W_t * 64 + L_t);
       else v2::dw2_stage<FT, NW - PW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, 11, v2::JobTabs<F, BATCH>::JT_DW27>(frames, tab, W_t - PW, L_t);
     }
 #else
@@ -1650,7 +1682,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_FETCH(12, W_t, L_t);
     YF_DW(FT, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, YF_W_DW27, W_t, L_t, 11, JT_DW27);    // conv2d_27
 #endif
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T17, 24, T17)
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T30, 24, P25, 24) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
     YF_PRIO(15);
     YF_FETCH(13, W_t, L_t);
@@ -1671,8 +1703,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(18);
     YF_FETCH(16, W_t, L_t);
+#if YF_V2
+    if constexpr (DUMP)   // debug builds: conv2d_34's own output -> the conv half of concat_46 (written by conv2d_42 only)
+      v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, 15, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD35), W_t, L_t);
+    else
+#endif
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, YF_D_C34, addctx(YF_A_ADD35), W_t, L_t, 15);   // conv2d_34 + eltwise_35
-    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22)
+    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22) YF_DUMP_T(typename U::T30, 8, C34, 24)
     YF_STAGE_END()
     YF_PRIO(19);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
@@ -1687,13 +1724,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(21);
     YF_FETCH(19, W_t, L_t);
+#if YF_V2
+    if constexpr (DUMP)
+      v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, 18, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD41), W_t, L_t);
+    else
+#endif
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, YF_D_C40, addctx(YF_A_ADD41), W_t, L_t, 18);   // conv2d_40 + eltwise_41
-    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26)
+    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26) YF_DUMP_T(typename U::T30, 8, C40, 24)
     YF_STAGE_END()
     YF_PRIO(22);
     YF_FETCH(20, W_t, L_t);
+#if YF_V2
+    if constexpr (DUMP)   // debug builds: LEAKY_RELU #43's output (through the debug LUT) -> T20's slot, dead since conv2d_40
+      v2::dense2_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, 19, U::T20::OFF, U::T20::S, DBG_LUT>(frames, out_all, tab, no_add, W_t, L_t);
+    else
+#endif
     YF_DENSE(FT, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30)
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) YF_DUMP_T(typename U::T20, 24, L43)
     YF_STAGE_END()
     YF_PRIO(23);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW49, tid_t);
@@ -1759,7 +1806,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::pre_bytes<F, tail_batch<DUMP>()>() : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES; }
+constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::pre_bytes<F, tail_batch<DUMP>()>() : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES + (DUMP ? YF_DBG_LUT_BYTES : 0); }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 

@@ -65,6 +65,7 @@ typedef struct {
  *   A[q1] = MBQM((q1 - zp1) << 20, m1, s1)   (the stored operand)     B[q2] = MBQM((q2 - zp2) << 20, m2, s2) + O
  * laid out [YF_N_ADD][2][256] right behind the byte LUTs. */
 #define YF_ADDLUT_BYTES (YF_N_ADD * 2 * 256 * 4)
+#define YF_DBG_LUT_BYTES 256   /* behind the add tables: LEAKY_RELU #43 alone (production composes it with QUANTIZE #44); only the debug builds load it, for the per-node dump */
 
 enum {
   /* dense stages in execution order */
@@ -113,7 +114,7 @@ typedef struct {
   yf_dense dense[YF_N_DENSE];
   yf_dw    dw[YF_N_DW];
   yf_add   add[YF_N_ADD];
-  uint32_t lut_off;          /* YF_N_LUT * 256 bytes of byte LUTs followed by YF_ADDLUT_BYTES of add tables */
+  uint32_t lut_off;          /* YF_N_LUT * 256 bytes of byte LUTs followed by YF_ADDLUT_BYTES of add tables and YF_DBG_LUT_BYTES */
   uint32_t total_bytes;
   int32_t  in_zp;            /* input zero point (-128): halo fill of the staged frame */
   int32_t  halo_zp[YF_N_DW]; /* zero point of each depthwise INPUT buffer: its halo fill value */
