@@ -291,6 +291,39 @@ YF_API const char* yf_network_kernel_name_for(ai_handle network, long n);
  * profile only when the stamp equals the id of the library it is running.  Host-only, no GPU. */
 YF_API const char* yf_network_build_id(void);
 
+/* ---- per-node observer of the runtime-level interface (reference ai_platform_interface.h:684-731 datatypes, 981-1024 entry points).
+ * Available to callers that link the reference's generated network.c against this library (the node list is theirs): an observed
+ * ai_network_run goes through the debug build of the kernel, which dumps every node's output tensor, and the registered client is
+ * called before / after every c-node, frame by frame, with the node's tensor chain; the node's output tensor then holds that node's
+ * result at the address the caller's graph gives it.  AI_OBSERVER_INIT_EVT, `inner_tensors` and the scratch tensors' contents are not
+ * reproduced (csrc/platform_abi.c). */
+typedef struct __attribute__((packed, aligned(4))) ai_observer_node_s {
+  ai_u16 c_idx;                 /* node index (position in the execution list) */
+  ai_u16 type;                  /* node type */
+  ai_u16 id;                    /* id the code generator gave the model layer */
+  ai_u16 unused;
+  const void* inner_tensors;    /* const ai_tensor_chain*: always NULL here */
+  const void* tensors;          /* const ai_tensor_chain*: the caller's own chain of the node */
+} ai_observer_node;
+#define AI_OBSERVER_NONE_EVT    (0)
+#define AI_OBSERVER_INIT_EVT    (1 << 0)
+#define AI_OBSERVER_PRE_EVT     (1 << 1)
+#define AI_OBSERVER_POST_EVT    (1 << 2)
+#define AI_OBSERVER_FIRST_EVT   (1 << 8)
+#define AI_OBSERVER_LAST_EVT    (1 << 9)
+#define AI_OBSERVER_REGISTERED  (1 << 24)
+#define AI_OBSERVER_MASK_EVT    (0xFF)
+typedef ai_u32 (*ai_observer_node_cb)(const ai_handle cookie, const ai_u32 flags, const ai_observer_node* node);
+struct ai_node_s;
+typedef struct __attribute__((packed, aligned(4))) ai_observer_exec_ctx_s {
+  ai_observer_node_cb on_node; ai_handle cookie; ai_u32 flags; ai_u16 c_idx; ai_u16 n_nodes; struct ai_node_s* cur;
+} ai_observer_exec_ctx;
+YF_API ai_bool ai_platform_observer_node_info(ai_handle network, ai_observer_node* node_info);
+YF_API ai_bool ai_platform_observer_register(ai_handle network, ai_observer_node_cb cb, ai_handle cookie, ai_u32 flags);
+YF_API ai_bool ai_platform_observer_register_s(ai_handle network, ai_observer_exec_ctx* ctx);
+YF_API ai_bool ai_platform_observer_unregister(ai_handle network, ai_observer_node_cb cb, ai_handle cookie);
+YF_API ai_bool ai_platform_observer_unregister_s(ai_handle network, ai_observer_exec_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

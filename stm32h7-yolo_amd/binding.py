@@ -89,6 +89,8 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
            "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id",
+           "ai_platform_observer_node_info", "ai_platform_observer_register", "ai_platform_observer_register_s",
+           "ai_platform_observer_unregister", "ai_platform_observer_unregister_s",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
            "ai_platform_context_acquire", "ai_platform_network_create", "ai_platform_network_destroy",
            "ai_platform_network_get_error", "ai_platform_network_init", "ai_platform_network_post_init",

@@ -182,6 +182,29 @@ ai_i32 yf_impl_run(ai_handle network, const ai_buffer* input, ai_buffer* output)
 
 ai_i32 yf_impl_forward(ai_handle network, const ai_buffer* input) { return process(network, input, NULL); }
 
+/* Per-node observer (platform_abi.c): validates like ai_network_run, then runs the debug build on frames [first, first + count) of
+ * `input`: heads into `heads` (count x 882 bytes), every node's tensor into `dump` (count x yf_impl_dump_bytes()).  0 on error (latched). */
+ai_i32 yf_impl_run_dump(ai_handle network, const ai_buffer* input, const ai_buffer* output, long first, long count, int8_t* heads, int8_t* dump) {
+  yf_context* c = acquire(network);
+  if (!c) return 0;
+  if (c->state != ST_READY || !c->engine) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_MISSED_INIT, "network not initialised"); return 0; }
+  if (!check_io(c, input, 1)) return 0;
+  if (output) {
+    if (!check_io(c, output, 0)) return 0;
+    if (output->n_batches < input->n_batches) { latch(c, AI_ERROR_INVALID_OUTPUT, AI_ERROR_CODE_INVALID_BATCH, "output holds fewer batches than input"); return 0; }
+  }
+  if (first < 0 || count < 1 || first + count > input->n_batches || !heads || !dump) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_OUT_OF_RANGE, "observed frame range"); return 0; }
+  const int rc = yf_engine_run_host_dump(c->engine, (const int8_t*)input->data + first * AI_NETWORK_IN_1_SIZE, heads, dump, count);
+  if (rc != YF_ENG_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_engine_error(c->engine)); return 0; }
+  return (ai_i32)count;
+}
+long yf_impl_dump_bytes(void) { return yf_engine_dump_bytes(); }
+long yf_impl_dump_offset(int tflite_op) { return yf_engine_dump_offset(tflite_op); }
+void yf_impl_fail_run(ai_handle network, unsigned code, const char* text) {
+  yf_context* c = acquire(network);
+  if (c) latch(c, AI_ERROR_INVALID_STATE, code, text);
+}
+
 /* ------------------------------------------------------------------------------------------------ report */
 static ai_buffer g_io_in = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_IN_1_HEIGHT, AI_NETWORK_IN_1_WIDTH, AI_NETWORK_IN_1_CHANNEL, NULL, NULL };
 static ai_buffer g_io_out = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_OUT_1_HEIGHT, AI_NETWORK_OUT_1_WIDTH, AI_NETWORK_OUT_1_CHANNEL, NULL, NULL };

@@ -222,8 +222,125 @@ YF_API void* ai_platform_network_init(ai_handle network, const ai_network_params
 
 YF_API ai_bool ai_platform_network_post_init(ai_handle network) { return own(network) != AI_HANDLE_NULL; }
 
+/* ---- per-node observer (reference ai_platform_interface.h:684-731, 981-1024) ----------------------------------------------------
+ * ST's runtime calls a registered client before and/or after every c-node with the node's tensor chain; the node's output tensor then
+ * holds that node's result in the caller's activation arrays.  The fused engine has no per-node execution, so an OBSERVED run goes
+ * through the debug build of the kernel instead: it dumps the output tensor of every one of the 31 nodes per frame (the six the fused
+ * stages never materialise included -- raw max-pools, the convolutions in front of the residual adds, LEAKY_RELU #43 alone), and this
+ * layer then walks the caller's node list in execution order, frame by frame: PRE call-back, the node's tensor copied from the dump
+ * into the address the caller's graph gives it, POST call-back.  The input tensor's and the last node's data pointers are bound to
+ * the caller's I/O buffers for the duration of the run, as ST's runtime does (network.c:2954-2955, 3016-3017 leave them NULL).
+ * Not reproduced: AI_OBSERVER_INIT_EVT, the `inner_tensors` of a node (NULL) and the content of the scratch tensors (the
+ * pre-activation values of convolutions with a fused LeakyReLU exist only as LUT indices inside the kernel).  Values follow TFLite's
+ * arithmetic, like everything this library computes (ST's LUT rounding differs by 1 LSB in places). */
+static struct { ai_observer_node_cb cb; ai_handle cookie; ai_u32 flags; ai_observer_exec_ctx* ctx; } g_obs;
+
+/* node i of k_graph: its output tensor = C channels of P pixels; source = the dump tensor of tflite op `op` (PIX channels per pixel
+ * there, this node's channels start at CH0), or the heads for the last node (op 0) */
+typedef struct { int16_t op, c, p, pix, ch0; } yf_node_src;
+static const yf_node_src k_node_src[31] = {
+  { 2,  8, 784,  8, 0}, { 4,  8, 784,  8, 0}, { 5,  4, 784,  4, 0}, { 7, 18, 784, 18, 0}, {11, 18, 196, 18, 0}, {12,  6, 196,  6, 0},
+  {14, 36, 196, 36, 0}, {16, 36, 196, 36, 0}, {17,  6, 196,  6, 0}, {18,  6, 196,  6, 0}, {22, 18, 196, 36, 18}, { 8, 18, 196, 18, 0},
+  {22, 36, 196, 36, 0}, {24, 24, 196, 24, 0}, {28, 24,  49, 24, 0}, {29,  8,  49,  8, 0}, {31, 40,  49, 40, 0}, {33, 40,  49, 40, 0},
+  {34,  8,  49,  8, 0}, {35,  8,  49,  8, 0}, {37, 40,  49, 40, 0}, {39, 40,  49, 40, 0}, {40,  8,  49,  8, 0}, {41,  8,  49,  8, 0},
+  {43, 24,  49, 24, 0}, {25, 24,  49, 24, 0}, {46, 48,  49, 48, 0}, {48, 40,  49, 40, 0}, {50, 40,  49, 40, 0}, {52, 32,  49, 32, 0},
+  { 0, 18,  49, 18, 0},
+};
+
+static const stv_node* node_at(const stv_network* net, int idx) {
+  const stv_node* node = net->input_node;
+  for (int i = 0; node && i < idx; ++i) node = (node->next == node) ? NULL : node->next;
+  return node;
+}
+
+YF_API ai_bool ai_platform_observer_node_info(ai_handle network, ai_observer_node* node_info) {
+  if (!own(network) || !node_info) return false;
+  const stv_node* node = node_info->c_idx < 31 ? node_at((const stv_network*)network, node_info->c_idx) : NULL;
+  if (!node) { yf_impl_fail_run(g_own, AI_ERROR_CODE_OUT_OF_RANGE, "observer: no such c-node index"); return false; }
+  node_info->type = node->type; node_info->id = node->id; node_info->unused = 0;
+  node_info->inner_tensors = NULL; node_info->tensors = node->tensors;
+  return true;
+}
+
+YF_API ai_bool ai_platform_observer_register(ai_handle network, ai_observer_node_cb cb, ai_handle cookie, ai_u32 flags) {
+  if (!own(network) || !cb) return false;
+  g_obs.cb = cb; g_obs.cookie = cookie; g_obs.flags = (flags & AI_OBSERVER_MASK_EVT) | AI_OBSERVER_REGISTERED; g_obs.ctx = NULL;
+  return true;
+}
+YF_API ai_bool ai_platform_observer_register_s(ai_handle network, ai_observer_exec_ctx* ctx) {
+  if (!ctx || !ai_platform_observer_register(network, ctx->on_node, ctx->cookie, ctx->flags)) return false;
+  g_obs.ctx = ctx; ctx->flags |= AI_OBSERVER_REGISTERED; ctx->c_idx = 0; ctx->n_nodes = 31; ctx->cur = NULL;
+  return true;
+}
+YF_API ai_bool ai_platform_observer_unregister(ai_handle network, ai_observer_node_cb cb, ai_handle cookie) {
+  if (!own(network) || !(g_obs.flags & AI_OBSERVER_REGISTERED) || g_obs.cb != cb || g_obs.cookie != cookie) return false;
+  if (g_obs.ctx) g_obs.ctx->flags &= ~(ai_u32)AI_OBSERVER_REGISTERED;
+  memset(&g_obs, 0, sizeof g_obs);
+  return true;
+}
+YF_API ai_bool ai_platform_observer_unregister_s(ai_handle network, ai_observer_exec_ctx* ctx) {
+  return ctx ? ai_platform_observer_unregister(network, ctx->on_node, ctx->cookie) : false;
+}
+
+static ai_i32 process_observed(ai_handle network, const ai_buffer* input, ai_buffer* output) {
+  if (!input || !input->data || input->n_batches < 1 || (output && !output->data))      /* the plain path latches the matching error */
+    return output ? yf_impl_run(g_own, input, output) : yf_impl_forward(g_own, input);
+  const stv_network* net = (const stv_network*)network;
+  const long ds = yf_impl_dump_bytes();
+  enum { CHUNK = 32 };
+  long off_of[31];
+  for (int i = 0; i < 31; ++i) {
+    off_of[i] = k_node_src[i].op ? yf_impl_dump_offset(k_node_src[i].op) : 0;
+    if (off_of[i] < 0) { yf_impl_fail_run(g_own, AI_ERROR_CODE_NETWORK, "observer: the debug build does not dump every node"); return 0; }
+  }
+  /* the caller's I/O arrays: the first node's input tensor and the last node's output tensor */
+  const stv_node* first = net->input_node;
+  const stv_node* last = node_at(net, 30);
+  if (!first || !last || !first->tensors || !last->tensors) { yf_impl_fail_run(g_own, AI_ERROR_CODE_NETWORK, "observer: no node list"); return 0; }
+  stv_array* in_arr = first->tensors->chain[0].tensor[0]->data;
+  stv_array* out_arr = last->tensors->chain[1].tensor[0]->data;
+  const stv_array in_keep = *in_arr, out_keep = *out_arr;
+  int8_t* heads = (int8_t*)malloc((size_t)CHUNK * AI_NETWORK_OUT_1_SIZE);
+  int8_t* dump = (int8_t*)malloc((size_t)CHUNK * (size_t)ds);
+  ai_i32 done = 0;
+  const long n = input->n_batches;
+  if (!heads || !dump) { yf_impl_fail_run(g_own, AI_ERROR_CODE_NETWORK, "observer: out of memory"); free(heads); free(dump); return 0; }
+  for (long base = 0; base < n; base += CHUNK) {
+    const long cnt = n - base < CHUNK ? n - base : CHUNK;
+    if (yf_impl_run_dump(g_own, input, output, base, cnt, heads, dump) == 0) goto out;      /* validates shapes / formats and latches */
+    for (long f = 0; f < cnt; ++f) {
+      in_arr->data = in_arr->data_start = (uint8_t*)input->data + (base + f) * AI_NETWORK_IN_1_SIZE;
+      out_arr->data = out_arr->data_start = output ? (uint8_t*)output->data + (base + f) * AI_NETWORK_OUT_1_SIZE : (uint8_t*)heads + f * AI_NETWORK_OUT_1_SIZE;
+      const stv_node* node = first;
+      for (int i = 0; i < 31 && node; ++i) {
+        ai_observer_node on;
+        on.c_idx = (ai_u16)i; on.type = node->type; on.id = node->id; on.unused = 0; on.inner_tensors = NULL; on.tensors = node->tensors;
+        const ai_u32 pos = (i == 0 ? AI_OBSERVER_FIRST_EVT : 0) | (i == 30 ? AI_OBSERVER_LAST_EVT : 0);
+        if (g_obs.ctx) { g_obs.ctx->c_idx = (ai_u16)i; g_obs.ctx->n_nodes = 31; g_obs.ctx->cur = (struct ai_node_s*)(uintptr_t)node; }
+        if (g_obs.flags & AI_OBSERVER_PRE_EVT) g_obs.cb(g_obs.cookie, AI_OBSERVER_PRE_EVT | pos, &on);
+        const yf_node_src* sv = &k_node_src[i];
+        const stv_array* dst_arr = node->tensors->chain[1].tensor[0]->data;
+        uint8_t* dst = dst_arr ? dst_arr->data : NULL;
+        if (!dst) { yf_impl_fail_run(g_own, AI_ERROR_CODE_INVALID_PTR, "observer: a node's output tensor has no address (no activation arrays bound)"); goto out; }
+        const int8_t* src = sv->op ? dump + f * ds + off_of[i] : heads + f * AI_NETWORK_OUT_1_SIZE;
+        if (sv->pix == sv->c) memcpy(dst, src, (size_t)sv->c * sv->p);
+        else for (int px = 0; px < sv->p; ++px) memcpy(dst + (size_t)px * sv->c, src + (size_t)px * sv->pix + sv->ch0, (size_t)sv->c);
+        if (g_obs.flags & AI_OBSERVER_POST_EVT) g_obs.cb(g_obs.cookie, AI_OBSERVER_POST_EVT | pos, &on);
+        node = (node->next == node) ? NULL : node->next;
+      }
+    }
+  }
+  done = (ai_i32)n;
+out:
+  *in_arr = in_keep; *out_arr = out_keep;
+  free(heads); free(dump);
+  return done;
+}
+
 YF_API ai_i32 ai_platform_network_process(ai_handle network, const ai_buffer* input, ai_buffer* output) {
   if (!own(network)) return 0;
+  if ((g_obs.flags & AI_OBSERVER_REGISTERED) && (g_obs.flags & (AI_OBSERVER_PRE_EVT | AI_OBSERVER_POST_EVT)) && g_obs.cb)
+    return process_observed(network, input, output);
   return output ? yf_impl_run(g_own, input, output) : yf_impl_forward(g_own, input);
 }
 

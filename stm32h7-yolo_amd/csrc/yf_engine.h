@@ -44,6 +44,10 @@ int  yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out
 /* 160x160 frames (int8 [n][160][160][3] -> [n][20][20][18]): layer-by-layer over an engine-owned HBM arena */
 int  yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n, void* stream);
 long yf_engine_dump_bytes(void);
+/* debug: dump build on n host frames; heads and the per-stage dump records come back to host memory (per-node observer) */
+int  yf_engine_run_host_dump(yf_engine* e, const void* h_in, void* h_out, void* h_dump, long n);
+/* byte offset of the tensor tflite op `op` produces inside a frame's dump record, -1 = not dumped */
+long yf_engine_dump_offset(int tflite_op);
 
 #ifdef __cplusplus
 }

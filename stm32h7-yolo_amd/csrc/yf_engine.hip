@@ -537,6 +537,45 @@ int yf_engine_run_host(yf_engine* e, const void* h_in, void* h_out, long n) {
   return YF_ENG_OK;
 }
 
+// Debug form of yf_engine_run_host for the per-node observer (platform_abi.c): the dump build of the configured shape on n host
+// frames; heads and the per-stage dump records (yf_engine_dump_bytes() per frame) come back to host memory.  Allocates per call.
+int yf_engine_run_host_dump(yf_engine* e, const void* h_in, void* h_out, void* h_dump, long n) {
+  if (!e || !h_in || !h_out || !h_dump || n <= 0) return YF_ENG_ERR_ARG;
+  if (!e->var_dump) { e->err = "no debug (dump) build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t ds = (size_t)yf::DumpOffsets::TOTAL;
+  char *d_i = nullptr, *d_o = nullptr, *d_d = nullptr;
+  int rc = YF_ENG_OK;
+  hipError_t h = hipMalloc((void**)&d_i, (size_t)n * 9408);
+  if (h == hipSuccess) h = hipMalloc((void**)&d_o, (size_t)n * 882);
+  if (h == hipSuccess) h = hipMalloc((void**)&d_d, (size_t)n * ds);
+  if (h == hipSuccess) h = hipMemcpyAsync(d_i, h_in, (size_t)n * 9408, hipMemcpyHostToDevice, e->own_stream);
+  if (h == hipSuccess) rc = launch(e, e->var_dump, d_i, d_o, d_d, n, e->own_stream);
+  if (h == hipSuccess && rc == YF_ENG_OK) h = hipMemcpyAsync(h_out, d_o, (size_t)n * 882, hipMemcpyDeviceToHost, e->own_stream);
+  if (h == hipSuccess && rc == YF_ENG_OK) h = hipMemcpyAsync(h_dump, d_d, (size_t)n * ds, hipMemcpyDeviceToHost, e->own_stream);
+  const hipError_t hs = hipStreamSynchronize(e->own_stream);
+  if (d_i) (void)hipFree(d_i);
+  if (d_o) (void)hipFree(d_o);
+  if (d_d) (void)hipFree(d_d);
+  if (rc != YF_ENG_OK) return rc;
+  if (h != hipSuccess || hs != hipSuccess) { e->err = std::string("observed run: ") + hipGetErrorString(h != hipSuccess ? h : hs); return YF_ENG_ERR_HIP; }
+  return YF_ENG_OK;
+}
+
+// byte offset of a dumped tensor inside a frame's dump record, by tflite op number (the op that produces it); -1 = not dumped
+long yf_engine_dump_offset(int tflite_op) {
+  typedef yf::DumpOffsets D;
+  switch (tflite_op) {
+    case 2: return D::T1; case 4: return D::T2; case 5: return D::T3; case 7: return D::T4; case 21: return D::Q21; case 11: return D::T6;
+    case 12: return D::T7; case 14: return D::T8; case 16: return D::T9; case 18: return D::T11; case 22: return D::T14; case 24: return D::T15;
+    case 45: return D::Q45; case 28: return D::T17; case 29: return D::T18; case 31: return D::T19; case 33: return D::T20; case 35: return D::T22;
+    case 37: return D::T23; case 39: return D::T24; case 41: return D::T26; case 46: return D::T30; case 48: return D::T31; case 50: return D::T32;
+    case 52: return D::T33; case 8: return D::P8; case 17: return D::C17; case 25: return D::P25; case 34: return D::C34; case 40: return D::C40;
+    case 43: return D::L43;
+    default: return -1;
+  }
+}
+
 int yf_engine_time_device(yf_engine* e, const void* d_in, void* d_out, long n, int iters, void* stream, float* ms_per_launch) {
   if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));

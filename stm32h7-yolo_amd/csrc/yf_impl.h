@@ -10,6 +10,11 @@ ai_i32    yf_impl_run(ai_handle network, const ai_buffer* input, ai_buffer* outp
 ai_i32    yf_impl_forward(ai_handle network, const ai_buffer* input);
 ai_bool   yf_impl_get_report(ai_handle network, ai_network_report* report);
 const uint8_t* yf_impl_resolve_weights(const ai_network_params* p, size_t* bytes, const ai_buffer** act);
+/* per-node observer support: debug build on frames [first, first + count) of input; heads + per-node dump records to host memory */
+ai_i32    yf_impl_run_dump(ai_handle network, const ai_buffer* input, const ai_buffer* output, long first, long count, int8_t* heads, int8_t* dump);
+long      yf_impl_dump_bytes(void);
+long      yf_impl_dump_offset(int tflite_op);
+void      yf_impl_fail_run(ai_handle network, unsigned code, const char* text);
 /* latch an initialisation failure (first error wins, text replaces the previous one) */
 void      yf_impl_fail_init(ai_handle network, unsigned code, const char* text);
 #endif

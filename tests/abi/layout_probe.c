@@ -8,6 +8,7 @@
 #include "yf_network.h"
 #else
 #include "ai_platform.h"
+#include "ai_platform_interface.h"      /* the per-node observer's datatypes (:684-731) */
 #endif
 int main(void) {
   printf("S8=0x%08x U8=0x%08x CONST=0x%08x\n", (unsigned)AI_BUFFER_FORMAT_S8, (unsigned)AI_BUFFER_FORMAT_U8, (unsigned)AI_BUFFER_FMT_FLAG_CONST);
@@ -27,5 +28,11 @@ int main(void) {
   printf("errors: %d %d %d %d %d %d %d | %d %d %d %d %d %d %d\n", AI_ERROR_NONE, AI_ERROR_INVALID_HANDLE, AI_ERROR_INVALID_STATE, AI_ERROR_INVALID_INPUT,
          AI_ERROR_INVALID_OUTPUT, AI_ERROR_INIT_FAILED, AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_NETWORK, AI_ERROR_CODE_NETWORK_WEIGHTS,
          AI_ERROR_CODE_NETWORK_ACTIVATIONS, AI_ERROR_CODE_INVALID_SIZE, AI_ERROR_CODE_INVALID_FORMAT, AI_ERROR_CODE_INVALID_BATCH, AI_ERROR_CODE_MISSED_INIT);
+  printf("ai_observer_node %zu: %zu %zu %zu %zu %zu\n", sizeof(ai_observer_node), offsetof(ai_observer_node, c_idx), offsetof(ai_observer_node, type),
+         offsetof(ai_observer_node, id), offsetof(ai_observer_node, inner_tensors), offsetof(ai_observer_node, tensors));
+  printf("ai_observer_exec_ctx %zu: %zu %zu %zu %zu %zu %zu\n", sizeof(ai_observer_exec_ctx), offsetof(ai_observer_exec_ctx, on_node), offsetof(ai_observer_exec_ctx, cookie),
+         offsetof(ai_observer_exec_ctx, flags), offsetof(ai_observer_exec_ctx, c_idx), offsetof(ai_observer_exec_ctx, n_nodes), offsetof(ai_observer_exec_ctx, cur));
+  printf("observer events: %d %d %d %d %d %d %d\n", AI_OBSERVER_INIT_EVT, AI_OBSERVER_PRE_EVT, AI_OBSERVER_POST_EVT, AI_OBSERVER_FIRST_EVT, AI_OBSERVER_LAST_EVT,
+         AI_OBSERVER_REGISTERED, AI_OBSERVER_MASK_EVT);
   return 0;
 }

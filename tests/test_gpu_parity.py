@@ -687,6 +687,40 @@ def test_reference_header_caller_binary(golden, tmp_path, binary):
         assert np.array_equal(np.fromfile(fout, np.int8).reshape(6, 7, 7, 18), golden["heads"])
 
 
+def test_per_node_observer_through_the_reference_headers(oracle, tmp_path):
+    """oracle/_ref/abi_observer_probe = the reference's generated network.c (unchanged) + a client of ai_platform_observer_* written against
+    the reference's headers (ai_platform_interface.h:684-731, 981-1024).  An observed ai_network_run calls the client before and after each
+    of the 31 c-nodes of every frame; in the POST call the node's output tensor -- read through the caller's own tensor objects -- must hold
+    what the matching TFLite op produces (node ids are the op numbers: network_generate_report.txt:290-480)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "abi_observer_probe")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/abi_observer_probe was not built (needs /root/reference at build time)")
+    from oracle.np_restatement import load_yfm
+    m = load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+    sizes = [int(np.prod(m["tensors"][o["out"]]["shape"][1:])) for o in m["ops"]]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    n = 3
+    x = np.fromfile(os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), np.int8).reshape(-1, 56, 56, 3)[:n]
+    fin, fout = str(tmp_path / "frames.bin"), str(tmp_path / "nodes.bin")
+    x.tofile(fin)
+    r = subprocess.run([exe, fin, str(n), fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ids = [2, 4, 5, 7, 11, 12, 14, 16, 17, 18, 20, 8, 22, 24, 28, 29, 31, 33, 34, 35, 37, 39, 40, 41, 43, 25, 46, 48, 50, 52, 53]
+    lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("node ")]
+    assert [int(t[3]) for t in lines] == ids and [int(t[1]) for t in lines] == list(range(31))
+    assert int(lines[0][9], 16) & 0x100 and int(lines[30][9], 16) & 0x200            # FIRST / LAST event flags
+    assert "info c_idx 12: id 22" in r.stdout and f"PRE {31 * n} POST {31 * n}" in r.stdout and "heads equal" in r.stdout and f"OK {n}" in r.stdout
+    head_ref, dump_ref = oracle.run(x, dump=True)
+    got = np.fromfile(fout, np.int8)
+    want = np.concatenate([dump_ref[f, offs[k]:offs[k] + sizes[k]] for f in range(n) for k in ids])
+    assert got.size == want.size
+    pos = 0
+    for f in range(n):
+        for k in ids:
+            assert np.array_equal(got[pos:pos + sizes[k]], dump_ref[f, offs[k]:offs[k] + sizes[k]]), f"frame {f}, node id {k}"
+            pos += sizes[k]
+
+
 def _rgb565_frames(golden):
     """112x112 big-endian RGB565 camera frames: random colours, and the golden 56x56 frames blown up 2x (each 2x2 block
     one colour, so the firmware's box average gives the frame back up to the 5/6/5 truncation)."""
