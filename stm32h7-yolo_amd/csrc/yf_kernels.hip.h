@@ -840,7 +840,6 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
   }
 }
 
-#ifndef YF_GENERIC
 // ================================================================================================ lean stages (round 3)
 // The 56x56 fused kernel's own forms of the dense and depthwise stages.  What changes against dense_stage / dw_mfma_stage
 // (which the 160x160 kernels keep using):
@@ -864,6 +863,12 @@ constexpr int ZERO = JT + JT_B, ZERO_B = 640;                 // zeros: the A fr
 constexpr int SLOT0 = ZERO + ZERO_B, SLOT_B = 2816;           // two ring slots for the constant blocks of consecutive const-stages
 // behind the ring slots: the halo tables (size depends on the kernel shape), then the frame arenas (pre_bytes)
 constexpr int slot(int cs) { return SLOT0 + (cs & 1) * SLOT_B; }
+// Where a kernel keeps the lean stages' LDS-resident pieces.  The 56x56 kernel: the regions above, constants through the two ring slots.
+// The 160x160 band kernels have their own layouts (constants RESIDENT for the kernel's lifetime, in LUT / add-table bytes they do not use).
+struct Lay56 {
+  static constexpr int ZERO = v2::ZERO, JT = v2::JT, JT_BYTES = v2::JT_B;
+  static constexpr int slot(int cs) { return v2::slot(cs); }
+};
 constexpr int max_block() { int m = 0; for (int i = 0; i < YF_N_CS; ++i) m = PLAN.vb_bytes[i] > m ? PLAN.vb_bytes[i] : m; return m; }
 static_assert(max_block() <= SLOT_B && SLOT0 % 16 == 0 && SLOT_B % 16 == 0, "a constant block fits a ring slot");
 
@@ -877,7 +882,7 @@ __device__ __forceinline__ v4u lds_v4u(uint32_t a) { return *(lds_v4u_ptr)a; }
 // LDS-DMA of const-stage CS's block into its ring slot: wave w moves bytes [1024 w, 1024 w + 1024) -- one wave-instruction of
 // 64 x 16 bytes, no registers.  The compiler does not see the transfer (inline assembly): whoever reads the slot does so behind
 // an explicit s_waitcnt vmcnt(0) + barrier (V2_SYNC in the kernel).  M0 carries the LDS destination and is restored.
-template <int CS>
+template <int CS, class LAY = Lay56>
 __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, int wave, int lane) {
   constexpr int BYTES = PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
   if (wave < NCHUNK) {
@@ -885,7 +890,7 @@ __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, in
     const int off = wave * 1024 + lane * 16;
     if (off < BYTES) {
       const uint8_t* src = tab + PLAN.vb_off[CS] + off;
-      const uint32_t dst = (uint32_t)(slot(CS) + wave * 1024);
+      const uint32_t dst = (uint32_t)(LAY::slot(CS) + wave * 1024);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -894,11 +899,11 @@ __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, in
 }
 
 // floor(p / W) for p < 2048 by one multiply and one shift (checked exhaustively at compile time)
-template <int W> struct DivW {
-  static constexpr uint32_t M = (65536 + W - 1) / W;
-  static constexpr bool ok() { for (uint32_t p = 0; p < 2048; ++p) if (((p * M) >> 16) != p / W) return false; return true; }
+template <int W, int SH = (W > 32 ? 20 : 16)> struct DivW {      // wider grids (the 160x160 bands: 80, 40 columns) need the longer reciprocal
+  static constexpr uint32_t M = ((1u << SH) + W - 1) / W;
+  static constexpr bool ok() { for (uint32_t p = 0; p < 2048; ++p) if (((p * M) >> SH) != p / W) return false; return true; }
   static_assert(ok(), "multiply-shift division is exact on [0, 2048)");
-  __device__ static __forceinline__ int div(int p) { return (int)(((uint32_t)p * M) >> 16); }
+  __device__ static __forceinline__ int div(int p) { return (int)(((uint32_t)p * M) >> SH); }
 };
 
 // residual-add context of the lean stages: the two 256-entry int32 tables sit in the stage's ring slot at LA / LA + 1024
@@ -938,14 +943,14 @@ __device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char
 // STASH_OFF >= 0 (debug builds, residual-add stages): the convolution's own requantised output of pixel p also goes to byte
 // STASH_OFF + p * STASH_S of the frame's arena (the per-node observer wants the tensor the fused add never materialises)
 template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB, int CS,
-          int STASH_OFF = -1, int STASH_S = 0, int STASH_LUT = -1>
+          int STASH_OFF = -1, int STASH_S = 0, int STASH_LUT = -1, class LAY = Lay56>
 YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const AddK ad, int wave, int lane) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
   constexpr int P = IN::P, TOT = F * P;
   constexpr bool FRAME_TILES = P <= 64;                       // one frame per tile (7x7 grid): no per-job index arithmetic
   constexpr int MT = FRAME_TILES ? F : (TOT + 63) / 64;
   constexpr int JOBS = NCH * MT, KROW = 16 * KS;
-  constexpr int SLOT = slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB, LA = PV + NP * (int)sizeof(yf_pass_v);
+  constexpr int SLOT = LAY::slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB, LA = PV + NP * (int)sizeof(yf_pass_v);
   static_assert(yf_cs_dense[CS] >= 0 && KROW == PLAN_KROW[yf_cs_dense[CS]] && NP == plan_passes(CS), "stage and constant block agree");
   static_assert((EPI == EPI_ADD) == (yf_cs_add[CS] >= 0), "residual-add tables travel with their stage");
   static_assert(OUT::P == P || EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "1x1 conv keeps the grid");
@@ -954,7 +959,7 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
   static_assert(IN::RS == IN::W && IN::PT == 0 && IN::PL == 0, "dense inputs are plain buffers");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
-  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + (c & 3) * KROW) : (uint32_t)ZERO;      // A fragments: row 4*pass + (c&3), or zeros
+  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + (c & 3) * KROW) : (uint32_t)LAY::ZERO;      // A fragments: row 4*pass + (c&3), or zeros
   const uint32_t a_step = a_on ? (uint32_t)(TPJ * 4 * KROW) : 0u;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
   // per-lane pixel offsets of the frame-per-tile form
@@ -1064,14 +1069,14 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
 }
 
 // ---- conv2d_1 (see conv1_stage), constants from ring slot CS
-template <int F, int NW, int CS, class IN = B_IN, class OUT = B_T1>
+template <int F, int NW, int CS, class IN = B_IN, class OUT = B_T1, class LAY = Lay56>
 YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, int wave, int lane) {
   constexpr int P = OUT::P, W1 = OUT::W, RSW = IN::RS, TOT = F * P;
   constexpr int MT = (TOT + 63) / 64;
-  constexpr int SLOT = slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB;
+  constexpr int SLOT = LAY::slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB;
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
-  const uint32_t a_addr = a_on ? (uint32_t)(SLOT + (c & 3) * YF_CONV1_KROW) : (uint32_t)ZERO;
+  const uint32_t a_addr = a_on ? (uint32_t)(SLOT + (c & 3) * YF_CONV1_KROW) : (uint32_t)LAY::ZERO;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
   v4i a[2][3];
   PassV pv[2];
@@ -1134,6 +1139,7 @@ struct DwGeo {
     return uint2{(uint32_t)(fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
   }
 };
+#if YF_H0 == 56
 // job tables of the five depthwise geometries (8 bytes per job of one channel group), laid out one after another
 template <int F, bool BATCH>
 struct JobTabs {
@@ -1147,6 +1153,7 @@ struct JobTabs {
   static constexpr int END = JT_DW32 + 8 * DwGeo<FT, 1, typename U::T19, typename U::T20>::JPG;
   static_assert(END <= JT_B, "job tables fit");
 };
+#endif
 // ---- halo fills from a table.  The halo pixels of a depthwise input (ring or top row + left column, every frame of the workgroup)
 // are a fixed list of LDS offsets: written once per workgroup as uint16 (offset / 4) tables, so that a fill is "thread i < N:
 // read entry i, store one pixel of zero points" -- two VALU instructions instead of ~20 of index arithmetic per dword.
@@ -1169,6 +1176,7 @@ struct HaloGeo {
     return (uint32_t)(f * B::FS + B::OFF + r * B::ROWB + c * B::S);
   }
 };
+#if YF_H0 == 56
 template <int F, bool BATCH>
 struct HaloTabs {
   typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
@@ -1199,23 +1207,24 @@ YF_STAGE_FN void fill_halo_t(char* frames, int zp, int tid) {
     }
   }
 }
+#endif
 
 // the job table of one stage geometry, written once per workgroup (kernel prologue)
-template <int F, int STRIDE, class IN, class OUT, int JTOFF>
+template <int F, int STRIDE, class IN, class OUT, int JTOFF, class LAY = Lay56>
 __device__ __forceinline__ void fill_jobtab(char* smem, int tid) {
   typedef DwGeo<F, STRIDE, IN, OUT> G;
-  static_assert(JTOFF % 8 == 0 && JTOFF + G::JPG * 8 <= JT_B, "job table in bounds");
-  if (tid < G::JPG) *reinterpret_cast<uint2*>(smem + JT + JTOFF + 8 * tid) = G::job(tid);
+  static_assert(JTOFF % 8 == 0 && JTOFF + G::JPG * 8 <= LAY::JT_BYTES, "job table in bounds");
+  if (tid < G::JPG) *reinterpret_cast<uint2*>(smem + LAY::JT + JTOFF + 8 * tid) = G::job(tid);
 }
 
-template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID, int CS, int JTOFF>
+template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID, int CS, int JTOFF, class LAY = Lay56>
 YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wave, int lane) {
   typedef DwGeo<F, STRIDE, IN, OUT> G;
   constexpr int W = G::W, FL = G::FL, JPG = G::JPG;
   constexpr int NG = (C + 3) / 4, JOBS = NG * JPG;
   constexpr int DROW = STRIDE * IN::ROWB;                      // input bytes between consecutive output rows
   constexpr int TS = IN::S, TR = IN::ROWB;                     // tap strides: +1 column, +1 row
-  constexpr int SLOT = slot(CS);
+  constexpr int SLOT = LAY::slot(CS);
   static_assert(yf_cs_dw[CS] >= 0 && NG == plan_passes(CS), "stage and constant block agree");
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
@@ -1223,7 +1232,7 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
   const char* lane_in = frames + fl * IN::FS + g * DROW + xl * STRIDE * IN::S;     // this lane's pixel: row oy0+g, col x0+xl
   char* lane_out = frames + fl * IN::FS + (g * W + xl) * OUT::S;
   const bool a_on = (c >> 2) == g;
-  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + 4 * (c & 3)) : (uint32_t)ZERO;   // masked weight dwords of channel c&3: +16*tap
+  const uint32_t a_lane = a_on ? (uint32_t)(SLOT + 4 * (c & 3)) : (uint32_t)LAY::ZERO;   // masked weight dwords of channel c&3: +16*tap
   const uint32_t a_step = a_on ? (uint32_t)YF_DWV_GROUP_BYTES : 0u;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
   int j, j1;
@@ -1242,7 +1251,7 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
     const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     const char* lin = lane_in + 4 * cg;
     char* lout = lane_out + 4 * cg;
-    auto entry = [&](int job) { return *(lds_u2_ptr)(uint32_t)(JT + JTOFF + 8 * min(job, JPG - 1)); };    // {src, dst} offsets of a job
+    auto entry = [&](int job) { return *(lds_u2_ptr)(uint32_t)(LAY::JT + JTOFF + 8 * min(job, JPG - 1)); };    // {src, dst} offsets of a job
     auto taps = [&](const v2u e, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
       const char* src = lin + e[0];
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
@@ -1322,6 +1331,7 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
   }
 }
 }  // namespace v2
+#ifndef YF_GENERIC
 
 // ------------------------------------------------------------------------------------------------ debug dump
 // Observer-style per-stage dump (reference observer API, ai_platform_interface.h:684-731): logical NHWC bytes.
@@ -2002,6 +2012,36 @@ __device__ __forceinline__ void pf_commit(const Prefetch<NT, CNT>& p, char* dst,
   for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) { const int i = tid + k * NT; if (i < n16) reinterpret_cast<v4u*>(dst)[i] = p.v[k]; }
 }
 
+// ---- lean stage forms in the band kernels (round 3) -----------------------------------------------------------------------
+// band_k1 and band_k23 use the 56x56 kernel's lean stage forms (namespace v2) with their constants RESIDENT: a workgroup runs many band
+// jobs with the same few stages, so the vector-side blocks of those stages (1.4 KB for band_k1, 8 KB for band_k23) are loaded once per
+// workgroup -- into bytes of the LUT / residual-add-table area [0, LB) that the kernel's own stages never index -- instead of fetched from
+// global memory behind every stage boundary of every job (1.5-2.5 k cycles each; the band jobs ran at half the 56x56 kernel's per-pixel rate).
+#ifndef YF_BAND_LEAN
+#define YF_BAND_LEAN 1
+#endif
+template <int CS0, int CS1, int BASE_, int ZERO_, int JT_, int JT_BYTES_>
+struct BandLay {
+  static constexpr int ZERO = ZERO_, JT = JT_, JT_BYTES = JT_BYTES_, FIRST = CS0, LAST = CS1, BASE = BASE_;
+  static constexpr int slot(int cs) { int off = BASE_; for (int i = CS0; i < cs; ++i) off += PLAN.vb_bytes[i]; return off; }
+  static constexpr int END = slot(CS1 + 1);
+};
+// after load_luts: zeros, then the blocks of const-stages FIRST .. LAST at their slots (16-byte vectors, every thread)
+template <class LAY, int NT>
+__device__ __forceinline__ void load_resident(char* smem, const uint8_t* __restrict__ tab, int tid) {
+  for (int i = tid; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + LAY::ZERO)[i] = uint4{0, 0, 0, 0};
+#pragma unroll
+  for (int cs = LAY::FIRST; cs <= LAY::LAST; ++cs)
+    for (int i = tid; i < PLAN.vb_bytes[cs] / 16; i += NT)
+      reinterpret_cast<uint4*>(smem + LAY::slot(cs))[i] = reinterpret_cast<const uint4*>(tab + PLAN.vb_off[cs])[i];
+}
+// band_k1 indexes LUTs 0-2 only ([0, 768)): blocks of conv2d_1 / 3 / 5 / 6 behind them, job table and zeros at the end of the area
+typedef BandLay<0, 3, 768, LB - v2::ZERO_B, LB - v2::ZERO_B - 768, 768> LayK1;
+// band_k23 indexes LUTs 3-8 ([768, 2304)) and no add table of the area (conv2d_17's block brings its own): zeros and job tables on
+// LUTs 0-2, the seven blocks of conv2d_10 .. conv2d_23 from 2304 on
+typedef BandLay<4, 10, 2304, 0, v2::ZERO_B, 768 - v2::ZERO_B> LayK23;
+static_assert(LayK1::END <= LayK1::JT && LayK1::ZERO + v2::ZERO_B <= LB && LayK23::END <= LB && v2::ZERO_B + LayK23::JT_BYTES <= 768, "resident constants fit the unused LUT / add-table bytes");
+
 // ---- K1 ----------------------------------------------------------------------------------------------------------------
 #ifndef YF_K1_BH
 #define YF_K1_BH 16
@@ -2032,6 +2072,11 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
   int vz = 0;
   asm volatile("" : "+v"(vz));
   load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+#if YF_BAND_LEAN
+  __syncthreads();                                                // the LUT area is written; its unused bytes now take the resident pieces
+  load_resident<LayK1, NT>(smem, tab, tid);
+  v2::fill_jobtab<1, 1, L1_T1, L1_T2, 0, LayK1>(smem, tid);
+#endif
   const AddK no_add = {};
   const uint32_t z_in = splat((int)uniform_u32(tab + offsetof(yf_table_index, in_zp)));
   const uint32_t z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
@@ -2076,7 +2121,11 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     if (tid < K1_NIN) *reinterpret_cast<uint32_t*>(frames + L1_IN::OFF + tid * RSW * 4 + 12) = z_in;        // halo column (dword 3)
     lds_barrier();
     if (job + gridDim.x < jobs) fetch(job + gridDim.x);
+#if YF_BAND_LEAN
+    v2::conv1_2_stage<F, NW, 0, L1_IN, L1_T1, LayK1>(frames, tab, wave, lane);
+#else
     conv1_stage<F, NW, L1_IN, L1_T1>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
+#endif
     fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
     fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
     lds_barrier();
@@ -2084,12 +2133,21 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * (G1 + 2) * 8, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
     if (a == 0 || a + K1_BH == G1) lds_barrier();
     YF_BAND_PRIO(2);
+#if YF_BAND_LEAN
+    v2::dw2_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4, 1, 0, LayK1>(frames, tab, wave, lane);
+    lds_barrier();
+    YF_BAND_PRIO(1);
+    v2::dense2_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3, 2, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
+    lds_barrier();
+    v2::dense2_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4, 3, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
+#else
     dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
     lds_barrier();
     YF_BAND_PRIO(1);
     dense_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3>(frames, nullptr, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4>(frames, nullptr, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
+#endif
     fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
     lds_barrier();
     YF_BAND_PRIO(0);
@@ -2318,6 +2376,13 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
                 (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15)), z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
+#if YF_BAND_LEAN
+  constexpr int JT_DW10 = 0, JT_DW15 = 8 * v2::DwGeo<1, 2, L23_T4_DW, L23_T6>::JPG;
+  __syncthreads();
+  load_resident<LayK23, NT>(smem, tab, tid);
+  v2::fill_jobtab<1, 2, L23_T4_DW, L23_T6, JT_DW10, LayK23>(smem, tid);
+  v2::fill_jobtab<1, 1, L23_T8, L23_T9, JT_DW15, LayK23>(smem, tid);
+#endif
   char* frames = smem;
   const long jobs = prm.n * K23_BANDS;
   Prefetch<NT, K23_NR * T4_ROW / 16> pre;
@@ -2366,11 +2431,19 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     }
     lds_barrier();                                                 // T6 (written next) aliases HB
     YF_BAND_PRIO(2);
+#if YF_BAND_LEAN
+    v2::dw2_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11, 4, JT_DW10, LayK23>(frames, tab, wave, lane);               // ten rows
+    lds_barrier();
+    v2::dense2_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7, 5, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
+    lds_barrier();
+    v2::dense2_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8, 6, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
+#else
     dw_mfma_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);      // ten rows
     lds_barrier();
     dense_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
+#endif
     fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
     fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
     lds_barrier();
@@ -2378,6 +2451,16 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
     if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
     YF_BAND_PRIO(1);
+#if YF_BAND_LEAN
+    v2::dw2_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16, 7, JT_DW15, LayK23>(frames, tab, wave, lane);
+    lds_barrier();
+    v2::dense2_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C, 8, -1, 0, -1, LayK23>(frames, nullptr, tab, addctx(YF_A_ADD18), wave, lane);
+    lds_barrier();
+    v2::dense2_stage<F, NW, 2, 1, 8, L23_T11, L23_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L23_T14, 9, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
+    lds_barrier();
+    YF_BAND_PRIO(0);
+    v2::dense2_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15, 10, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
+#else
     dw_mfma_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
     lds_barrier();
     dense_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
@@ -2386,6 +2469,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     lds_barrier();
     YF_BAND_PRIO(0);
     dense_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
+#endif
     fill_column<NT, T15_ROW, 24>(frames + L23_T15::OFF, 0, K23_BP, z_t15, tid);
     lds_barrier();
     store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L23_T15::OFF, K23_BP * T15_ROW, tid);
