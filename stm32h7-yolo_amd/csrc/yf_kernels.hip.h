@@ -882,9 +882,9 @@ __device__ __forceinline__ v4u lds_v4u(uint32_t a) { return *(lds_v4u_ptr)a; }
 // LDS-DMA of const-stage CS's block into its ring slot: wave w moves bytes [1024 w, 1024 w + 1024) -- one wave-instruction of
 // 64 x 16 bytes, no registers.  The compiler does not see the transfer (inline assembly): whoever reads the slot does so behind
 // an explicit s_waitcnt vmcnt(0) + barrier (V2_SYNC in the kernel).  M0 carries the LDS destination and is restored.
-template <int CS, class LAY = Lay56>
+template <int CS, class LAY = Lay56, int BYTES_ = -1>      // BYTES_: only the first BYTES_ bytes of the block (a residual-add stage whose add tables are resident elsewhere)
 __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, int wave, int lane) {
-  constexpr int BYTES = PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
+  constexpr int BYTES = BYTES_ >= 0 ? BYTES_ : PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
   if (wave < NCHUNK) {
     asm volatile("" : "+v"(lane));          // the source address is two instructions: recomputed here, not parked in (spilled) VGPRs for the whole kernel
     const int off = wave * 1024 + lane * 16;
@@ -943,14 +943,14 @@ __device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char
 // STASH_OFF >= 0 (debug builds, residual-add stages): the convolution's own requantised output of pixel p also goes to byte
 // STASH_OFF + p * STASH_S of the frame's arena (the per-node observer wants the tensor the fused add never materialises)
 template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB, int CS,
-          int STASH_OFF = -1, int STASH_S = 0, int STASH_LUT = -1, class LAY = Lay56>
+          int STASH_OFF = -1, int STASH_S = 0, int STASH_LUT = -1, class LAY = Lay56, int LA_ABS = -1>      // LA_ABS: the stage's add tables at an absolute LDS address instead of inside its block
 YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const AddK ad, int wave, int lane) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
   constexpr int P = IN::P, TOT = F * P;
   constexpr bool FRAME_TILES = P <= 64;                       // one frame per tile (7x7 grid): no per-job index arithmetic
   constexpr int MT = FRAME_TILES ? F : (TOT + 63) / 64;
   constexpr int JOBS = NCH * MT, KROW = 16 * KS;
-  constexpr int SLOT = LAY::slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB, LA = PV + NP * (int)sizeof(yf_pass_v);
+  constexpr int SLOT = LAY::slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB, LA = LA_ABS >= 0 ? LA_ABS : PV + NP * (int)sizeof(yf_pass_v);
   static_assert(yf_cs_dense[CS] >= 0 && KROW == PLAN_KROW[yf_cs_dense[CS]] && NP == plan_passes(CS), "stage and constant block agree");
   static_assert((EPI == EPI_ADD) == (yf_cs_add[CS] >= 0), "residual-add tables travel with their stage");
   static_assert(OUT::P == P || EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "1x1 conv keeps the grid");
@@ -2498,7 +2498,29 @@ typedef Buf<L4_T20::OFF,                          G3, K4_HALF, 32, G3, 0, 0> L4_
 typedef Buf<L4_T20::OFF + K4_HALF * G3 * 32,      G3, K4_HALF, 32, G3, 0, 0> L4_T17B; // rows HALF .. G3-1
 typedef Buf<L4_T20::OFF + G3 * G3 * 48,           G3, G3, 48, G3,     0, 0> L4_T30;
 typedef Buf<LB,                                   G3, G3, 32, G3,     0, 0> L4_T33;   // aliases T19 (dead after conv2d_49)
-constexpr int K4_LDS = L4_T30::OFF + G3 * G3 * 48;
+constexpr int K4_BUFS_END = L4_T30::OFF + G3 * G3 * 48;
+// lean stage forms in band_k4 (round 3): a frame's thirteen stages need 19 KB of constants -- not resident, but through TWO RING SLOTS in
+// LUT-area bytes the tail never indexes: even const-stages (largest: conv2d_47, 2240 B) on LUTs 0-8 [0, 2304), odd ones (largest: a
+// depthwise conv, 1760 B) on eltwise_18's add tables [4864, 6912).  conv2d_34 / 40 read their add tables from the resident area instead of
+// from their blocks (which would not fit).  Zeros and the three depthwise job tables sit behind the buffers.
+struct LayK4 {
+  static constexpr int ZERO = K4_BUFS_END, JT = K4_BUFS_END + v2::ZERO_B, JT_BYTES = 256;
+  static constexpr int slot(int cs) { return (cs & 1) ? YF_N_LUT * 256 : 0; }
+};
+constexpr bool k4_ring_ok() {
+  for (int cs = 11; cs <= 23; ++cs) {
+    const int b = PLAN.vb_bytes[cs] - (yf_cs_add[cs] >= 0 ? 2048 : 0);
+    if (b > ((cs & 1) ? 2048 : 2304)) return false;
+  }
+  return true;
+}
+static_assert(k4_ring_ok(), "every tail block (without its add tables) fits its ring slot");
+#if YF_BAND_LEAN
+constexpr int K4_LDS = K4_BUFS_END + v2::ZERO_B + LayK4::JT_BYTES;
+#else
+constexpr int K4_LDS = K4_BUFS_END;
+#endif
+static_assert(K4_LDS <= 81920, "two workgroups per CU");
 
 // pool_25 for output rows [oy0, oy0 + K4_HALF) from a T15 half whose first halo'd row is h0
 template <int NT>
@@ -2517,6 +2539,105 @@ YF_STAGE_FN void pool25_half(char* frames, int oy0, int h0, int tid) {
   }
 }
 
+#if YF_BAND_LEAN
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64, F = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t* __restrict__ tab = prm.tab;
+  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
+  const AddK no_add = {};
+  auto addctx = [&](int k) {
+    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
+    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
+                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
+                (int)uniform_u32(a + offsetof(yf_add, rso))};
+  };
+  // zeros and the depthwise job tables behind the buffers (the ring slots themselves are filled per stage)
+  constexpr int JT_A = 0, JT_B = JT_A + 8 * v2::DwGeo<1, 2, L4_T15H, L4_T17A>::JPG, JT_32 = JT_B + 8 * v2::DwGeo<1, 2, L4_T15H, L4_T17B>::JPG;
+  static_assert(JT_32 + 8 * v2::DwGeo<1, 1, L4_T19, L4_T20>::JPG <= LayK4::JT_BYTES, "job tables fit");
+  for (int i = tid; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + LayK4::ZERO)[i] = uint4{0, 0, 0, 0};
+  v2::fill_jobtab<1, 2, L4_T15H, L4_T17A, JT_A, LayK4>(smem, tid);
+  v2::fill_jobtab<1, 2, L4_T15H, L4_T17B, JT_B, LayK4>(smem, tid);
+  v2::fill_jobtab<1, 1, L4_T19, L4_T20, JT_32, LayK4>(smem, tid);
+  constexpr int LA35 = YF_N_LUT * 256 + YF_A_ADD35 * 2048, LA41 = YF_N_LUT * 256 + YF_A_ADD41 * 2048;      // add tables: resident with the LUTs
+  // a stage's constants arrive by LDS-DMA one stage ahead; the barrier that ends a stage waits for the transfer first
+#define K4_FETCH(CS) v2::fetch_consts<CS, LayK4, PLAN.vb_bytes[CS] - (yf_cs_add[CS] >= 0 ? 2048 : 0)>(tab, wave, lane)
+#define K4_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); } while (0)
+#define K4_DENSE(TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, AD, CS, LAABS) \
+  v2::dense2_stage<F, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS, -1, 0, -1, LayK4, LAABS>(frames, out_all, tab, AD, wave, lane)
+  char* frames = smem;
+  constexpr int N0 = K4_ROWS0 * T15_ROW / 16, N1 = K4_ROWS1 * T15_ROW / 16, H1 = 2 * K4_HALF;     // halves: vectors, first halo'd row of the second
+  Prefetch<NT, N0> pre;
+  long fr = blockIdx.x;
+  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N0, tid);
+  for (; fr < prm.n; fr += gridDim.x) {
+    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
+    const char* t15 = prm.arena + fr * (long)ARENA_BYTES + A_T15;
+    YF_BAND_PRIO(3);
+    lds_barrier();                                                                    // every wave has left the previous frame's head stage (ring slots, buffers)
+    K4_FETCH(11);
+    pf_commit(pre, frames + L4_T15H::OFF, N0, tid);                                   // halo'd rows 0 .. ROWS0-1
+    K4_SYNC();
+    pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
+    pool25_half<NT>(frames, 0, 0, tid);
+    v2::dw2_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28, 11, JT_A, LayK4>(frames, tab, wave, lane);
+    lds_barrier();
+    pf_commit(pre, frames + L4_T15H::OFF, N1, tid);                                   // halo'd rows H1 .. G2
+    lds_barrier();
+    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
+    K4_FETCH(12);
+    pool25_half<NT>(frames, K4_HALF, H1, tid);
+    v2::dw2_stage<F, NW, 2, L4_T15H, L4_T17B, 24, YF_L_LEAKY28, 11, JT_B, LayK4>(frames, tab, wave, lane);
+    K4_SYNC();
+    YF_BAND_PRIO(2);
+    K4_FETCH(13);
+    K4_DENSE(1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18, no_add, 12, -1);                              // conv2d_29
+    K4_SYNC();
+    K4_FETCH(14);
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
+    K4_DENSE(3, 1, 8, L4_T18, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, L4_T19, no_add, 13, -1);                   // conv2d_30
+    K4_SYNC();
+    K4_FETCH(15);
+    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33, 14, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_32
+    K4_SYNC();
+    YF_BAND_PRIO(1);
+    K4_FETCH(16);
+    K4_DENSE(1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18, addctx(YF_A_ADD35), 15, LA35);       // conv2d_34 + eltwise_35
+    K4_SYNC();
+    K4_FETCH(17);
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
+    K4_DENSE(3, 1, 8, L4_T22, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, L4_T19, no_add, 16, -1);                   // conv2d_36
+    K4_SYNC();
+    K4_FETCH(18);
+    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY39, 17, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_38
+    K4_SYNC();
+    K4_FETCH(19);
+    K4_DENSE(1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22, addctx(YF_A_ADD41), 18, LA41);       // conv2d_40 + eltwise_41
+    K4_SYNC();
+    YF_BAND_PRIO(0);
+    K4_FETCH(20);
+    K4_DENSE(2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30, no_add, 19, -1);                   // conv2d_42 -> concat_46
+    K4_SYNC();
+    K4_FETCH(21);
+    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
+    K4_DENSE(2, 3, 16, L4_T30, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, L4_T19, no_add, 20, -1);                  // conv2d_47
+    K4_SYNC();
+    K4_FETCH(22);
+    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY50, 21, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_49
+    K4_SYNC();
+    K4_FETCH(23);
+    K4_DENSE(2, 3, 16, L4_T20, L4_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, L4_T33, no_add, 22, -1);                  // conv2d_51
+    K4_SYNC();
+    K4_DENSE(1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33, no_add, 23, -1);                            // conv2d_53 -> head
+  }
+#undef K4_FETCH
+#undef K4_SYNC
+#undef K4_DENSE
+}
+#else
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2587,6 +2708,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
     dense_stage<F, NW, 1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
   }
 }
+#endif
 }  // namespace band
 #endif  // YF_GENERIC
 
