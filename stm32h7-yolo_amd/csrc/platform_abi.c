@@ -45,10 +45,13 @@ YF_API ai_error ai_platform_network_create(ai_handle* network, const ai_buffer* 
   return e;
 }
 
+static void observer_reset(void);
+
 YF_API ai_handle ai_platform_network_destroy(ai_handle network) {
   if (!own(network)) return network;
   yf_impl_destroy(g_own);
   g_own = AI_HANDLE_NULL; g_tag = NULL;
+  observer_reset();                              /* a registration does not outlive its network */
   return AI_HANDLE_NULL;
 }
 
@@ -234,6 +237,7 @@ YF_API ai_bool ai_platform_network_post_init(ai_handle network) { return own(net
  * pre-activation values of convolutions with a fused LeakyReLU exist only as LUT indices inside the kernel).  Values follow TFLite's
  * arithmetic, like everything this library computes (ST's LUT rounding differs by 1 LSB in places). */
 static struct { ai_observer_node_cb cb; ai_handle cookie; ai_u32 flags; ai_observer_exec_ctx* ctx; } g_obs;
+static void observer_reset(void) { memset(&g_obs, 0, sizeof g_obs); }
 
 /* node i of k_graph: its output tensor = C channels of P pixels; source = the dump tensor of tflite op `op` (PIX channels per pixel
  * there, this node's channels start at CH0), or the heads for the last node (op 0) */
