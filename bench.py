@@ -392,6 +392,13 @@ def main():
                                      "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
         else:
             line["roofline_valu"] = {"bound": "valu-issue", "achieved": None, "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instr/s", "frac": None, "source": why}
+        # ... and the LDS pipe, which co-limits with the VALU port (DESIGN.md "What binds"): LDS-array cycles of the profile (SQ_LDS_IDX_ACTIVE,
+        # summed over the CUs) against one LDS pipe per CU for the kernel's duration
+        if prof and prof.get("SQ_LDS_IDX_ACTIVE"):
+            cu_cycles = (SIMDS // 4) * CLOCK_HZ * (kernel_ms * 1e-3)
+            line["roofline_lds"] = {"bound": "lds-pipe", "achieved": prof["SQ_LDS_IDX_ACTIVE"], "peak": round(cu_cycles), "unit": "LDS-array cycles per launch",
+                                    "frac": round(prof["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4), "bank_conflict_cycles": prof.get("SQ_LDS_BANK_CONFLICT"),
+                                    "lds_instructions_per_launch": prof.get("SQ_INSTS_LDS"), "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
         if world == 1:
             cb, mism = cpu_baseline(x, heads)
             line["cpu_baseline"] = cb
