@@ -225,6 +225,29 @@ __device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u 
   for (int j = 0; j < 4; ++j) idx[j] = min(max(t[j] >> rs[j], 0), 255);     // v_ashrrev, v_med3_i32
 #endif
 }
+// the same for TWO channels: the last pass of a layer with 4k + 2 output channels (6, 18) carries two padding channels whose
+// requantisation, LUT reads and packing would be thrown away
+template <bool AFTER_MFMA>
+__device__ __forceinline__ void requant2(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[2]) {
+  v2u d0, d1;
+  unsigned long cy0, cy1;
+  int t0, t1;
+  if constexpr (AFTER_MFMA)
+    asm("s_nop 7\n\ts_nop 1\n\tv_mad_u64_u32 %0, %2, %4, %6, %8\n\tv_mad_u64_u32 %1, %3, %5, %7, %9"
+        : "=&v"(d0), "=&v"(d1), "=&s"(cy0), "=&s"(cy1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]));
+  else
+    asm("v_mad_u64_u32 %0, %2, %4, %6, %8\n\tv_mad_u64_u32 %1, %3, %5, %7, %9"
+        : "=&v"(d0), "=&v"(d1), "=&s"(cy0), "=&s"(cy1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]));
+  asm("v_addc_co_u32_e64 %0, vcc, %2, %4, %6\n\tv_addc_co_u32_e64 %1, vcc, %3, %5, %7"
+      : "=&v"(t0), "=&v"(t1) : "v"(zr[0]), "v"(zr[1]), "v"(d0[1]), "v"(d1[1]), "s"(cy0), "s"(cy1) : "vcc");
+  idx[0] = min(max(t0 >> rs[0], 0), 255);
+  idx[1] = min(max(t1 >> rs[1], 0), 255);
+}
+__device__ __forceinline__ uint32_t join2(uint32_t b0, uint32_t b1) {
+  uint32_t v;
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(v) : "v"(b1), "v"(b0));
+  return v;
+}
 constexpr int ACC0 = YF_ACC_OFFSET;            // MFMA C operand: the inline constant 2.0 (no v_mov)
 // A register with no particular content and no instruction behind it: the k-slots of an MFMA B operand whose weights are
 // zero may hold anything (integer arithmetic: 0 * x = 0), so they are not cleared.
@@ -939,6 +962,30 @@ __device__ __forceinline__ void epilogue2(char* dstpix, const char* addpix, char
   }
 }
 
+// the last pass of a layer with 4k + 2 output channels: two channels requantised, looked up and packed (the two padding bytes of the
+// pixel's dword are written as zero; nothing reads them with a non-zero weight)
+template <int EPI, int LUT_ID, int LA>
+__device__ __forceinline__ void epilogue2_half(char* dstpix, const char* addpix, int chq, const int (&idx)[2], const AddK& ad) {
+  static_assert(EPI == EPI_LUT || EPI == EPI_RAW || EPI == EPI_ADD, "half passes: LUT, raw and residual-add epilogues");
+  if constexpr (EPI == EPI_LUT) {
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]));
+  } else if constexpr (EPI == EPI_RAW) {
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(idx[0], idx[1]) ^ 0x8080u;
+  } else {
+    typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
+    const uint32_t o = lds_u32(addpix + chq) ^ 0x80808080u;
+    v4i sum = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      sum[j] = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255)) + *(lds_i32_ptr)(uint32_t)(LA + 1024 + 4 * idx[j]);
+    int r[2];
+    requant2<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro},
+                    v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
+    *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(r[0], r[1]) ^ 0x8080u;
+  }
+}
+#define YF_HALF_PASS (!YF_TOGGLED(512))          /* the experimental build with mask bit 512 requantises the padding channels too (A/B) */
+
 // ---- dense 1x1 (lane-private MFMA, see dense_stage), constants from ring slot CS
 // STASH_OFF >= 0 (debug builds, residual-add stages): the convolution's own requantised output of pixel p also goes to byte
 // STASH_OFF + p * STASH_S of the frame's arena (the per-node observer wants the tensor the fused add never materialises)
@@ -1058,9 +1105,20 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
           v4i acc = {ACC0, ACC0, ACC0, ACC0};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
-          int idx[4];
-          requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
-          epilogue2<EPI, LUT_ID, LA, STASH_LUT>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad, stashpix);
+          // the layer's last pass holds two padding channels when COUT = 4k + 2: requantise the two real ones only
+          constexpr bool HALF_L = YF_HALF_PASS && COUT % 4 == 2 && STASH_OFF < 0 && (EPI == EPI_LUT || EPI == EPI_RAW || EPI == EPI_ADD);
+          const bool half = HALF_L && t == (NP - 1) % TPJ && ps == NP - 1;      // uniform; t is a constant of the unrolled pass
+          if (half) {
+            if constexpr (HALF_L) {
+              int idx2[2];
+              requant2<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx2);
+              epilogue2_half<EPI, LUT_ID, LA>(dstpix, addpix, t * 4, idx2, ad);
+            }
+          } else {
+            int idx[4];
+            requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
+            epilogue2<EPI, LUT_ID, LA, STASH_LUT>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad, stashpix);
+          }
         }
       }
     }
@@ -1266,9 +1324,15 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
       return __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
     };
     auto finish = [&](const v4i& acc, char* dst) {
-      int idx[4];
-      requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
-      *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+      if (YF_HALF_PASS && C % 4 == 2 && cg == NG - 1) {          // uniform: the last channel group of an 18-channel layer has two real channels
+        int idx2[2];
+        requant2<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx2);
+        *reinterpret_cast<uint32_t*>(dst) = join2(lutb<LUT_ID>(idx2[0]), lutb<LUT_ID>(idx2[1]));
+      } else {
+        int idx[4];
+        requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
+        *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+      }
     };
     const int n = min(left, JPG - jj);
     int i = 0;
