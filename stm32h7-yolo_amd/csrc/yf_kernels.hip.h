@@ -444,25 +444,36 @@ YF_STAGE_FN void stage_input(char* frames, const int8_t* __restrict__ in, long f
   const int lastf = __builtin_amdgcn_readfirstlane((int)(rest < (long)(F - 1) ? rest : (long)(F - 1)));
   const int8_t* base = in + first_frame * IN_FRAME_BYTES;
   static_assert(RSW == B_IN::W + 4 && B_IN::S == 4, "dst = OFF + 16 * (r + y + RSW/4 + 1) relies on rows of W + 4 dwords");
+  // ALL loads first (items past the end re-read the last one), then the shuffles and stores.  One loop with an early exit made every
+  // iteration wait for its own load before the next one was issued -- three to four global-load latencies in a row per group (-1.1 %).
+  uint32_t ld[ITERS][3];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int i = tid + it * NT;
-    if (ITERS * NT != TOTAL && i >= TOTAL) break;
+    const int i = min(tid + it * NT, TOTAL - 1);
     int f = 0;
 #pragma unroll
     for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
     const int r = i - f * PER_FRAME;
-    const uint32_t off = (uint32_t)(min(f, lastf) * PER_FRAME + r) * 12u;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(base + off);
-    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
-    uint4 px;
-    px.x = d0;
-    px.y = funnel(d1, d0, 24);
-    px.z = funnel(d2, d1, 16);
-    px.w = d2 >> 8;
-    const int y = (int)((uint32_t)r / (uint32_t)WQ);
-    // halo'd dword index ((y + 1) * RSW + 4 * xq + 4) with xq = r - y * WQ, RSW = 4 * WQ + 4  ->  4 * (r + y) + RSW + 4
-    *reinterpret_cast<uint4*>(frames + f * B_IN::FS + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(base + (uint32_t)(min(f, lastf) * PER_FRAME + r) * 12u);
+    ld[it][0] = src[0]; ld[it][1] = src[1]; ld[it][2] = src[2];
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int i = tid + it * NT;
+    if (ITERS * NT == TOTAL || i < TOTAL) {
+      int f = 0;
+#pragma unroll
+      for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
+      const int r = i - f * PER_FRAME;
+      uint4 px;
+      px.x = ld[it][0];
+      px.y = funnel(ld[it][1], ld[it][0], 24);
+      px.z = funnel(ld[it][2], ld[it][1], 16);
+      px.w = ld[it][2] >> 8;
+      const int y = (int)((uint32_t)r / (uint32_t)WQ);
+      // halo'd dword index ((y + 1) * RSW + 4 * xq + 4) with xq = r - y * WQ, RSW = 4 * WQ + 4  ->  4 * (r + y) + RSW + 4
+      *reinterpret_cast<uint4*>(frames + f * B_IN::FS + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
+    }
   }
 }
 
