@@ -2127,10 +2127,14 @@ static_assert(LayK1::END <= LayK1::JT && LayK1::ZERO + v2::ZERO_B <= LB && LayK2
 constexpr int K1_BH = YF_K1_BH, K1_BANDS = G1 / K1_BH, K1_NIN = 2 * K1_BH + 5, K1_NT1 = K1_BH + 2;
 static_assert(G1 % K1_BH == 0, "band height must divide the grid");
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int K1_IN_BYTES = K1_NIN * (G0 + 4) * 4, K1_T1_BYTES = K1_NT1 * (G1 + 2) * 8;
+#ifndef YF_BAND_SKEW
+#define YF_BAND_SKEW 4              /* bytes of row skew in the band kernels' depthwise inputs with 8- / 40-byte pixels (see Buf::SK) */
+#endif
+constexpr int K1_T1_ROW = (G1 + 2) * 8 + YF_BAND_SKEW;
+constexpr int K1_IN_BYTES = K1_NIN * (G0 + 4) * 4, K1_T1_BYTES = (K1_NT1 * K1_T1_ROW + 15) & ~15;
 constexpr int K1_R0 = cmax(K1_IN_BYTES + K1_T1_BYTES, K1_BH * T4_ROW);                       // IN + T1, later T4
 typedef Buf<LB,                                  G0, K1_NIN - 1, 4, G0 + 4, 1, 4> L1_IN;    // RGBX rows: local row l = global halo'd row 2(a-1)+l
-typedef Buf<L1_IN::OFF + K1_IN_BYTES,            G1, K1_NT1,     8, G1 + 2, 0, 1> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
+typedef Buf<L1_IN::OFF + K1_IN_BYTES,            G1, K1_NT1,     8, G1 + 2, 0, 1, BUF_FS, YF_BAND_SKEW> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
 typedef Buf<LB + K1_R0,                          G1, K1_BH,      8, G1,     0, 0> L1_T2;
 typedef Buf<L1_T2::OFF + K1_BH * G1 * 8,         G1, K1_BH,      4, G1,     0, 0> L1_T3;
 typedef Buf<LB,                                  G1, K1_BH,     20, T4_RS,  0, 1> L1_T4;    // left halo column; aliases IN and T1 (dead after conv2d_3)
@@ -2201,11 +2205,11 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
 #else
     conv1_stage<F, NW, L1_IN, L1_T1>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
 #endif
-    fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
-    fill_column<NT, (G1 + 2) * 8, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
+    fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
+    fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
     lds_barrier();
     if (a == 0) fill_dwords<NT>(frames + L1_T1::OFF, z_t1, (G1 + 2) * 8, tid);                               // T1 row -1 = halo
-    if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * (G1 + 2) * 8, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
+    if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * K1_T1_ROW, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
     if (a == 0 || a + K1_BH == G1) lds_barrier();
     YF_BAND_PRIO(2);
 #if YF_BAND_LEAN
@@ -2423,13 +2427,18 @@ typedef Buf<K23_RH,                              G2, K23_NR, 20, G2,     0, 0> L
 typedef Buf<K23_RH,                              G2, K23_NM, 32, G2,     0, 0> L23_T6;       // aliases HB (dead after the vertical pool pass)
 typedef Buf<K23_RH + K23_NM * G2 * 32,           G2, K23_NM,  8, G2,     0, 0> L23_T7;       // rows p0-1 .. p0+8
 typedef Buf<L23_T7::OFF + G2 * 8,                G2, K23_BP,  8, G2,     0, 0> L23_T7C;      // rows p0 .. p0+7: the residual input of eltwise_18
-typedef Buf<K23_RA,                              G2, K23_NM, 36, T8_RS,  0, 1> L23_T8;       // aliases T4 (dead after conv2d_10); halo'd rows p0 .. p0+9
-typedef Buf<K23_RA + K23_NM * T8_ROW,            G2, K23_BP, 48, G2,     0, 0> L23_T9;
+// T8's 1584-byte rows put the second row of a 32-lane tap read 12 banks behind the first (4 of 16 lanes collide); 16 bytes of skew make it 16
+#ifndef YF_K23_T8_SKEW
+#define YF_K23_T8_SKEW 16
+#endif
+constexpr int K23_T8_ROW = T8_ROW + YF_K23_T8_SKEW;
+typedef Buf<K23_RA,                              G2, K23_NM, 36, T8_RS,  0, 1, BUF_FS, YF_K23_T8_SKEW> L23_T8;       // aliases T4 (dead after conv2d_10); halo'd rows p0 .. p0+9
+typedef Buf<K23_RA + K23_NM * K23_T8_ROW,        G2, K23_BP, 48, G2,     0, 0> L23_T9;
 typedef Buf<K23_RH,                              G2, K23_BP,  8, G2,     0, 0> L23_T11;      // aliases T6 (dead after conv2d_12)
 typedef Buf<K23_R14,                             G2, K23_BP, 48, G2,     0, 0> L23_T14;
 typedef Buf<K23_RH + K23_BP * G2 * 8,            G2, K23_BP, 24, T15_RS, 0, 1> L23_T15;      // behind T11, on T6's old bytes
 constexpr int K23_LDS = K23_R14 + K23_BP * G2 * 48;
-static_assert(K23_NM * G2 * 32 + K23_NM * G2 * 8 <= K23_RH_BYTES && K23_NM * T8_ROW + K23_BP * G2 * 48 <= K23_RA_BYTES, "aliases fit");
+static_assert(K23_NM * G2 * 32 + K23_NM * G2 * 8 <= K23_RH_BYTES && K23_NM * K23_T8_ROW + K23_BP * G2 * 48 <= K23_RA_BYTES, "aliases fit");
 static_assert(K23_BP * G2 * 8 + K23_BP * T15_ROW <= K23_NM * G2 * 32, "T11 | T15 fit T6's bytes (T7 behind them stays alive until conv2d_17)");
 static_assert(K23_LDS <= 81920 && K23_RA % 16 == 0 && K23_RH % 16 == 0 && K23_R14 % 16 == 0 && L23_T9::OFF % 16 == 0 && L23_T15::OFF % 16 == 0, "two workgroups per CU, aligned buffers");
 
@@ -2519,11 +2528,11 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     lds_barrier();
     dense_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
 #endif
-    fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
-    fill_column<NT, T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
+    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
+    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
     lds_barrier();
     if (p0 == 0) fill_dwords<NT>(frames + L23_T8::OFF, z_t8, T8_ROW, tid);                                       // T8 row -1 = halo
-    if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
+    if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * K23_T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
     if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
     YF_BAND_PRIO(1);
 #if YF_BAND_LEAN
@@ -2560,11 +2569,12 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
 // slot (dead before conv2d_32 writes it), T33 on T19's.
 constexpr int K4_HALF = G3 / 2, K4_ROWS0 = 2 * K4_HALF + 2, K4_ROWS1 = (G2 + 1) - 2 * K4_HALF;      // T15 halo'd rows of the halves
 static_assert(G3 % 2 == 0 && K4_HALF >= 4 && K4_ROWS1 <= K4_ROWS0, "two halves of output rows");
-constexpr int K4_R1 = (G3 + 2) * (G3 + 2) * 40 + 3 * G3 * G3 * 8;                                     // T19 | T18 | T22 | T26
+constexpr int K4_T19_BYTES = ((G3 + 2) * ((G3 + 2) * 40 + YF_BAND_SKEW) + 15) & ~15;
+constexpr int K4_R1 = K4_T19_BYTES + 3 * G3 * G3 * 8;                                     // T19 | T18 | T22 | T26
 static_assert(K4_ROWS0 * T15_ROW <= K4_R1, "a T15 half fits the slot of T19 and the small tensors");
 typedef Buf<LB,                                   G2, K4_ROWS0,   24, T15_RS, 0, 1> L4_T15H;  // halo'd rows of one half (halo'd row 0 at OFF)
-typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1> L4_T19;
-typedef Buf<LB + (G3 + 2) * (G3 + 2) * 40,        G3, G3,  8, G3,     0, 0> L4_T18;
+typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1, BUF_FS, YF_BAND_SKEW> L4_T19;
+typedef Buf<LB + K4_T19_BYTES,                    G3, G3,  8, G3,     0, 0> L4_T18;
 typedef Buf<L4_T18::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T22;
 typedef Buf<L4_T22::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T26;
 typedef Buf<LB + K4_R1,                           G3, G3, 48, G3,     0, 0> L4_T20;
