@@ -141,6 +141,18 @@ struct Tables { ConvT conv[24]; };
 
 __device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret_cast<const uint32_t*>(p); }
 __device__ __forceinline__ uint2 lds_u64(const char* p) { return *reinterpret_cast<const uint2*>(p); }
+// A depthwise tap: eight bytes read as ONE ds_read_b64.  Left to itself the compiler merges two taps into a ds_read2_b64, and that
+// instruction runs at HALF the pipe rate of two ds_read_b64 (tools/probe/lds_banks.hip: 8.0 cycles against 2 x 2.2 -- the 256-byte-per-
+// clock mode of 64-bit reads is lost); a volatile access is not merged and still gets its s_waitcnt from the compiler.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 lds_tap64(const char* p) {
+#if YF16_WHATIF & 8
+  return *reinterpret_cast<const uint2*>(p);
+#else
+  const v2u_t v = *(const volatile __attribute__((address_space(3))) v2u_t*)p;      // explicit LDS address space: a volatile access through a generic pointer becomes a flat load
+  return uint2{v.x, v.y};
+#endif
+}
 typedef const __attribute__((address_space(4))) v4f* cv4f_ptr;
 __device__ __forceinline__ v4f uniform_f4(const void* p) { return *(cv4f_ptr)(uintptr_t)p; }
 
@@ -295,7 +307,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, column ox*STRIDE+kx; depthwise: channel group cg
       const char* src = lds + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) tp[k] = lds_u64(src + (k / 3) * TR + (k % 3) * TS);
+      for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
       dst = lds + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg;
     };
     auto kstep = [&](const uint2 (&tp)[9], int ks, v4f acc) {
@@ -464,7 +476,7 @@ __device__ __forceinline__ void pool25_cols(char* lds0, int item) {
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds)
+struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; int stop; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds); stop: leave a frame behind barrier `stop` (YF16_STAGEPMC builds, 0 = never)
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params prm) {
@@ -489,6 +501,11 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
+#elif defined(YF16_STAGEPMC)
+  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop, every frame is abandoned behind its barrier number `stop`;
+  // the differences between consecutive launches are the stages' instruction counts.  Results are wrong by construction.
+  int stage_no = 0;
+#define SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (++stage_no == prm.stop) continue; }
 #else
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
@@ -518,6 +535,9 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     float* out_frame = prm.out + fr * (7 * 7 * 18);
 #ifdef YF16_BARPROF
     bar_no = 0; prof_on = prof_out != nullptr && fr == (long)blockIdx.x + gridDim.x;
+#endif
+#ifdef YF16_STAGEPMC
+    stage_no = 0;
 #endif
     SYNC();                                                       // previous frame's buffers are dead
     FETCH(0);
@@ -760,7 +780,10 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
   if (((uintptr_t)d_in & 3) != 0) { c->err = "fp16 input must be 4-byte aligned"; return -2; }
   HIPCHK(c, hipSetDevice(c->device));
   yf16::Params prm;
-  prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab; prm.prof = nullptr;
+  prm.in = (const yf16::half_t*)d_in; prm.out = (float*)d_out; prm.n = n; prm.tab = c->d_tab; prm.prof = nullptr; prm.stop = 0;
+#ifdef YF16_STAGEPMC
+  if (getenv("YF16_STOP_STAGE")) prm.stop = atoi(getenv("YF16_STOP_STAGE"));
+#endif
   HIPCHK(c, c->park.get((hipStream_t)stream, c->park_region, &prm.scratch));
   long grid = (long)c->cus * 2;                              // two 76 KB workgroups per CU, persistent over the frames
   if (grid > n) grid = n;
