@@ -42,11 +42,17 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // Buf: OFF byte offset, logical W x H, S bytes per pixel (fp16 channels, padded), RS pixels per row incl. halo, PT/PL halo
 // rows / columns in front of logical pixel (0,0).  Halos hold 0 (the ONNX graph pads with zeros).  Buffers alias by lifetime.
 // FS: bytes between consecutive frames of a stage (only the 7x7 tail runs on two frames: tail batching, see the kernel).
-template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = 0>
+// SK: extra bytes per row (row pitch ROWB = RS * S + SK).  A depthwise tap read (ds_read_b64, 64 banks) puts the 16 lanes of a tile row on
+// the banks 4k and 4k+1 when the pixel is 16 or 80 bytes; with a row pitch that is a multiple of 4 dwords the next tile row lands on the
+// same banks.  Eight bytes of skew move it to 4k+2 / 4k+3 (T1, T8, T19: the inputs of conv2d_3, conv2d_15 and conv2d_32 / 38 / 49).
+#ifndef YF16_ROW_SKEW
+#define YF16_ROW_SKEW 8
+#endif
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = 0, int SK_ = 0>
 struct Buf {
-  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_;
-  static constexpr int P = W_ * H_;
-  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + ((y + PT_) * RS_ + (x + PL_)) * S_; }
+  static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_, SK = SK_;
+  static constexpr int P = W_ * H_, ROWB = RS_ * S_ + SK_;
+  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + (y + PT_) * ROWB + (x + PL_) * S_; }
   __device__ static __forceinline__ int at_p(int p) {
     if constexpr (RS_ == W_ && PT_ == 0 && PL_ == 0) return OFF_ + p * S_;
     else { const int y = p / W_; return at(y, p - y * W_); }
@@ -54,62 +60,69 @@ struct Buf {
 };
 //              OFF    W   H   S  RS PT PL
 typedef Buf<     0, 56, 56,  8, 57, 1, 1> B_IN;    // RGBX fp16, top/left halo (3x3 stride 2, pad 1)
-typedef Buf< 26000, 28, 28, 16, 30, 1, 1> B_T1;    // conv1 out, 8 ch, halo ring
-typedef Buf< 40400, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch
+typedef Buf< 26000, 28, 28, 16, 30, 1, 1, 0, YF16_ROW_SKEW> B_T1;    // conv1 out, 8 ch, halo ring; 30 rows of 488 bytes
+typedef Buf< 40640, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch
 typedef Buf<     0, 28, 28, 16, 28, 0, 0> B_T3;    // c5 out, 4 ch in an 8-channel pixel (upper half zero)
 typedef Buf< 12544, 28, 28, 40, 29, 1, 1> B_T4;    // c6 out, 18 ch (stride 20), top/left halo for dw10
 typedef Buf< 46184, 14, 28, 36, 14, 0, 0> B_HB;    // pool_8 horizontal pass, 18 ch
 typedef Buf< 60304, 14, 14, 80, 14, 0, 0> B_T14;   // concat: pool [0,18) | conv [20,38) (8-byte aligned start), stride 40; 16-byte aligned pixels (conv2d_23 reads them with ds_read_b128)
 typedef Buf<     0, 14, 14, 48, 14, 0, 0> B_T6;    // dw10 out, 18 ch (stride 24)
 typedef Buf<  9408, 14, 14, 16, 14, 0, 0> B_T7;    // c12 out, 6 ch
-typedef Buf< 12544, 14, 14, 80, 16, 1, 1> B_T8;    // c13 out, 36 ch, halo ring
-typedef Buf< 33024, 14, 14, 80, 14, 0, 0> B_T9;    // dw15 out
-typedef Buf< 48704, 14, 14, 16, 14, 0, 0> B_T11;   // c17 + add out, 6 ch
-typedef Buf<     0, 14, 14, 48, 15, 1, 1> B_T15;   // c23 out, 24 ch, top/left halo
-typedef Buf< 10800,  7,  7, 96,  7, 0, 0> B_T30;   // concat: pool [0,24) | conv [24,48)
-typedef Buf< 15504,  7,  7, 48,  7, 0, 0> B_T17;   // dw27 out, 24 ch
-typedef Buf< 17856,  7,  7, 16,  7, 0, 0> B_T18;   // c29 out, 8 ch
-typedef Buf< 18640,  7,  7, 80,  9, 1, 1> B_T19;   // c30 / c36 / c47 out, 40 ch, halo ring
-typedef Buf< 25120,  7,  7, 80,  7, 0, 0> B_T20;   // dw32 / dw38 / dw49 out
-typedef Buf< 29040,  7,  7, 16,  7, 0, 0> B_T22;   // c34 + add out
-typedef Buf< 29824,  7,  7, 16,  7, 0, 0> B_T26;   // c40 + add out
-typedef Buf< 30608,  7,  7, 64,  7, 0, 0> B_T33;   // c51 out, 32 ch
+typedef Buf< 12544, 14, 14, 80, 16, 1, 1, 0, YF16_ROW_SKEW> B_T8;    // c13 out, 36 ch, halo ring; 16 rows of 1288 bytes
+typedef Buf< 33152, 14, 14, 80, 14, 0, 0> B_T9;    // dw15 out
+typedef Buf< 48832, 14, 14, 16, 14, 0, 0> B_T11;   // c17 + add out, 6 ch
+// Pixel strides of the tail: 96 bytes (concat_46's 48 channels) and 64 bytes (conv2d_51's 32) put the lanes of a ds_read_b128 / ds_write_b64
+// on every second / fourth group of banks (tools/probe/lds_banks.hip: 8.0 / 16.0 cycles per read instead of 4.1, 32 per store instead of 6);
+// 112 and 80 bytes are conflict-free.  T15's stride-2 tap reads (96 bytes between lanes) halve their conflicts with the row skew.
+typedef Buf<     0, 14, 14, 48, 15, 1, 1, 0, YF16_ROW_SKEW> B_T15;   // c23 out, 24 ch, top/left halo; 15 rows of 728 bytes
+typedef Buf< 10928,  7,  7, 112, 7, 0, 0> B_T30;   // concat: pool [0,24) | conv [24,48), 16 bytes of padding
+typedef Buf< 16416,  7,  7, 48,  7, 0, 0> B_T17;   // dw27 out, 24 ch
+typedef Buf< 18768,  7,  7, 16,  7, 0, 0> B_T18;   // c29 out, 8 ch
+typedef Buf< 19552,  7,  7, 80,  9, 1, 1, 0, YF16_ROW_SKEW> B_T19;   // c30 / c36 / c47 out, 40 ch, halo ring; 9 rows of 728 bytes
+typedef Buf< 26112,  7,  7, 80,  7, 0, 0> B_T20;   // dw32 / dw38 / dw49 out
+typedef Buf< 30032,  7,  7, 16,  7, 0, 0> B_T22;   // c34 + add out
+typedef Buf< 30816,  7,  7, 16,  7, 0, 0> B_T26;   // c40 + add out
+typedef Buf< 31600,  7,  7, 80,  7, 0, 0> B_T33;   // c51 out, 32 ch in an 80-byte pixel
 constexpr int LDS_BYTES = 76032;                    // end of B_T14, rounded up to 64
 // The 7x7 tail works on one 33.7 KB SET per frame (the offsets of B_T15 .. B_T33 above); two sets fit the arena, the second
 // one FS = LDS_BYTES / 2 behind the first.
-constexpr int TAIL_FS = LDS_BYTES / 2, TAIL_T15_BYTES = 15 * 15 * 48;
+constexpr int TAIL_FS = LDS_BYTES / 2, TAIL_T15_BYTES = (15 * B_T15::ROWB + 15) & ~15;
 struct TB {
-  typedef Buf<     0, 14, 14, 48, 15, 1, 1, TAIL_FS> T15;
-  typedef Buf< 10800,  7,  7, 96,  7, 0, 0, TAIL_FS> T30;
-  typedef Buf< 15504,  7,  7, 48,  7, 0, 0, TAIL_FS> T17;
-  typedef Buf< 17856,  7,  7, 16,  7, 0, 0, TAIL_FS> T18;
-  typedef Buf< 18640,  7,  7, 80,  9, 1, 1, TAIL_FS> T19;
-  typedef Buf< 25120,  7,  7, 80,  7, 0, 0, TAIL_FS> T20;
-  typedef Buf< 29040,  7,  7, 16,  7, 0, 0, TAIL_FS> T22;
-  typedef Buf< 29824,  7,  7, 16,  7, 0, 0, TAIL_FS> T26;
-  typedef Buf< 30608,  7,  7, 64,  7, 0, 0, TAIL_FS> T33;
+  typedef Buf<B_T15::OFF, 14, 14, 48, 15, 1, 1, TAIL_FS, YF16_ROW_SKEW> T15;
+  typedef Buf<B_T30::OFF,  7,  7, 112, 7, 0, 0, TAIL_FS> T30;
+  typedef Buf<B_T17::OFF,  7,  7, 48,  7, 0, 0, TAIL_FS> T17;
+  typedef Buf<B_T18::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T18;
+  typedef Buf<B_T19::OFF,  7,  7, 80,  9, 1, 1, TAIL_FS, YF16_ROW_SKEW> T19;
+  typedef Buf<B_T20::OFF,  7,  7, 80,  7, 0, 0, TAIL_FS> T20;
+  typedef Buf<B_T22::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T22;
+  typedef Buf<B_T26::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T26;
+  typedef Buf<B_T33::OFF,  7,  7, 80,  7, 0, 0, TAIL_FS> T33;
 };
-static_assert(30608 + 7 * 7 * 64 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0, "a tail set fits half the arena");
+static_assert(TB::T33::OFF + 7 * 7 * 80 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0 && TAIL_T15_BYTES <= B_T30::OFF, "a tail set fits half the arena");
+static_assert(B_T19::OFF + 9 * B_T19::ROWB <= B_T20::OFF && B_T20::OFF + 49 * 80 <= B_T22::OFF && B_T22::OFF + 49 * 16 <= B_T26::OFF && B_T26::OFF + 49 * 16 <= B_T33::OFF &&
+              B_T30::OFF + 49 * 112 <= B_T17::OFF && B_T17::OFF + 49 * 48 <= B_T18::OFF && B_T18::OFF + 49 * 16 <= B_T19::OFF && B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF, "skewed buffers do not run into their neighbours");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
-static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * 30 * 16 <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
+static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROWB <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
 
 // ---- weight ring.  A conv's A-operand rows come from LDS, not from global memory: stage k's first act is ONE LDS-DMA of stage
 // k+1's rows (global_load_lds_dwordx4: 64 x 16 bytes per wave-instruction, no registers), so that the next stage's waves read
 // their fragments with ds_read_b128 (~100 cycles) instead of waiting 1.5-2.5 k cycles for a global load behind every barrier
 // and every channel-group switch (what-if without those loads: -9 % kernel time at one frame per workgroup).  Blocks k and k+1
 // are the only ones alive together, so even blocks grow up from the bottom of a 5.9 KB region behind the arena and odd blocks
-// down from its top; conv2d_47's 3.8 KB (next to dw49's 3.2 KB) sits in the bytes of tail set 0 that no tail buffer uses.
+// down from its top; conv2d_47's 3.8 KB (next to dw49's 3.2 KB) sits in T20's dead bytes of tail set 0 (woff below).
 constexpr int WBYTES[24] = {640, 640, 64, 320, 1600, 384, 576, 2880, 640, 320, 1920, 1920, 384, 640, 3200, 640, 640, 3200, 640, 384, 3840, 3200, 2560, 1280};
 constexpr int RING0 = LDS_BYTES, LDS_TOTAL = 81920, RING_BYTES = LDS_TOTAL - LDS_BYTES;
-constexpr int TAIL_SET_END = 30608 + 7 * 7 * 64;
-constexpr int woff(int k) { return k == 20 ? TAIL_SET_END : (k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]); }
+constexpr int TAIL_SET_END = TB::T33::OFF + 7 * 7 * 80;
+// conv2d_47's block (the largest, next to dw49's 3.2 KB) does not fit the ring: it sits in the bytes of T20 of tail set 0, which are dead from conv2d_40's
+// barrier (last reader of dw38's output) until conv2d_49 writes them again -- exactly the two stages (conv2d_42: fetch, conv2d_47: use) the block lives
+constexpr int woff(int k) { return k == 20 ? B_T20::OFF : (k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]); }
 constexpr bool ring_ok() {
   for (int k = 0; k + 1 < 24; ++k) {
     if (WBYTES[k] % 16 != 0) return false;
     if (k == 20 || k + 1 == 20) continue;
     if (WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
   }
-  return WBYTES[20] <= TAIL_FS - TAIL_SET_END && TAIL_SET_END % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
+  return WBYTES[20] <= 49 * 80 && B_T20::OFF % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
 }
 static_assert(ring_ok(), "adjacent weight blocks fit the ring side by side");
 // LDS-DMA of conv K's rows into its place in the ring: wave w moves bytes [1024 w, 1024 w + 1024).  The compiler does not see
@@ -277,7 +290,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
   constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4;
   constexpr int NG = (C + 3) / 4;                                  // output-channel groups of 4
   constexpr int JPG = NRB * NSEG, JOBS = NG * JPG;
-  constexpr int DROW = STRIDE * IN::RS * IN::S, TS = IN::S, TR = IN::RS * IN::S;
+  constexpr int DROW = STRIDE * IN::ROWB, TS = IN::S, TR = IN::ROWB;
   const int g = lane >> 4, c = lane & 15;
   const int fl = (FL == 2) ? (c >> 3) : 0;
   const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);
@@ -305,7 +318,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, column ox*STRIDE+kx; depthwise: channel group cg
-      const char* src = lds + IN::OFF + ((oy0 * STRIDE) * IN::RS + x0 * STRIDE) * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
+      const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
 #pragma unroll
       for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
       dst = lds + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg;
@@ -358,12 +371,14 @@ __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
 #if YF16_WHATIF & 2
   return;
 #endif
-  constexpr int S = B::S, WR = B::RS, HR = B::H + B::PT + (RING ? 1 : 0);
-  constexpr int G = (S % 16 == 0 && B::OFF % 16 == 0) ? 16 : 8, PG = S / G;       // granule bytes, granules per pixel
-  static_assert(S % G == 0 && B::OFF % G == 0 && (F == 1 || B::FS % G == 0), "granules");
-  constexpr int NA = RING ? (WR + 1) * PG : WR * PG;                  // first run
-  constexpr int NB = RING ? (HR - 3) * 2 * PG : (HR - 1) * PG;        // middle runs (two pixels / one pixel each)
-  constexpr int NC = RING ? (WR + 1) * PG : 0;                        // last run
+  constexpr int S = B::S, WR = B::RS, HR = B::H + B::PT + (RING ? 1 : 0), SK = B::SK, ROWB = B::ROWB;
+  constexpr int G = (S % 16 == 0 && B::OFF % 16 == 0 && SK % 16 == 0) ? 16 : 8, PG = S / G, SG = SK / G;       // granule bytes, granules per pixel / per row skew
+  static_assert(S % G == 0 && B::OFF % G == 0 && SK % G == 0 && (F == 1 || B::FS % G == 0), "granules");
+  // the skew bytes between a row's last pixel and the next row's first one are unused: a run that crosses a row boundary clears them too
+  constexpr int NA = RING ? (WR + 1) * PG + SG : WR * PG;             // first run
+  constexpr int RUN = RING ? 2 * PG + SG : PG;                        // middle runs (two pixels / one pixel each)
+  constexpr int NB = RING ? (HR - 3) * RUN : (HR - 1) * RUN;
+  constexpr int NC = RING ? (WR + 1) * PG + SG : 0;                   // last run
   constexpr int N1 = NA + NB + NC;
   for (int i = tid; i < F * N1; i += NT) {
     const int f = (F == 1) ? 0 : (i >= N1 ? 1 : 0);
@@ -372,10 +387,9 @@ __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
     if (k < NA) off = k * G;
     else if (k < NA + NB) {
       const int j = k - NA;
-      constexpr int RUN = RING ? 2 * PG : PG;
       const int r = j / RUN, g = j - r * RUN;                         // compile-time divisor
-      off = RING ? ((r + 2) * WR - 1) * S + g * G : (r + 1) * WR * S + g * G;
-    } else off = ((HR - 1) * WR - 1) * S + (k - NA - NB) * G;
+      off = RING ? (r + 1) * ROWB + (WR - 1) * S + g * G : (r + 1) * ROWB + g * G;
+    } else off = (HR - 2) * ROWB + (WR - 1) * S + (k - NA - NB) * G;
     char* dst = lds0 + f * B::FS + B::OFF + off;
     if constexpr (G == 16) *reinterpret_cast<uint4*>(dst) = uint4{0u, 0u, 0u, 0u};
     else *reinterpret_cast<uint2*>(dst) = uint2{0u, 0u};
@@ -458,7 +472,7 @@ __device__ __forceinline__ void pool25_cols(char* lds0, int item) {
   const int f = t / 7, ox = t - 7 * f;
   char* lds = lds0 + f * T15::FS;
   const char* base = lds + T15::at(0, 0) + 4 * d;
-  constexpr int S = T15::S, ROW = T15::RS * T15::S;
+  constexpr int S = T15::S, ROW = T15::ROWB;
   const int c0 = max(2 * ox - 1, 0) * S, c1 = 2 * ox * S, c2 = c1 + S, c3 = min(2 * ox + 2, 13) * S;
   auto hrow = [&](int r) {
     const char* p = base + r * ROW;
