@@ -524,13 +524,24 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
 #define FETCH(K) fetch_w<K>(tab, conv(K).w_off, wave, lane)
+  // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
+  // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
+#if defined(YF16_BARPROF) || defined(YF16_STAGEPMC) || (YF16_WHATIF & 16)
+#define SYNC_KEEP_PREFETCH() SYNC()
+#else
+  static_assert((56 * 28 + NW * 64 - 1) / (NW * 64) == 4, "the wait count below is the number of prefetch load instructions");
+#define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads(); } while (0)
+#endif
   // The next frame's input (12 bytes per item, IN_ITERS items per thread) is loaded into registers while a long stage of the current
   // frame runs -- conv2d_23 when the frame only parks its T15, conv2d_51 when it runs the tail -- instead of behind the barrier of the
   // staging stage, where the HBM latency was the stage's whole time (2.9 k cycles in the stage timeline).
   constexpr int IN_ITERS = (56 * 28 + NT - 1) / NT;
   uint32_t pin[IN_ITERS][3];
+  // ALWAYS IN_ITERS load instructions (a frame index past the batch re-reads the last frame): the barrier behind the stage that issues
+  // them waits with vmcnt(IN_ITERS) -- for everything older than these loads, i.e. for the weight DMA, but not for the HBM latency of the
+  // prefetch itself (SYNC_KEEP_PREFETCH below; vector-memory loads return in order)
   auto prefetch_in = [&](long frame) {
-    if (frame >= prm.n) return;
+    frame = frame < prm.n ? frame : prm.n - 1;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(prm.in + frame * (56 * 56 * 3));
 #pragma unroll
     for (int k = 0; k < IN_ITERS; ++k) {
@@ -611,7 +622,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     if (parks) prefetch_in(fr + gridDim.x);
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
-    SYNC();
+    if (parks) SYNC_KEEP_PREFETCH(); else SYNC();
     // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
     // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
     // the halo) in a per-workgroup HBM scratch and skips the tail; the second fetches it into tail set 1 (half the arena
@@ -673,10 +684,11 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     FETCH(23);
     prefetch_in(fr + gridDim.x);
     dense_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
-    SYNC();
+    SYNC_KEEP_PREFETCH();
     dense_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
   }
 #undef SYNC
+#undef SYNC_KEEP_PREFETCH
 #undef FETCH
 }
 
