@@ -30,6 +30,9 @@
 #ifndef YF16_WHATIF
 #define YF16_WHATIF 0      /* timing-only what-if builds (wrong results): 1 no weight loads, 2 no halo fills, 4 tap loads fenced before the MFMAs */
 #endif
+#ifndef YF16_TPJ_SET
+#define YF16_TPJ_SET 1       /* 0: the round-2 passes-per-job of the small-grid 1x1 layers (A/B) */
+#endif
 namespace yf16 {
 
 typedef _Float16 half_t;
@@ -616,7 +619,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     dense_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7>(lds, nullptr, tab, conv(8), wave, lane);     // conv2d_17 + eltwise_18
     SYNC();
     FETCH(10);
-    dense_stage<9, NW, 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
+    dense_stage<9, NW, YF16_TPJ_SET ? 3 : 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
     FETCH(11);
     if (parks) prefetch_in(fr + gridDim.x);
@@ -655,7 +658,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     SYNC();
     FETCH(14);
     fill_halo<TB::T19, true, NT, 2>(lds, tid);
-    dense_stage<13, NW, 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
+    dense_stage<13, NW, YF16_TPJ_SET ? 3 : 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
     SYNC();
     FETCH(15);
     conv3x3_stage<14, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(14), wave, lane);          // conv2d_32 (dw)
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     dense_stage<15, NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, 2>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
     SYNC();
     FETCH(17);
-    dense_stage<16, NW, 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
+    dense_stage<16, NW, YF16_TPJ_SET ? 3 : 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
     SYNC();
     FETCH(18);
     conv3x3_stage<17, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(17), wave, lane);          // conv2d_38 (dw)
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     dense_stage<18, NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, 2>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
     SYNC();
     FETCH(20);
-    dense_stage<19, NW, 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
+    dense_stage<19, NW, YF16_TPJ_SET ? 2 : 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
     SYNC();
     FETCH(21);
     dense_stage<20, NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
