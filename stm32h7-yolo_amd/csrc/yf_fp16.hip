@@ -101,7 +101,7 @@ struct TB {
   typedef Buf<B_T26::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T26;
   typedef Buf<B_T33::OFF,  7,  7, 80,  7, 0, 0, TAIL_FS> T33;
 };
-static_assert(TB::T33::OFF + 7 * 7 * 80 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0 && TAIL_T15_BYTES <= B_T30::OFF, "a tail set fits half the arena");
+static_assert(TAIL_FS >= B_T9::OFF && TAIL_FS + TAIL_T15_BYTES <= B_T14::OFF && TB::T33::OFF + 7 * 7 * 80 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0 && TAIL_T15_BYTES <= B_T30::OFF, "a tail set fits half the arena");
 static_assert(B_T19::OFF + 9 * B_T19::ROWB <= B_T20::OFF && B_T20::OFF + 49 * 80 <= B_T22::OFF && B_T22::OFF + 49 * 16 <= B_T26::OFF && B_T26::OFF + 49 * 16 <= B_T33::OFF &&
               B_T30::OFF + 49 * 112 <= B_T17::OFF && B_T17::OFF + 49 * 48 <= B_T18::OFF && B_T18::OFF + 49 * 16 <= B_T19::OFF && B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF, "skewed buffers do not run into their neighbours");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
@@ -152,6 +152,21 @@ enum { EPI_ACT = 0, EPI_LINEAR = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 //   dense 1x1 (and conv1): rows [cout_pad4][KS*8] f16                   (KS k-steps of 8 input channels / 2 taps)
 //   depthwise: per 4-channel group [5 k-steps][4 rows][8] f16           (row j: w[tap 2ks][j] at slot j, w[tap 2ks+1][j] at slot 4+j)
 //   bias [cout_pad4] f32 behind the rows (16-byte aligned)
+// LDS-DMA of a parked T15 (TAIL_T15_BYTES at src) into tail set 1: wave w moves the 1 KB chunks w, w + NW, ...
+template <int NW>
+__device__ __forceinline__ void fetch_park(const char* __restrict__ src, int wave, int lane) {
+  constexpr int NCHUNK = (TAIL_T15_BYTES + 1023) / 1024;
+  for (int j = wave; j < NCHUNK; j += NW) {
+    const int off = j * 1024 + lane * 16;
+    if (off < TAIL_T15_BYTES) {
+      const char* p = src + off;
+      const uint32_t dst = (uint32_t)(TAIL_FS + j * 1024);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+    }
+  }
+}
 struct ConvT { uint32_t w_off, b_off; };
 struct Tables { ConvT conv[24]; };
 
@@ -623,6 +638,9 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     SYNC();
     FETCH(11);
     if (parks) prefetch_in(fr + gridDim.x);
+    // a pair-closing frame fetches its partner's parked T15 into tail set 1 NOW, by LDS-DMA behind conv2d_23 (the set's bytes -- T9 / T11's --
+    // are dead since conv2d_19; the plain barrier behind this stage waits for it): as a copy loop behind the stage it was 1.6 k cycles of HBM latency
+    else if (parked >= 0) fetch_park<NW>(prm.scratch + (long)blockIdx.x * TAIL_T15_BYTES, wave, lane);
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
     if (parks) SYNC_KEEP_PREFETCH(); else SYNC();
@@ -639,11 +657,9 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
       continue;
     }
     float* out_frame1 = nullptr;
-    if (parked >= 0) {
-      for (int i = tid; i < PV; i += NT) reinterpret_cast<uint4*>(lds + TAIL_FS)[i] = park[i];
+    if (parked >= 0) {                          // its T15 is already in tail set 1 (fetch_park above)
       out_frame1 = prm.out + parked * (7 * 7 * 18);
       parked = -1;
-      SYNC();
     }
     FETCH(12);
     {   // pool_25 -> concat_46[0,24) on the first waves (by columns), conv2d_27 (dw, stride 2) on the others: both only read T15

@@ -12,7 +12,7 @@ N = 4096
 # barrier-delimited stages in launch order (stop = 1 ... 27, then the full kernel) and their conv outputs per frame
 STAGES = [("arena clear + top barrier", 0), ("input staging + halo fills", 0), ("conv2d_1", 6272), ("conv2d_3 (dw)", 6272), ("conv2d_5", 3136),
           ("conv2d_6", 14112), ("pool_8 h", 0), ("pool_8 v + conv2d_10 (dw)", 3528), ("conv2d_12", 1176), ("conv2d_13", 7056),
-          ("conv2d_15 (dw)", 7056), ("conv2d_17+add", 1176), ("conv2d_19", 3528), ("conv2d_23 (+ parking)", 4704), ("fetch of the parked T15", 0),
+          ("conv2d_15 (dw)", 7056), ("conv2d_17+add", 1176), ("conv2d_19", 3528), ("conv2d_23 (+ parking / fetch of the parked T15)", 4704),
           ("pool_25 + conv2d_27 (dw)", 1176), ("conv2d_29", 392), ("conv2d_30", 1960), ("conv2d_32 (dw)", 1960), ("conv2d_34+add", 392),
           ("conv2d_36", 1960), ("conv2d_38 (dw)", 1960), ("conv2d_40+add", 392), ("conv2d_42", 1176), ("conv2d_47", 1960), ("conv2d_49 (dw)", 1960),
           ("conv2d_51", 1568), ("conv2d_53 (head) + stores", 882)]

@@ -27,7 +27,7 @@ body = np.zeros_like(arrive); body[:, :, 1:] = arrive[:, :, 1:] - leave[:, :, :-
 wait = leave - arrive
 span = leave[:, :, -1] - leave[:, :, 0]
 names = ["top of loop", "input staging + halo fills", "conv2d_1", "conv2d_3 (dw)", "conv2d_5", "conv2d_6", "pool_8 h", "pool_8 v + conv2d_10 (dw)",
-         "conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23", "fetch of the parked T15",
+         "conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23",
          "pool_25 + conv2d_27 (dw) [2 frames]", "conv2d_29 [2]", "conv2d_30 [2]", "conv2d_32 (dw) [2]", "conv2d_34+add [2]", "conv2d_36 [2]",
          "conv2d_38 (dw) [2]", "conv2d_40+add [2]", "conv2d_42 [2]", "conv2d_47 [2]", "conv2d_49 (dw) [2]", "conv2d_51 [2]"]
 print(f"{wgs} workgroups x {nw} waves, {nb} barriers in a pair-closing frame; cycles from its first to its last barrier: mean {span.mean():.0f} "
