@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     else if (parked >= 0) fetch_park<NW>(prm.scratch + (long)blockIdx.x * TAIL_T15_BYTES, wave, lane);
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
-    if (parks) SYNC_KEEP_PREFETCH(); else SYNC();
+    if (parks) { SYNC_KEEP_PREFETCH(); } else { SYNC(); }
     // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
     // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
     // the halo) in a per-workgroup HBM scratch and skips the tail; the second fetches it into tail set 1 (half the arena
