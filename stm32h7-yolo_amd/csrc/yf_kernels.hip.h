@@ -1840,6 +1840,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(25);
     YF_FETCH(23, W_t, L_t);
+    // the decode's two look-up tables (2 KB) -> the first bytes of the frame arenas, dead since conv2d_47 (T15 / T30 of set 0), two stages ahead of
+    // the decode: the barrier behind this stage waits for the transfer, the one behind conv2d_53 would do so on the critical path
+    if (BATCH && prm.dets != nullptr && W_t < 2) {
+      int dl = L_t;
+      asm volatile("" : "+v"(dl));
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(W_t == 0 ? yfdec::d_sig_bits : yfdec::d_exp_bits) + 16 * dl;
+      const uint32_t dst = (uint32_t)(PRE + OUT_ALL_BYTES + 1024 * W_t);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
     YF_DENSE(FT, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33, YF_D_C51, no_add, W_t, L_t, 22);   // conv2d_51
     YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
     YF_STAGE_END()
@@ -1859,17 +1870,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       YF_SYNC();
       // heads: 882 bytes per frame from its set -> HBM, 2-byte granules; the boxes of set w are decoded by wave w meanwhile
       constexpr int H16 = OUT_FRAME_BYTES / 2;
-      for (int i = tid_t; i < FT * H16; i += NT) {
-        const int f = i / H16, k = i - f * H16;
-        const long id = frame_of(f);
-        if (id >= 0) reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES)[k] = *reinterpret_cast<const uint16_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF + 2 * k);
+      // with a decode the first FT waves decode (one frame each) while the other waves copy the heads; without one every wave copies
+      const bool split = prm.dets != nullptr && FT < NW;
+      const int c0 = split ? tid_t - FT * 64 : tid_t, cstep = split ? NT - FT * 64 : NT;
+      if (!split || W_t >= FT) {
+        for (int i = c0; i < FT * H16; i += cstep) {
+          const int f = i / H16, k = i - f * H16;
+          const long id = frame_of(f);
+          if (id >= 0) reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES)[k] = *reinterpret_cast<const uint16_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF + 2 * k);
+        }
       }
       for (int f = W_t; f < FT; f += NW) {
         const long id = frame_of(f);
         if (prm.dets != nullptr && id >= 0) {
           int dl = L_t;
           asm volatile("" : "+v"(dl));
-          yfdec::decode_frame(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap);
+          yfdec::decode_frame_lds(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap,
+                                  (uint32_t)(PRE + OUT_ALL_BYTES));
         }
       }
     }

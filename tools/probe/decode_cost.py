@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""What the fused box decode costs: network-only launches against network + decode launches, interleaved, events around 50 launches,
+   eight rotating input batches (HBM-resident inputs as in bench.py).  DEV TOOL."""
+import importlib, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+yf = importlib.import_module("stm32h7-yolo_amd")
+n, cap = 4096, 4
+net = yf.Network().init()
+if len(sys.argv) > 1 and sys.argv[1] == "exp": net.configure(202, 8)      # the experimental namespace of a library built with YF_EXP_MASK
+rng = np.random.default_rng(5)
+ins = [torch.from_numpy(rng.integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)).cuda() for _ in range(8)]
+d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+d_dets = torch.zeros((n * cap * 28,), dtype=torch.uint8, device="cuda"); d_cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+def run(decode, k):
+    x = ins[k % 8]
+    if decode: net.run_decode_device(x.data_ptr(), d_out.data_ptr(), n, d_dets.data_ptr(), d_cnt.data_ptr(), cap)
+    else: net.run_device(x.data_ptr(), d_out.data_ptr(), n)
+for k in range(400): run(k & 1, k)
+torch.cuda.synchronize()
+res = {0: [], 1: []}
+for rnd in range(10):
+    for dec in (0, 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(50): run(dec, k)
+        e1.record(); torch.cuda.synchronize()
+        res[dec].append(e0.elapsed_time(e1) / 50 * 1e3)
+a, b = np.median(res[0]), np.median(res[1])
+print(f"network only {a:.1f} us per launch, network + fused decode {b:.1f} us  (+{100 * (b / a - 1):.1f} %)")
