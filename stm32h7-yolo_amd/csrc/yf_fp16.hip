@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     SYNC();
     FETCH(4);
     fill_halo<B_T4, false, NT>(lds, tid);
-    dense_stage<3, NW, 3, 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4>(lds, nullptr, tab, conv(3), wave, lane);     // conv2d_6
+    dense_stage<3, NW, YF16_TPJ_SET ? 5 : 3, 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4>(lds, nullptr, tab, conv(3), wave, lane);     // conv2d_6
     SYNC();
     pool8_h<NT>(lds, tid);
     SYNC();
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     SYNC();
     FETCH(7);
     fill_halo<B_T8, true, NT>(lds, tid);
-    dense_stage<6, NW, 3, 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8>(lds, nullptr, tab, conv(6), wave, lane);     // conv2d_13
+    dense_stage<6, NW, YF16_TPJ_SET ? 5 : 3, 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8>(lds, nullptr, tab, conv(6), wave, lane);     // conv2d_13
     SYNC();
     FETCH(8);
     conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv(7), wave, lane);                     // conv2d_15 (dw)
