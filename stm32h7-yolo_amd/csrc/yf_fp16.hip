@@ -320,11 +320,23 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     const int cg = j / JPG;
     const int jend = min(j1, (cg + 1) * JPG);
     v4i a[5];                        // A fragments as dword vectors (bit-cast at the MFMA): as half vectors the compiler re-packs
-#pragma unroll                       // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
+                                     // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
+#if YF16_WHATIF & 32
+#pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
       a[ks] = v4i{0, 0, 0, 0};
       if (a_on) a[ks] = *reinterpret_cast<const v4i*>(lds + woff(K) + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
     }
+#else
+    // the lanes whose fragment is all zero read it too -- from the input buffer's top halo row, which holds zeros while the stage runs --
+    // at the same immediate offsets: no zero-filling moves, no exec masking per channel group (the int8 kernel's zero region)
+    static_assert(IN::PT == 1 && IN::RS * IN::S >= 5 * 64 && IN::OFF % 16 == 0, "a zero halo row of at least five fragments");
+    {
+      const char* abase = lds + (a_on ? woff(K) + cg * 320 + (c & 3) * 16 : IN::OFF);
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) a[ks] = *reinterpret_cast<const v4i*>(abase + 64 * ks);
+    }
+#endif
     v4f bias = uniform_f4(tab + t.b_off + 16 * cg);
     asm volatile("" : "+v"(bias));     // in VGPRs before the job loop: as SGPRs the accumulators' initial moves wait for the scalar load INSIDE it (lgkmcnt(0): every LDS read with it)
     // one job: nine tap reads -> five MFMAs -> LeakyReLU -> fp16 -> one 8-byte store.  TWO jobs run in flight per iteration: all
