@@ -503,14 +503,19 @@ YF_STAGE_FN void stage_input_cam(char* frames, const uint8_t* __restrict__ cam, 
   const long rest = n_frames - 1 - first_frame;
   const int lastf = __builtin_amdgcn_readfirstlane((int)(rest < (long)(F - 1) ? rest : (long)(F - 1)));
   const uint8_t* base = cam + first_frame * CAM_FRAME_BYTES;
-  for (int i = tid; i < TOTAL; i += NT) {
-    int f = 0;
+  // items in PAIRS: the four 16-byte loads of two items are issued before the first is used (one loop iteration per item waited for its own
+  // two loads before the next item's were issued: up to four global-load latencies in a row per group, as in stage_input before round 3)
+  constexpr int ITERS = (TOTAL + NT - 1) / NT;
+  auto item = [&](int i, int& f, int& r, int& y, const uint8_t*& src) {
+    f = 0;
 #pragma unroll
     for (int k = 1; k < F; ++k) f += (i >= k * PER_FRAME) ? 1 : 0;
-    const int r = i - f * PER_FRAME;
-    const int y = (int)((uint32_t)r / (uint32_t)WQ), xq = r - y * WQ;
-    const uint8_t* src = base + (uint32_t)(min(f, lastf) * CAM_FRAME_BYTES + (2 * y) * 224 + 16 * xq);
-    const uint4 a = *reinterpret_cast<const uint4*>(src), c = *reinterpret_cast<const uint4*>(src + 224);
+    r = i - f * PER_FRAME;
+    y = (int)((uint32_t)r / (uint32_t)WQ);
+    const int xq = r - y * WQ;
+    src = base + (uint32_t)(min(f, lastf) * CAM_FRAME_BYTES + (2 * y) * 224 + 16 * xq);
+  };
+  auto commit = [&](int f, int r, int y, const uint4& a, const uint4& c) {
     constexpr uint32_t SWAP = 0x02030001u;                           // bytes of each 16-bit half swapped: big-endian pairs -> values
     uint4 px;
     px.x = cam_pixel(__builtin_amdgcn_perm(a.x, a.x, SWAP), __builtin_amdgcn_perm(c.x, c.x, SWAP));
@@ -518,6 +523,18 @@ YF_STAGE_FN void stage_input_cam(char* frames, const uint8_t* __restrict__ cam, 
     px.z = cam_pixel(__builtin_amdgcn_perm(a.z, a.z, SWAP), __builtin_amdgcn_perm(c.z, c.z, SWAP));
     px.w = cam_pixel(__builtin_amdgcn_perm(a.w, a.w, SWAP), __builtin_amdgcn_perm(c.w, c.w, SWAP));
     *reinterpret_cast<uint4*>(frames + f * B_IN::FS + B_IN::OFF + (RSW + 4) * 4 + 16 * (r + y)) = px;
+  };
+#pragma unroll
+  for (int it = 0; it < ITERS; it += 2) {
+    const int i0 = tid + it * NT, i1 = i0 + NT;
+    int f0, r0, y0, f1, r1, y1;
+    const uint8_t *s0, *s1;
+    item(min(i0, TOTAL - 1), f0, r0, y0, s0);
+    item(min(i1, TOTAL - 1), f1, r1, y1, s1);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(s0), c0 = *reinterpret_cast<const uint4*>(s0 + 224);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(s1), c1 = *reinterpret_cast<const uint4*>(s1 + 224);
+    if (i0 < TOTAL) commit(f0, r0, y0, a0, c0);
+    if (it + 1 < ITERS && i1 < TOTAL) commit(f1, r1, y1, a1, c1);
   }
 }
 
