@@ -84,30 +84,17 @@ __device__ __forceinline__ void decode_frame(const int8_t* head, long frame, int
 // global round trips, six in a row per frame on one wave (2.7 us per launch of 4096 frames; tools/probe/decode_cost.py).
 typedef const __attribute__((address_space(3))) uint32_t* dec_lds_u32;
 __device__ __forceinline__ void decode_frame_lds(const int8_t* head, long frame, int lane, int mode, float w_scale, float h_scale,
-                                                 yf_det* __restrict__ dets, int* __restrict__ counts, int cap, uint32_t lds_tabs) {
+                                                 yf_det* __restrict__ dets, int* __restrict__ counts, int cap, uint32_t lds_tabs, int q_thr) {
   yf_det* out = dets + frame * cap;
   const float anc_w[3] = {9.f, 12.f, 22.f}, anc_h[3] = {14.f, 17.f, 21.f};
   auto sig = [&](int q) { return __uint_as_float(*(dec_lds_u32)(lds_tabs + 4u * (uint32_t)(q + 128))); };
   auto ex = [&](int q) { return __uint_as_float(*(dec_lds_u32)(lds_tabs + 1024u + 4u * (uint32_t)(q + 128))); };
   // phase 1: the confidence test on the QUANTISED value (the sigmoid table is monotonic: conf > 0.7 <=> q >= q_thr, the first table entry that
-  // passes the mode's comparison -- found once per wave with a ballot over the table) and the candidate's byte offset; (anchor, row, column) and
-  // everything else only for the records that are written
+  // passes the mode's comparison -- found by the engine on the host, yf_decode_q_threshold) and the candidate's byte offset; (anchor, row, column)
+  // and everything else only for the records that are written
   int pos[3], off[3], q4[3];
   bool keep[3];
   int total = 0;
-  int q_thr;
-  {
-    unsigned long long pass = 0;      // 256 table entries, four per lane: which pass the test?
-    int first = 256;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float v = sig(64 * k + lane - 128);
-      const bool ok = (mode == YF_DECODE_PY) ? (v > 0.7f) : ((double)v >= 0.7);
-      pass = __ballot(ok);
-      if (pass != 0 && first == 256) first = 64 * k + __builtin_ctzll(pass);
-    }
-    q_thr = first - 128;              // uniform
-  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int i = min(64 * c + lane, 146);

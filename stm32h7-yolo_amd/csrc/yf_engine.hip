@@ -276,6 +276,10 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   }
   if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
   if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
+  for (int i = 1; i < 256; ++i) {           // the fused decode compares quantised confidences (yf_decode_q_threshold): the table must not decrease
+    float a, b; memcpy(&a, &yf_sigmoid_bits[i - 1], 4); memcpy(&b, &yf_sigmoid_bits[i], 4);
+    if (b < a) return bail(hipErrorInvalidValue, "sigmoid table is not monotonic");
+  }
   if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_sig_bits), yf_sigmoid_bits, sizeof yf_sigmoid_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(sigmoid)");
   if ((rc = hipMemcpyToSymbol(HIP_SYMBOL(d_exp_bits), yf_exp_bits, sizeof yf_exp_bits)) != hipSuccess) return bail(rc, "hipMemcpyToSymbol(exp)");
   for (const Variant& v : k_variants) {
@@ -395,6 +399,15 @@ const char* yf_engine_kernel_name_for(const yf_engine* e, long n) { return e && 
 const char* yf_engine_build_id(void) { return YF_BUILD_ID; }
 long yf_engine_dump_bytes(void) { return yf::DumpOffsets::TOTAL; }
 
+// The fused decode tests the QUANTISED confidence: the first entry of the (monotonic) sigmoid table that passes the mode's comparison --
+// conf > 0.7f for the Python decode, (double)conf >= 0.7 for the firmware's -- as an int8 value; 128 = none passes.
+static int yf_decode_q_threshold(int mode) {
+  for (int i = 0; i < 256; ++i) {
+    float v; memcpy(&v, &yf_sigmoid_bits[i], 4);
+    if (mode == YF_DECODE_PY ? (v > 0.7f) : ((double)v >= 0.7)) return i - 128;
+  }
+  return 128;
+}
 struct DecodeArgs { void* dets; void* counts; int cap, mode; float w_scale, h_scale; };
 
 // Kernel shape for a batch of n frames: up to SMALL_N frames run one frame per workgroup (every frame on a CU of its own: a 1-frame
@@ -409,7 +422,9 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   yf::NetParams prm;
   prm.in = (const int8_t*)d_in; prm.out = (int8_t*)d_out; prm.n = n; prm.tab = e->d_tab; prm.dump = (int8_t*)d_dump; prm.stop_stage = stop_stage;
   prm.dets = nullptr; prm.counts = nullptr; prm.cap = 0; prm.mode = 0; prm.w_scale = prm.h_scale = 1.f;
-  if (dec) { prm.dets = (yf_det*)dec->dets; prm.counts = (int*)dec->counts; prm.cap = dec->cap; prm.mode = dec->mode; prm.w_scale = dec->w_scale; prm.h_scale = dec->h_scale; }
+  prm.q_thr = 128;
+  if (dec) { prm.dets = (yf_det*)dec->dets; prm.counts = (int*)dec->counts; prm.cap = dec->cap; prm.mode = dec->mode; prm.w_scale = dec->w_scale; prm.h_scale = dec->h_scale;
+             prm.q_thr = yf_decode_q_threshold(dec->mode); }
   const long groups = (n + v->f - 1) / v->f;
   const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
   long grid = (long)e->cus * per_cu;

@@ -1102,30 +1102,6 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
       if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
       else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, any_value(), any_value()}; }
       else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), any_value(), any_value(), any_value()};
-#if YF_TOGGLED(64)
-      // phase-split: the MFMAs of all passes of the job, then their requantisations, then all LUT reads, then the stores -- the
-      // latencies (MFMA result, LUT read) are paid once per job instead of once per pass
-      if constexpr (TPJ > 1 && EPI == EPI_LUT) {
-        v4i acc[TPJ];
-#pragma unroll
-        for (int t = 0; t < TPJ; ++t) {
-          acc[t] = v4i{ACC0, ACC0, ACC0, ACC0};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc[t], 0, 0, 0);
-        }
-        int idx[TPJ][4];
-#pragma unroll
-        for (int t = 0; t < TPJ; ++t) requant4<true>(acc[t], pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx[t]);
-        uint32_t by[TPJ][4];
-#pragma unroll
-        for (int t = 0; t < TPJ; ++t)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) by[t][j] = lutb<LUT_ID>(idx[t][j]);
-#pragma unroll
-        for (int t = 0; t < TPJ; ++t)
-          if (chunk * TPJ + t < NP) *reinterpret_cast<uint32_t*>(dstpix + t * 4) = join4(by[t][0], by[t][1], by[t][2], by[t][3]);
-      } else
-#endif
 #pragma unroll
       for (int t = 0; t < TPJ; ++t) {
         const int ps = chunk * TPJ + t;
@@ -1370,16 +1346,11 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
       char *dp, *dq;
       taps(e0, p0, p1, p2, dp);
       taps(e1, q0, q1, q2, dq);
-#if !YF_TOGGLED(32)
       e0 = entry(jj + i + 2); e1 = entry(jj + i + 3);
-#endif
       const v4i ap = conv(p0, p1, p2);
       const v4i aq = conv(q0, q1, q2);
       finish(ap, dp);
       finish(aq, dq);
-#if YF_TOGGLED(32)
-      e0 = entry(jj + i + 2); e1 = entry(jj + i + 3);
-#endif
     }
     if (i < n) {
       v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
@@ -1466,6 +1437,7 @@ struct NetParams {
   yf_det* dets;           // [n][cap] detection records
   int* counts;            // [n] candidates per frame (may exceed cap)
   int cap, mode;          // YF_DECODE_PY / YF_DECODE_FW
+  int q_thr;              // smallest quantised confidence that passes the mode's threshold (the sigmoid table is monotonic): set by the engine
   float w_scale, h_scale;
   char* scratch;          // tail batching: gridDim.x * F * TailBufs::T15_BYTES bytes (a workgroup parks one group's T15 there)
 };
@@ -1509,14 +1481,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   int vz = 0;
   asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
   // Issue priorities.  A static priority for the first-dispatched half of a workgroup was worth -1.9 % in round 1 and costs
-  // 1.7 % with the tail on four frames (YF_EXP_MASK bit 1 turns it back on in the experimental build).  What pays is a priority
+  // 1.7 % with the tail on four frames.  What pays is a priority
   // LADDER over a group's stages (YF_PRIO_LIST, s_setprio before a stage whenever the level changes): 3 up to conv2d_13, 2 up
   // to conv2d_23, 1 for the first six tail stages, 0 for the rest.  The two workgroups of a CU are in different phases; the one
   // in the VALU-bound front stages then issues ahead of the one in the latency-bound tail, which only needs the slots left
   // over.  -6.8 % kernel time in-run (A/B 1.073 against no ladder); every placement of the three steps tried gave 6.0-7.3 %.
-#if YF_TOGGLED(1)
-  if (__builtin_amdgcn_readfirstlane(tid0 >> 6) < NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
 #if YF_V2
   for (int i = tid0; i < v2::LUT_B / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
@@ -1567,7 +1536,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_SYNC() __syncthreads()
 #endif
   // Stage calls: the lean forms (constants from an LDS ring slot, fetched one stage ahead by YF_FETCH) or the round-2 forms
-#if YF_V2 && !YF_TOGGLED(128)
+#if YF_V2
 #define YF_HALO(B, RING, FR, G, HOFF, WI, TID) \
   v2::fill_halo_t<B, typename v2::HaloTabs<F, BATCH>::G, v2::HaloTabs<F, BATCH>::HOFF>(frames, load_halo_zp(tab, WI), TID)
 #else
@@ -1627,7 +1596,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const int L_f = tid_f & 63, L_m = tid_m & 63, L_t = tid_t & 63;
     const int W_f = __builtin_amdgcn_readfirstlane(tid_f >> 6), W_m = __builtin_amdgcn_readfirstlane(tid_m >> 6), W_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
     (void)lane; (void)wave;
-#if !defined(YF_BARPROF) && !YF_TOGGLED(2)
+#if !defined(YF_BARPROF)
     // previous group's arena is dead.  LDS-only barrier: __syncthreads() would also wait for the acknowledgements of the
     // previous group's head / detection / parking stores (vmcnt), which nothing in this group depends on
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1714,7 +1683,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     // s_waitcnt vmcnt(0) in front of the barrier behind conv2d_23 (this toolchain also waits at conv2d_23's first LDS access: its
     // alias analysis cannot tell the DMA's destination from the stage's buffers, so the transfer overlaps less than it could).
     // One wave-instruction moves 64 x 16 contiguous bytes.
-    if constexpr (BATCH && !YF_TOGGLED(4)) {
+    if constexpr (BATCH) {
       if (parked_first >= 0) {
         constexpr int PV = TailBufs<FRAME_BYTES>::T15_BYTES / 16, WI = (PV + 63) / 64;      // vectors / wave-instructions per frame
         const char* park = prm.scratch + (long)blockIdx.x * (F * PV * 16);
@@ -1751,13 +1720,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
         continue;
       }
       if (parked_first >= 0) {                  // its T15 is already in the odd sets (LDS-DMA issued before conv2d_23)
-#if YF_TOGGLED(4)
-        for (int i = tid_t; i < F * V; i += NT) {
-          const int f = i / V, k = i - f * V;
-          *reinterpret_cast<uint4*>(frames + (2 * f + 1) * U::T15::FS + 16 * k) = park[i];
-        }
-        YF_SYNC();
-#endif
         odd_first = parked_first;
         parked_first = -1;
       }
@@ -1771,7 +1733,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_DUMP_T(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
     YF_PRIO(14);
-#if YF_V2 && !YF_TOGGLED(16)
+#if YF_V2
     YF_FETCH(12, W_t, L_t);
     {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
       constexpr int PW = v2::pool25_waves<FT>();
@@ -1903,7 +1865,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
           int dl = L_t;
           asm volatile("" : "+v"(dl));
           yfdec::decode_frame_lds(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap,
-                                  (uint32_t)(PRE + OUT_ALL_BYTES));
+                                  (uint32_t)(PRE + OUT_ALL_BYTES), prm.q_thr);
         }
       }
     }
