@@ -2082,6 +2082,21 @@ __device__ __forceinline__ void pf_commit(const Prefetch<NT, CNT>& p, char* dst,
 #pragma unroll
   for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) { const int i = tid + k * NT; if (i < n16) reinterpret_cast<v4u*>(dst)[i] = p.v[k]; }
 }
+// the same into rows of PITCH bytes in LDS (ROWVEC 16-byte vectors per row in HBM): a pitch that is not a multiple of 16 bytes (a row skew
+// against bank conflicts) takes dword stores
+template <int ROWVEC, int PITCH, int NT, int CNT>
+__device__ __forceinline__ void pf_commit_rows(const Prefetch<NT, CNT>& p, char* dst, int n16, int tid) {
+#pragma unroll
+  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) {
+    const int i = tid + k * NT;
+    if (i < n16) {
+      const int r = (int)((uint32_t)i / (uint32_t)ROWVEC), c = i - r * ROWVEC;
+      uint32_t* d = reinterpret_cast<uint32_t*>(dst + r * PITCH + 16 * c);
+      if constexpr (PITCH % 16 == 0) *reinterpret_cast<v4u*>(d) = p.v[k];
+      else { d[0] = p.v[k][0]; d[1] = p.v[k][1]; d[2] = p.v[k][2]; d[3] = p.v[k][3]; }
+    }
+  }
+}
 
 // ---- lean stage forms in the band kernels (round 3) -----------------------------------------------------------------------
 // band_k1 and band_k23 use the 56x56 kernel's lean stage forms (namespace v2) with their constants RESIDENT: a workgroup runs many band
@@ -2567,8 +2582,15 @@ constexpr int K4_HALF = G3 / 2, K4_ROWS0 = 2 * K4_HALF + 2, K4_ROWS1 = (G2 + 1) 
 static_assert(G3 % 2 == 0 && K4_HALF >= 4 && K4_ROWS1 <= K4_ROWS0, "two halves of output rows");
 constexpr int K4_T19_BYTES = ((G3 + 2) * ((G3 + 2) * 40 + YF_BAND_SKEW) + 15) & ~15;
 constexpr int K4_R1 = K4_T19_BYTES + 3 * G3 * G3 * 8;                                     // T19 | T18 | T22 | T26
-static_assert(K4_ROWS0 * T15_ROW <= K4_R1, "a T15 half fits the slot of T19 and the small tensors");
-typedef Buf<LB,                                   G2, K4_ROWS0,   24, T15_RS, 0, 1> L4_T15H;  // halo'd rows of one half (halo'd row 0 at OFF)
+// T15's rows are 1008 bytes in HBM (16-byte rows for the band copies) = 252 dwords: conv2d_27's stride-2 tap reads (lanes 12 dwords apart, tile rows
+// 504 apart) put all 64 lanes on the eight banks 4k -- the probe's worst pattern.  In LDS the rows are one dword longer (pf_commit_rows): tile rows land on
+// different bank classes, two lanes per bank instead of eight.
+#ifndef YF_K4_T15_SKEW
+#define YF_K4_T15_SKEW 4
+#endif
+constexpr int K4_T15_PITCH = T15_ROW + YF_K4_T15_SKEW;
+static_assert(K4_ROWS0 * K4_T15_PITCH <= K4_R1, "a T15 half fits the slot of T19 and the small tensors");
+typedef Buf<LB,                                   G2, K4_ROWS0,   24, T15_RS, 0, 1, BUF_FS, YF_K4_T15_SKEW> L4_T15H;  // halo'd rows of one half (halo'd row 0 at OFF)
 typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1, BUF_FS, YF_BAND_SKEW> L4_T19;
 typedef Buf<LB + K4_T19_BYTES,                    G3, G3,  8, G3,     0, 0> L4_T18;
 typedef Buf<L4_T18::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T22;
@@ -2615,7 +2637,7 @@ YF_STAGE_FN void pool25_half(char* frames, int oy0, int h0, int tid) {
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx)
-        m = m.mx(SplitB(lds_u32(frames + L4_T15H::OFF + ((clampi(2 * oy - 1 + ky, 0, LIM) + 1 - h0) * T15_RS + clampi(2 * ox - 1 + kx, 0, LIM) + 1) * 24 + 4 * cg)));
+        m = m.mx(SplitB(lds_u32(frames + L4_T15H::OFF + (clampi(2 * oy - 1 + ky, 0, LIM) + 1 - h0) * K4_T15_PITCH + (clampi(2 * ox - 1 + kx, 0, LIM) + 1) * 24 + 4 * cg)));
     *reinterpret_cast<uint32_t*>(frames + L4_T30::at(oy, ox) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
   }
 }
@@ -2660,13 +2682,13 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
     YF_BAND_PRIO(3);
     lds_barrier();                                                                    // every wave has left the previous frame's head stage (ring slots, buffers)
     K4_FETCH(11);
-    pf_commit(pre, frames + L4_T15H::OFF, N0, tid);                                   // halo'd rows 0 .. ROWS0-1
+    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N0, tid);    // halo'd rows 0 .. ROWS0-1
     K4_SYNC();
     pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
     pool25_half<NT>(frames, 0, 0, tid);
     v2::dw2_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28, 11, JT_A, LayK4>(frames, tab, wave, lane);
     lds_barrier();
-    pf_commit(pre, frames + L4_T15H::OFF, N1, tid);                                   // halo'd rows H1 .. G2
+    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N1, tid);    // halo'd rows H1 .. G2
     lds_barrier();
     if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
     K4_FETCH(12);
@@ -2746,13 +2768,13 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
     const char* t15 = prm.arena + fr * (long)ARENA_BYTES + A_T15;
     YF_BAND_PRIO(3);
     lds_barrier();
-    pf_commit(pre, frames + L4_T15H::OFF, N0, tid);                                   // halo'd rows 0 .. ROWS0-1
+    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N0, tid);    // halo'd rows 0 .. ROWS0-1
     lds_barrier();
     pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
     pool25_half<NT>(frames, 0, 0, tid);
     dw_mfma_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
     lds_barrier();
-    pf_commit(pre, frames + L4_T15H::OFF, N1, tid);                                   // halo'd rows H1 .. G2
+    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N1, tid);    // halo'd rows H1 .. G2
     lds_barrier();
     if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
     pool25_half<NT>(frames, K4_HALF, H1, tid);
