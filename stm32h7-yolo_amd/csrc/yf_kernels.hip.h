@@ -66,21 +66,11 @@ constexpr int BUF_FS = 0;                      // one frame per workgroup
 // with 8- or 40-byte pixels a row's 16 lanes cover the 16 even LDS banks, and an even row pitch (in dwords) puts the next row on the
 // same banks -- a 2-way conflict on every tap read.  One dword of skew per row makes the pitch odd: rows alternate between the even
 // and the odd banks and the reads are conflict-free (T1: conv2d_3's input; T19: the input of conv2d_32 / 38 / 49).
-#ifndef YF_V2
-#define YF_V2 1                                /* the lean stage forms (namespace v2) */
-#endif
-// PAR: the halo'd rows in two PLANES by row parity (even rows first, then the odd ones).  A stride-2 depthwise tile reads the rows 2m, 2m + 1, 2m + 2 of
-// its four output rows m: with rows in sequence the tile rows are 2 * ROWB apart -- an even number of dwords whatever the pitch, so with a pixel of an
-// odd number of dwords two tile rows share their banks.  In planes the tile rows are ONE pitch apart (T4: 145 dwords, odd: conflict-free) and the three
-// tap rows sit at the constant offsets 0, PLANE, ROWB.
-template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = BUF_FS, int SK_ = 0, bool PAR_ = false>
+template <int OFF_, int W_, int H_, int S_, int RS_, int PT_, int PL_, int FS_ = BUF_FS, int SK_ = 0>
 struct Buf {
   static constexpr int OFF = OFF_, W = W_, H = H_, S = S_, RS = RS_, PT = PT_, PL = PL_, FS = FS_, SK = SK_;
-  static constexpr bool PAR = PAR_;
   static constexpr int P = W_ * H_, ROWB = RS_ * S_ + SK_;
-  static constexpr int PLANE = ((H_ + PT_ + 2) / 2) * ROWB;            // even plane: halo'd rows 0, 2, ... (one bottom halo row at most)
-  __device__ static __forceinline__ int rowoff(int h) { return PAR_ ? (h & 1) * PLANE + (h >> 1) * ROWB : h * ROWB; }     // byte offset of halo'd row h
-  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + rowoff(y + PT_) + (x + PL_) * S_; }
+  __device__ static __forceinline__ int at(int y, int x) { return OFF_ + (y + PT_) * ROWB + (x + PL_) * S_; }
   __device__ static __forceinline__ int at_p(int p) {
     if constexpr (RS_ == W_ && PT_ == 0 && PL_ == 0) return OFF_ + p * S_;
     else { const int y = p / W_; return at(y, p - y * W_); }
@@ -100,7 +90,7 @@ typedef Buf<    0, 56, 56,  4, 60, 1, 4> B_IN;    // RGBX dwords, top halo row, 
 typedef Buf<13696, 28, 28,  8, 30, 1, 1, BUF_FS, YF_ROW_SKEW> B_T1;    // conv2d_1 out (+LeakyReLU), halo ring for dw3; 30 rows of 244 bytes
 typedef Buf<21024, 28, 28,  8, 28, 0, 0> B_T2;    // conv2d_3 out
 typedef Buf<16832, 28, 28,  4, 28, 0, 0> B_T3;    // conv2d_5 out
-typedef Buf<    0, 28, 28, 20, 29, 1, 1, BUF_FS, 0, YF_V2 != 0> B_T4;    // conv2d_6 out, top/left halo for dw10 (stride 2: rows in parity planes)
+typedef Buf<    0, 28, 28, 20, 29, 1, 1> B_T4;    // conv2d_6 out, top/left halo for dw10
 typedef Buf<16832, 14, 28, 20, 14, 0, 0> B_HB;    // pool_8 horizontal pass [28 rows][14]
 typedef Buf<24672, 14, 14, 48, 14, 0, 0> B_T14;   // concat_22: pool [0,18) | conv [20,38)
 typedef Buf<16832, 14, 14, 32, 14, 0, 0> B_T6;    // conv2d_10 out
@@ -921,6 +911,9 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
 //     a lane's pixel offsets are per-lane constants and a tile adds a scalar frame offset -- no per-job index arithmetic.
 //   * the depthwise stages read the offsets of a job (row block, column segment, frame pair) from a small LDS table built once
 //     per workgroup instead of deriving them with ~35 scalar instructions per job.
+#ifndef YF_V2
+#define YF_V2 1
+#endif
 namespace v2 {
 constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LDS offset 0 (absolute addressing, as before)
 constexpr int JT = LUT_B, JT_B = 896;                         // depthwise job tables
@@ -1214,7 +1207,7 @@ struct DwGeo {
     const int oy0 = min(rb * 4, H - 4);
     const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
     const int fb = fp * FL * IN::FS;
-    return uint2{(uint32_t)(fb + IN::OFF + IN::rowoff(oy0 * STRIDE) + x0 * STRIDE * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
+    return uint2{(uint32_t)(fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S), (uint32_t)(fb + OUT::OFF + (oy0 * W + x0) * OUT::S)};
   }
 };
 #if YF_H0 == 56
@@ -1251,7 +1244,7 @@ struct HaloGeo {
     } else {
       if (k < WR) { r = 0; c = k; } else { r = 1 + (k - WR); c = 0; }
     }
-    return (uint32_t)(f * B::FS + B::OFF + B::rowoff(r) + c * B::S);
+    return (uint32_t)(f * B::FS + B::OFF + r * B::ROWB + c * B::S);
   }
 };
 #if YF_H0 == 56
@@ -1300,10 +1293,8 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
   typedef DwGeo<F, STRIDE, IN, OUT> G;
   constexpr int W = G::W, FL = G::FL, JPG = G::JPG;
   constexpr int NG = (C + 3) / 4, JOBS = NG * JPG;
-  static_assert(!IN::PAR || (STRIDE == 2 && IN::PT == 1), "parity planes: a stride-2 input whose tiles start on even halo'd rows");
-  constexpr int DROW = IN::PAR ? IN::ROWB : STRIDE * IN::ROWB;  // input bytes between consecutive output rows
-  constexpr int TS = IN::S;                                    // tap strides: +1 column ...
-  constexpr int TR = IN::PAR ? IN::PLANE : IN::ROWB, TR2 = IN::PAR ? IN::ROWB : 2 * IN::ROWB;      // ... +1 row, +2 rows
+  constexpr int DROW = STRIDE * IN::ROWB;                      // input bytes between consecutive output rows
+  constexpr int TS = IN::S, TR = IN::ROWB;                     // tap strides: +1 column, +1 row
   constexpr int SLOT = LAY::slot(CS);
   static_assert(yf_cs_dw[CS] >= 0 && NG == plan_passes(CS), "stage and constant block agree");
   const int g = lane >> 4, c = lane & 15;
@@ -1337,7 +1328,7 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
       const char* src = lin + e[0];
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
-      b1[2] = (int)lds_u32(src + TR2);         b1[3] = (int)lds_u32(src + TR2 + TS);    b2[0] = (int)lds_u32(src + TR2 + 2 * TS);
+      b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
       dst = lout + e[1];
     };
     auto conv = [&](const v4i& b0, const v4i& b1, const v4i& b2) {
