@@ -49,7 +49,7 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------ LDS plan
 // Per-frame arena (bytes).  Buffers alias by lifetime; see DESIGN.md "LDS plan" for the liveness table.
 #if !defined(YF_H0) || YF_H0 == 56
-constexpr int FRAME_BYTES = 34304;
+constexpr int FRAME_BYTES = 34176;
 #endif
 constexpr int LUT_BYTES = YF_N_LUT * 256 + YF_ADDLUT_BYTES;    // byte LUTs, then the int32 add tables
 
@@ -98,38 +98,31 @@ typedef Buf<    0, 14, 14,  8, 14, 0, 0> B_T7;    // conv2d_12 out
 typedef Buf< 1568, 14, 14, 36, 16, 1, 1> B_T8;    // conv2d_13 out, halo ring
 typedef Buf<10784, 14, 14, 48, 14, 0, 0> B_T9;    // conv2d_15 out
 typedef Buf<20192, 14, 14,  8, 14, 0, 0> B_T11;   // eltwise_18 out
-// T15 is read with stride 2 (conv2d_27: lanes 48 bytes apart, i.e. on the eight banks 4k, the tile's second row 720 bytes = 180 dwords behind: the same
-// eight banks, four lanes each).  One dword of row skew (YF_T15_SKEW) moves every second tile row to the banks 4k + 2.
-#ifndef YF_T15_SKEW
-#define YF_T15_SKEW 4
-#endif
-typedef Buf<    0, 14, 14, 24, 15, 1, 1, BUF_FS, YF_T15_SKEW> B_T15;   // conv2d_23 out, top/left halo; 15 rows of 364 bytes
-typedef Buf< 5472,  7,  7, 48,  7, 0, 0> B_T30;   // concat_46: pool [0,24) | conv [24,48)
-typedef Buf< 7824,  7,  7, 32,  7, 0, 0> B_T17;   // conv2d_27 out
-typedef Buf< 9392,  7,  7,  8,  7, 0, 0> B_T18;   // conv2d_29 out
-typedef Buf< 9792,  7,  7, 40,  9, 1, 1, BUF_FS, YF_ROW_SKEW> B_T19;   // conv2d_30/36/47 out, halo ring (three lifetimes); 9 rows of 364 bytes
-typedef Buf<13072,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
-typedef Buf<15424,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
-typedef Buf<15816,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
-typedef Buf<16208,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
+typedef Buf<    0, 14, 14, 24, 15, 1, 1> B_T15;   // conv2d_23 out, top/left halo
+typedef Buf< 5408,  7,  7, 48,  7, 0, 0> B_T30;   // concat_46: pool [0,24) | conv [24,48)
+typedef Buf< 7760,  7,  7, 32,  7, 0, 0> B_T17;   // conv2d_27 out
+typedef Buf< 9328,  7,  7,  8,  7, 0, 0> B_T18;   // conv2d_29 out
+typedef Buf< 9728,  7,  7, 40,  9, 1, 1, BUF_FS, YF_ROW_SKEW> B_T19;   // conv2d_30/36/47 out, halo ring (three lifetimes); 9 rows of 364 bytes
+typedef Buf<13008,  7,  7, 48,  7, 0, 0> B_T20;   // conv2d_32/38/49 out
+typedef Buf<15360,  7,  7,  8,  7, 0, 0> B_T22;   // eltwise_35 out
+typedef Buf<15752,  7,  7,  8,  7, 0, 0> B_T26;   // eltwise_41 out
+typedef Buf<16144,  7,  7, 32,  7, 0, 0> B_T33;   // conv2d_51 out
 // The 7x7 tail (pool_25 ... conv2d_53) works on one 17 KB SET per frame: the same offsets as above, T33 on T17's slot
 // (dead after conv2d_29) and the staged head behind T26.  FS = FRAME_BYTES addresses the sets at the start of each frame's
 // arena; FS = FRAME_BYTES / 2 packs two sets per arena (tail batching: see the kernel).
 template <int FS_>
 struct TailBufs {
-  typedef Buf<    0, 14, 14, 24, 15, 1, 1, FS_, YF_T15_SKEW> T15;
-  typedef Buf< 5472,  7,  7, 48,  7, 0, 0, FS_> T30;
-  typedef Buf< 7824,  7,  7, 32,  7, 0, 0, FS_> T17;
-  typedef Buf< 9392,  7,  7,  8,  7, 0, 0, FS_> T18;
-  typedef Buf< 9792,  7,  7, 40,  9, 1, 1, FS_, YF_ROW_SKEW> T19;
-  typedef Buf<13072,  7,  7, 48,  7, 0, 0, FS_> T20;
-  typedef Buf<15424,  7,  7,  8,  7, 0, 0, FS_> T22;
-  typedef Buf<15816,  7,  7,  8,  7, 0, 0, FS_> T26;
-  typedef Buf< 7824,  7,  7, 32,  7, 0, 0, FS_> T33;
-  typedef Buf<16224,  7,  7, 18,  7, 0, 0, FS_> HEAD;
-  static constexpr int END = 16224 + 882, T15_BYTES = 5472;
-  static_assert(15 * T15::ROWB <= T15_BYTES && T15_BYTES <= T30::OFF && T15_BYTES % 16 == 0 && T30::OFF + 49 * 48 <= T17::OFF && T17::OFF + 49 * 32 <= T18::OFF &&
-                T18::OFF + 49 * 8 <= T19::OFF, "tail buffers do not overlap");
+  typedef Buf<    0, 14, 14, 24, 15, 1, 1, FS_> T15;
+  typedef Buf< 5408,  7,  7, 48,  7, 0, 0, FS_> T30;
+  typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T17;
+  typedef Buf< 9328,  7,  7,  8,  7, 0, 0, FS_> T18;
+  typedef Buf< 9728,  7,  7, 40,  9, 1, 1, FS_, YF_ROW_SKEW> T19;
+  typedef Buf<13008,  7,  7, 48,  7, 0, 0, FS_> T20;
+  typedef Buf<15360,  7,  7,  8,  7, 0, 0, FS_> T22;
+  typedef Buf<15752,  7,  7,  8,  7, 0, 0, FS_> T26;
+  typedef Buf< 7760,  7,  7, 32,  7, 0, 0, FS_> T33;
+  typedef Buf<16160,  7,  7, 18,  7, 0, 0, FS_> HEAD;
+  static constexpr int END = 16160 + 882, T15_BYTES = 5408;
   static_assert(T19::OFF + 9 * T19::ROWB <= T20::OFF && T20::OFF + 49 * 48 <= T22::OFF && T26::OFF + 49 * 8 <= HEAD::OFF, "tail buffers do not overlap");
   static_assert(END <= FS_, "a set fits its stride");
 };
@@ -917,7 +910,7 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
 namespace v2 {
 constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LDS offset 0 (absolute addressing, as before)
 constexpr int JT = LUT_B, JT_B = 896;                         // depthwise job tables
-constexpr int ZERO = JT + JT_B, ZERO_B = 256;                 // zeros: the A fragments of the lanes outside a row block (the stages assert their reach)
+constexpr int ZERO = JT + JT_B, ZERO_B = 640;                 // zeros: the A fragments of the lanes outside a row block
 constexpr int SLOT0 = ZERO + ZERO_B, SLOT_B = 2816;           // two ring slots for the constant blocks of consecutive const-stages
 // behind the ring slots: the halo tables (size depends on the kernel shape), then the frame arenas (pre_bytes)
 constexpr int slot(int cs) { return SLOT0 + (cs & 1) * SLOT_B; }
@@ -1041,7 +1034,6 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
   static_assert(IN::RS == IN::W && IN::PT == 0 && IN::PL == 0, "dense inputs are plain buffers");
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
-  static_assert((TPJ - 1) * 4 * KROW + 16 * KS <= v2::ZERO_B, "zero fragments inside the zero region");
   const uint32_t a_lane = a_on ? (uint32_t)(SLOT + (c & 3) * KROW) : (uint32_t)LAY::ZERO;      // A fragments: row 4*pass + (c&3), or zeros
   const uint32_t a_step = a_on ? (uint32_t)(TPJ * 4 * KROW) : 0u;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
@@ -1146,7 +1138,6 @@ YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, in
   constexpr int SLOT = LAY::slot(CS), WB = plan_wbytes(CS), PV = SLOT + WB;
   const int g = lane >> 4, c = lane & 15;
   const bool a_on = (c >> 2) == g;
-  static_assert(4 * YF_CONV1_KROW + 16 * 3 <= v2::ZERO_B, "zero fragments inside the zero region");
   const uint32_t a_addr = a_on ? (uint32_t)(SLOT + (c & 3) * YF_CONV1_KROW) : (uint32_t)LAY::ZERO;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
   v4i a[2][3];
@@ -1303,7 +1294,6 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
   const char* lane_in = frames + fl * IN::FS + g * DROW + xl * STRIDE * IN::S;     // this lane's pixel: row oy0+g, col x0+xl
   char* lane_out = frames + fl * IN::FS + (g * W + xl) * OUT::S;
   const bool a_on = (c >> 2) == g;
-  static_assert(128 + 4 <= v2::ZERO_B, "zero fragments inside the zero region");
   const uint32_t a_lane = a_on ? (uint32_t)(SLOT + 4 * (c & 3)) : (uint32_t)LAY::ZERO;   // masked weight dwords of channel c&3: +16*tap
   const uint32_t a_step = a_on ? (uint32_t)YF_DWV_GROUP_BYTES : 0u;
   const uint8_t* sc = tab + PLAN.sb_off[CS];
