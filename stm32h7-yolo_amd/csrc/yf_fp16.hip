@@ -314,6 +314,55 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
   const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);
   const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;
   const bool a_on = (c >> 2) == g;
+#if !(YF16_WHATIF & 64)
+  if constexpr (!DEPTHWISE) {
+    // a dense 3x3 (conv2d_1): every output-channel group reads the SAME taps, so a job is a tile with ALL its groups -- the nine tap reads and
+    // the pixel arithmetic once instead of once per group, NG independent MFMA chains in flight
+    static_assert(F == 1 && NG == 2, "conv2d_1: eight output channels");
+    v4i a[NG][5];
+    v4f bias[NG];
+    {
+      const char* abase = lds + (a_on ? woff(K) + (c & 3) * 16 : IN::OFF);        // zero fragments from the zero halo row (see below)
+      const int gstep = a_on ? 320 : 0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) a[q][ks] = *reinterpret_cast<const v4i*>(abase + q * gstep + 64 * ks);
+        bias[q] = uniform_f4(tab + t.b_off + 16 * q);
+        asm volatile("" : "+v"(bias[q]));
+      }
+    }
+    int jt, jt1;
+    job_range<JPG, NW>(wave, jt, jt1);
+    for (; jt < jt1; ++jt) {
+      const int rb = jt / NSEG, seg = jt - rb * NSEG;
+      const int oy0 = min(rb * 4, H - 4);
+      const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
+      const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + lane_in;
+      uint2 tp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
+      char* dst = lds + OUT::at(oy0 + g, x0 + xl);
+      v4f acc[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) acc[q] = bias[q];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
+        const v4i u = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[q][ks]), __builtin_bit_cast(v8h, u), acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        uint2 v; v.x = leaky_pack2(acc[q][0], acc[q][1]); v.y = leaky_pack2(acc[q][2], acc[q][3]);
+        *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+      }
+    }
+    return;
+  }
+#endif
   int j, j1;
   job_range<JOBS, NW>(wave, j, j1);
   while (j < j1) {
