@@ -2128,6 +2128,9 @@ typedef BandLay<0, 3, 768, LB - v2::ZERO_B, LB - v2::ZERO_B - 768, 768> LayK1;
 typedef BandLay<4, 10, 2304, 0, v2::ZERO_B, 768 - v2::ZERO_B> LayK23;
 static_assert(LayK1::END <= LayK1::JT && LayK1::ZERO + v2::ZERO_B <= LB && LayK23::END <= LB && v2::ZERO_B + LayK23::JT_BYTES <= 768, "resident constants fit the unused LUT / add-table bytes");
 
+#ifndef YF_BAND_TPJ
+#define YF_BAND_TPJ 1          /* 1: five passes per job for conv2d_6 in band_k1 (10 jobs per band instead of 20: -2.5 % of that kernel; the same in band_k23 spills or loses) */
+#endif
 // ---- K1 ----------------------------------------------------------------------------------------------------------------
 #ifndef YF_K1_BH
 #define YF_K1_BH 16
@@ -2229,7 +2232,7 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     YF_BAND_PRIO(1);
     v2::dense2_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3, 2, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
     lds_barrier();
-    v2::dense2_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4, 3, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
+    v2::dense2_stage<F, NW, YF_BAND_TPJ ? 5 : 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4, 3, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
 #else
     dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
     lds_barrier();
