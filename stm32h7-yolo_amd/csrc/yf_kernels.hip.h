@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(12);
     YF_FETCH(10, W_m, L_m);
-    YF_DENSE(F, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
+    YF_DENSE(F, (YF_TOGGLED(4096) ? 2 : 3), 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     YF_PRIO(13);
@@ -1757,7 +1757,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_PRIO(16);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW32, tid_t);
     YF_FETCH(14, W_t, L_t);
-    YF_DENSE(FT, 3, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
+    YF_DENSE(FT, (YF_TOGGLED(2048) ? 3 : 5), 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
     YF_STAGE_END()
     YF_PRIO(17);
@@ -1778,7 +1778,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_PRIO(19);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
     YF_FETCH(17, W_t, L_t);
-    YF_DENSE(FT, 3, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
+    YF_DENSE(FT, (YF_TOGGLED(2048) ? 3 : 5), 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
     YF_STAGE_END()
     YF_PRIO(20);
@@ -1803,7 +1803,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       v2::dense2_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, 19, U::T20::OFF, U::T20::S, DBG_LUT>(frames, out_all, tab, no_add, W_t, L_t);
     else
 #endif
-    YF_DENSE(FT, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
+    YF_DENSE(FT, (YF_TOGGLED(2048) ? 2 : 3), 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) YF_DUMP_T(typename U::T20, 24, L43)
     YF_STAGE_END()
     YF_PRIO(23);
