@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Interleaved timing of the SHIPPED kernel of several library builds (one process per library and round; network + fused decode, HBM-resident
-   rotating inputs).  usage: ab_libs.py <libdir> <libdir> [rounds]      (directories under stm32h7-yolo_amd/).  DEV TOOL."""
+   rotating inputs).  usage: ab_libs.py <libdir> <libdir> [...] [rounds]      (directories under stm32h7-yolo_amd/).  DEV TOOL."""
 import subprocess, sys, os, re, statistics
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+args = sys.argv[1:]
+rounds = int(args.pop()) if args and args[-1].isdigit() else 4
+libs = args
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = {l: [] for l in libs}
 for r in range(rounds):
