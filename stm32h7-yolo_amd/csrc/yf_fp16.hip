@@ -30,6 +30,9 @@
 #ifndef YF16_WHATIF
 #define YF16_WHATIF 0      /* timing-only what-if builds (wrong results): 1 no weight loads, 2 no halo fills, 4 tap loads fenced before the MFMAs */
 #endif
+#ifndef YF16_NW
+#define YF16_NW 8          /* waves per workgroup (one frame per workgroup, two workgroups per CU) */
+#endif
 #ifndef YF16_TPJ_SET
 #define YF16_TPJ_SET 1       /* 0: the round-2 passes-per-job of the small-grid 1x1 layers (A/B) */
 #endif
@@ -87,6 +90,8 @@ typedef Buf< 30032,  7,  7, 16,  7, 0, 0> B_T22;   // c34 + add out
 typedef Buf< 30816,  7,  7, 16,  7, 0, 0> B_T26;   // c40 + add out
 typedef Buf< 31600,  7,  7, 80,  7, 0, 0> B_T33;   // c51 out, 32 ch in an 80-byte pixel
 constexpr int LDS_BYTES = 76032;                    // end of B_T14, rounded up to 64
+constexpr int ZSLACK = 75984;                       // the 48 bytes between the end of B_T14 and LDS_BYTES: never written after the arena clear, i.e. always zero
+static_assert(ZSLACK == B_T14::OFF + 14 * 14 * 80 && ZSLACK + 48 <= LDS_BYTES && ZSLACK % 16 == 0, "zero spot of the dense stages with at most three k-steps");
 // The 7x7 tail works on one 33.7 KB SET per frame (the offsets of B_T15 .. B_T33 above); two sets fit the arena, the second
 // one FS = LDS_BYTES / 2 behind the first.
 constexpr int TAIL_FS = LDS_BYTES / 2, TAIL_T15_BYTES = (15 * B_T15::ROWB + 15) & ~15;
@@ -113,11 +118,13 @@ static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROW
 // and every channel-group switch (what-if without those loads: -9 % kernel time at one frame per workgroup).  Blocks k and k+1
 // are the only ones alive together, so even blocks grow up from the bottom of a 5.9 KB region behind the arena and odd blocks
 // down from its top; conv2d_47's 3.8 KB (next to dw49's 3.2 KB) sits in T20's dead bytes of tail set 0 (woff below).
-constexpr int WBYTES[24] = {640, 640, 64, 320, 1600, 384, 576, 2880, 640, 320, 1920, 1920, 384, 640, 3200, 640, 640, 3200, 640, 384, 3840, 3200, 2560, 1280};
+// (a dense 1x1 block carries its fp32 biases behind its rows: 16 bytes per pass of four output channels; the 3x3 stages read theirs with scalar loads)
+constexpr int WBYTES[24] = {640, 640, 80, 400, 1600, 416, 720, 2880, 672, 400, 2016, 1920, 416, 800, 3200, 672, 800, 3200, 672, 480, 4000, 3200, 2688, 1360};
 constexpr int RING0 = LDS_BYTES, LDS_TOTAL = 81920, RING_BYTES = LDS_TOTAL - LDS_BYTES;
 constexpr int TAIL_SET_END = TB::T33::OFF + 7 * 7 * 80;
-// conv2d_47's block (the largest, next to dw49's 3.2 KB) does not fit the ring: it sits in the bytes of T20 of tail set 0, which are dead from conv2d_40's
-// barrier (last reader of dw38's output) until conv2d_49 writes them again -- exactly the two stages (conv2d_42: fetch, conv2d_47: use) the block lives
+// conv2d_47's block (the largest, next to dw49's 3.2 KB) does not fit the ring: it sits in the bytes of T20 (and the first 80 of T22) of tail set 0, which
+// are dead from conv2d_40's barrier (last reader of dw38's output and of eltwise_35's) until conv2d_49 writes T20 again -- exactly the two stages
+// (conv2d_42: fetch, conv2d_47: use) the block lives
 constexpr int woff(int k) { return k == 20 ? B_T20::OFF : (k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]); }
 constexpr bool ring_ok() {
   for (int k = 0; k + 1 < 24; ++k) {
@@ -125,19 +132,21 @@ constexpr bool ring_ok() {
     if (k == 20 || k + 1 == 20) continue;
     if (WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
   }
-  return WBYTES[20] <= 49 * 80 && B_T20::OFF % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
+  return WBYTES[20] <= 49 * 80 + 49 * 16 && B_T22::OFF == B_T20::OFF + 49 * 80 && B_T20::OFF % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
 }
 static_assert(ring_ok(), "adjacent weight blocks fit the ring side by side");
 // LDS-DMA of conv K's rows into its place in the ring: wave w moves bytes [1024 w, 1024 w + 1024).  The compiler does not see
 // the transfer (inline assembly): the barrier behind every stage is preceded by an explicit s_waitcnt vmcnt(0) (SYNC in the kernel).
-template <int K>
+// The LAST waves of the workgroup issue it: the job split gives a stage's surplus jobs to the first ones.
+template <int K, int NW>
 __device__ __forceinline__ void fetch_w(const uint8_t* __restrict__ tab, uint32_t w_off, int wave, int lane) {
   constexpr int BYTES = WBYTES[K], NCHUNK = (BYTES + 1023) / 1024;
-  if (wave < NCHUNK) {
-    const int off = wave * 1024 + lane * 16;
+  const int ch = NW - 1 - wave;
+  if (ch < NCHUNK) {
+    const int off = ch * 1024 + lane * 16;
     if (off < BYTES) {
       const uint8_t* src = tab + w_off + off;
-      const uint32_t dst = (uint32_t)(woff(K) + wave * 1024);
+      const uint32_t dst = (uint32_t)(woff(K) + ch * 1024);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -156,7 +165,7 @@ enum { EPI_ACT = 0, EPI_LINEAR = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 template <int NW>
 __device__ __forceinline__ void fetch_park(const char* __restrict__ src, int wave, int lane) {
   constexpr int NCHUNK = (TAIL_T15_BYTES + 1023) / 1024;
-  for (int j = wave; j < NCHUNK; j += NW) {
+  for (int j = NW - 1 - wave; j < NCHUNK; j += NW) {
     const int off = j * 1024 + lane * 16;
     if (off < TAIL_T15_BYTES) {
       const char* p = src + off;
@@ -169,6 +178,18 @@ __device__ __forceinline__ void fetch_park(const char* __restrict__ src, int wav
 }
 struct ConvT { uint32_t w_off, b_off; };
 struct Tables { ConvT conv[24]; };
+// The blob's layout is fixed by the graph, so the kernel compiles it in (no descriptor load in front of a stage's weight DMA or bias loads):
+// [Tables][conv 0 rows | biases][conv 1 rows | biases] ...; every piece is a multiple of 16 bytes.  yf_fp16_create builds the blob and checks
+// that it arrives at the same offsets.
+constexpr int COUT[24] = {8, 8, 4, 18, 18, 6, 36, 36, 6, 18, 24, 24, 8, 40, 40, 8, 40, 40, 8, 24, 40, 40, 32, 18};
+constexpr bool IS_3X3[24] = {1, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0};
+constexpr int bias_bytes(int k) { return ((COUT[k] + 3) / 4) * 16; }
+constexpr int rows_bytes(int k) { return IS_3X3[k] ? WBYTES[k] : WBYTES[k] - bias_bytes(k); }
+constexpr ConvT conv_at(int k) {
+  uint32_t off = sizeof(Tables);
+  for (int i = 0; i < k; ++i) off += rows_bytes(i) + bias_bytes(i);
+  return ConvT{off, off + (uint32_t)rows_bytes(k)};
+}
 
 __device__ __forceinline__ uint32_t lds_u32(const char* p) { return *reinterpret_cast<const uint32_t*>(p); }
 __device__ __forceinline__ uint2 lds_u64(const char* p) { return *reinterpret_cast<const uint2*>(p); }
@@ -208,7 +229,23 @@ __device__ __forceinline__ float leaky(float v) {                       // max(v
 
 // LeakyReLU of two channels, then one v_cvt_pk_f16_f32.  (On the packed halfs AFTER the conversion -- v_pk_mul_f16 by 0.1, v_pk_max_f16:
 // three instructions per pair instead of five -- the extra fp16 rounding of 0.1 h misses the tolerance and the kernel is 0.5 % faster.)
+#ifndef YF16_PKMUL
+#define YF16_PKMUL 1
+#endif
+#if YF16_PKMUL
+// 0.1 x for both channels as ONE v_pk_mul_f32 (same rate as a single v_mul_f32), then the two v_max_f32 and the conversion: four VALU instructions
+// per channel pair instead of five, results bit for bit the same
+__device__ __forceinline__ uint32_t leaky_pack2(float a, float b) {
+  const v2f x = {a, b};
+  const v2f t = x * 0.1f;                 // compiler-selected (it pads the MFMA -> VALU hazard only for instructions it selects itself); the inline v_max reads t, so it stays behind
+  float r0, r1;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(x[0]), "v"(t[0]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x[1]), "v"(t[1]));
+  return pack2(r0, r1);
+}
+#else
 __device__ __forceinline__ uint32_t leaky_pack2(float a, float b) { return pack2(leaky(a), leaky(b)); }
+#endif
 // four fp32 results of a pass (channels chq..chq+3 of pixel p) -> activation -> fp16 -> LDS (or fp32 logits -> HBM)
 template <int EPI, class OUT, int OUT_CH0, class ADDB, int COUT>
 __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_frame, int p, int chq, v4f acc, bool live) {
@@ -231,65 +268,113 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
 }
 
 // ------------------------------------------------------------------------------------------------ dense 1x1, lane-private
-// KS k-steps of 8 input channels (16 bytes of the pixel's fp16 vector each); TPJ passes of 4 output channels share a job's
-// pixel arithmetic and B fragments.
-// F frames (IN::FS apart); out_frame / out_frame1: the head's fp32 destination of frame 0 / 1 (nullptr: frame not wanted).
-template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int F = 1>
-__device__ __forceinline__ void dense_stage(char* lds0, float* __restrict__ out_frame0, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane,
-                                            float* __restrict__ out_frame1 = nullptr) {
-  constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ;
-  constexpr int P1 = IN::P, P = F * P1, MT = (P + 63) / 64, JOBS = NCH * MT, KROW = 8 * KS;
-  static_assert(WBYTES[K] == NP * 4 * KROW * 2, "stage and weight block agree");
+// KS k-steps of 8 input channels (16 bytes of the pixel's fp16 vector each); TPJ passes of 4 output channels share a job's B fragments; the bias is
+// the accumulator's initial value.  A job's 64 lanes are a TILE:
+//   28x28 / 14x14: 64 CONSECUTIVE pixels p0 + lane (the inputs of every dense stage are halo-free: consecutive pixels are consecutive bytes, and sixteen
+//     consecutive 16-, 48-, 80- or 112-byte pixels cover the 64 banks of a ds_read_b128 lane group exactly once); the last tile starts at P - 64 and redoes
+//     some pixels of the one before (same values, same addresses).  A lane's input offset is a per-stage constant plus a wave-uniform (scalar) tile offset;
+//     so is its output offset when the output has no halo, and with a halo it is one compare-and-select more (the lane's row / column inside the first
+//     tile are per-stage constants, a tile adds a scalar row / column and at most one carry into the next row): one to three VALU instructions per job
+//     (round 3: ~14 of pixel arithmetic -- a min, two divisions by multiplication, two multiply-adds)
+//   7x7 (two frames, tail batching): one frame per tile, 49 lanes (the others redo pixel 48)
+// A fragments: the lanes whose fragment is all zero (48 of 64) read it too -- from ZB, a spot of the arena that holds zeros while the stage runs (the
+// kernel names one per stage) -- so a chunk set-up is ONE address instruction and KS unmasked ds_read_b128 per pass instead of four zero moves, an exec
+// mask and a masked read per fragment.  The biases come with the block (LDS-DMA), are read into VGPRs once per chunk with one broadcast ds_read_b128 per
+// pass and enter the MFMA as its C operand: no scalar load, no move per pass and job.
+// absolute LDS addresses (the kernel has no static LDS: the dynamic segment starts at 0; `lds + offset` costs a v_add of the segment base per address)
+typedef __attribute__((address_space(3))) v4i* lds_v4i_p;
+typedef __attribute__((address_space(3))) v2u_t* lds_v2u_p;
+__device__ __forceinline__ v4i ld128(int a) { return *(const lds_v4i_p)(uintptr_t)(uint32_t)a; }
+__device__ __forceinline__ uint2 ld64(int a) { const v2u_t v = *(const lds_v2u_p)(uintptr_t)(uint32_t)a; return uint2{v.x, v.y}; }
+__device__ __forceinline__ void st64(int a, uint2 v) { *(lds_v2u_p)(uintptr_t)(uint32_t)a = v2u_t{v.x, v.y}; }
+constexpr int dense_rows_bytes(int cout, int ks) { return ((cout + 3) / 4) * 4 * 8 * ks * 2; }
+template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int ZB, int F = 1>
+__device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0, int wave, int lane, float* __restrict__ out_frame1 = nullptr) {
+  constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ, KROW = 8 * KS;
+  constexpr int W = IN::W, P = W * W, NT = (W == 7) ? F : (P + 63) / 64, JOBS = NCH * NT;
+  constexpr bool OUT_LINEAR = (OUT::RS == W && OUT::PT == 0 && OUT::PL == 0 && OUT::SK == 0);
+  constexpr int ROWS = NP * 4 * KROW * 2;                     // the block: A-operand rows, then the fp32 biases (16 bytes per pass)
+  static_assert(WBYTES[K] == ROWS + NP * 16, "stage and weight block agree");
   static_assert(IN::S >= 16 * KS, "the pixel vector must cover every k-step");
   static_assert(IN::OFF % 16 == 0 && IN::S % 16 == 0 && IN::FS % 16 == 0, "B fragments are aligned ds_read_b128 (a misaligned one is several times slower)");
-  static_assert(F == 1 || (F == 2 && IN::FS == OUT::FS && IN::FS == ADDB::FS && IN::FS > 0), "frames of a stage share one stride");
+  static_assert(IN::RS == W && IN::PT == 0 && IN::PL == 0 && IN::SK == 0 && (EPI != EPI_ADD || (ADDB::RS == W && ADDB::PT == 0 && ADDB::PL == 0 && ADDB::SK == 0)), "inputs are halo-free");
+  static_assert((W == 28 || W == 14 || W == 7) && IN::H == W && OUT::W == W && (EPI != EPI_ADD || ADDB::W == W), "tile geometries");
+  static_assert((W == 7) == (F == 2) && (F == 1 || (IN::FS == OUT::FS && IN::FS == ADDB::FS && IN::FS > 0)), "the 7x7 stages run on two frames with one stride");
+  static_assert(ZB % 16 == 0 && ZB >= 0, "zero fragments are aligned reads too");
   const int g = lane >> 4, c = lane & 15;
+  const int pl = (W == 7) ? min(lane, 48) : lane;            // the lane's pixel inside the first tile
+  const int ly = (W == 7) ? (pl * 37) >> 8 : (W == 14) ? (pl * 74) >> 10 : (pl * 37) >> 10;     // pl / W for pl < 64 (7: 37/256, 14: 74/1024, 28: 37/1024; checked exhaustively)
+  const int lx = pl - W * ly;
+  const int in_lane = IN::OFF + pl * IN::S, add_lane = ADDB::OFF + pl * ADDB::S;
+  const int out_lane = OUT::at(ly, lx) + 2 * OUT_CH0;
+  // tile t of a 28x28 / 14x14 stage starts at pixel p0 = min(64 t, P - 64) = (Y, X): output row Y + ly, column X + lx, minus one row's worth of columns on a carry
+  auto tile_p0 = [&](int tile) { return min(64 * tile, P - 64); };
   const bool a_on = (c >> 2) == g;
-  int j0, j1;
-  job_range<JOBS, NW>(wave, j0, j1);
-  int cur = -1;
-  v4i a[TPJ][KS];                    // dword vectors, bit-cast at the MFMA (see conv3x3_stage)
-  v4f bias[TPJ];                     // per chunk, in VGPRs (see conv3x3_stage)
-  for (int j = j0; j < j1; ++j) {
-    const int chunk = j / MT, mt = j - chunk * MT;
-    const bool fresh = chunk != cur;
-    if (fresh) {
-      cur = chunk;
-#pragma unroll
-      for (int tt = 0; tt < TPJ; ++tt) {
-        const int ps = min(chunk * TPJ + tt, NP - 1);
-        bias[tt] = uniform_f4(tab + t.b_off + 16 * ps);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          a[tt][ks] = v4i{0, 0, 0, 0};
-          if (a_on) a[tt][ks] = *reinterpret_cast<const v4i*>(lds0 + woff(K) + ((ps * 4 + (c & 3)) * KROW + 8 * ks) * 2);
-        }
-      }
-    }
-#if YF16_SCHED & 2
-    if (fresh) {                     // biases into VGPRs once per chunk, behind the fragment reads (as SGPRs every pass of every job would wait for them)
-#pragma unroll
-      for (int tt = 0; tt < TPJ; ++tt) asm volatile("" : "+v"(bias[tt]));
-    }
-#endif
-    const int q = mt * 64 + lane;
-    const int qc = min(q, P - 1);
-    const int f = (F == 1) ? 0 : (qc >= P1 ? 1 : 0);
-    const int p = qc - f * P1;
-    char* lds = lds0 + f * IN::FS;
-    float* out_frame = (F == 2 && f) ? out_frame1 : out_frame0;
-    const char* src = lds + IN::at_p(p);
-    v4i b[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
+  const int fr_base = a_on ? woff(K) + (c & 3) * (KROW * 2) : ZB;
+  int fr_scale = a_on ? 1 : 0;
+  asm("" : "+v"(fr_scale));                 // opaque: the fragment address stays ONE multiply-add (otherwise the compiler selects between two sums)
+  int j, j1;
+  job_range<JOBS, NW>(wave, j, j1);
+  while (j < j1) {
+    const int chunk = j / NT;
+    const int jend = min(j1, (chunk + 1) * NT);
+    v4i a[TPJ][KS];
+    v4f bias[TPJ];
 #pragma unroll
     for (int tt = 0; tt < TPJ; ++tt) {
-      const int ps = chunk * TPJ + tt;
-      if (ps < NP) {
-        v4f acc = bias[tt];                                                   // bias as the accumulator's initial value
+      const int ps = min(chunk * TPJ + tt, NP - 1);
+      const int fa = fr_base + __mul24(fr_scale, ps * (4 * KROW * 2));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[tt][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
-        epilogue<EPI, OUT, OUT_CH0, ADDB, COUT>(lds, out_frame, p, 4 * ps, acc, q < P);
+      for (int ks = 0; ks < KS; ++ks) a[tt][ks] = ld128(fa + 16 * ks);
+      bias[tt] = __builtin_bit_cast(v4f, ld128(woff(K) + ROWS + 16 * ps));        // one address for all lanes
+    }
+    for (; j < jend; ++j) {
+      const int tile = j - chunk * NT;
+      int src, dst, addp;
+      if constexpr (W == 7) {
+        src = in_lane + tile * IN::FS; dst = out_lane + tile * OUT::FS + 8 * TPJ * chunk; addp = add_lane + tile * ADDB::FS + 8 * TPJ * chunk;
+      } else {
+        const int p0 = tile_p0(tile);
+        src = in_lane + p0 * IN::S;
+        addp = add_lane + (p0 * ADDB::S + 8 * TPJ * chunk);
+        if constexpr (OUT_LINEAR) dst = out_lane + (p0 * OUT::S + 8 * TPJ * chunk);
+        else {
+          const int Y = (W == 14) ? (p0 * 4682) >> 16 : (p0 * 2341) >> 16;          // p0 / W for p0 <= P - 64 (scalar)
+          const int X = p0 - W * Y;
+          dst = out_lane + (Y * OUT::ROWB + X * OUT::S + 8 * TPJ * chunk) + (lx >= W - X ? OUT::ROWB - W * OUT::S : 0);
+        }
+      }
+      v4i b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks] = ld128(src + 16 * ks);
+      if constexpr (EPI == EPI_HEAD) {
+        static_assert(TPJ == 1, "the head stores one pass per job");
+        float* of = (F == 2 && tile) ? out_frame1 : out_frame0;
+        if (of == nullptr) continue;
+        v4f acc = bias[0];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[0][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
+        float* o = of + (ly * 7 + lx) * COUT + 4 * chunk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (4 * chunk + q < COUT) o[q] = acc[q];
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < TPJ; ++tt) {
+          if (chunk * TPJ + tt < NP) {
+            v4f acc = bias[tt];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[tt][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
+            if constexpr (EPI == EPI_ADD) {
+              const uint2 r = ld64(addp + 8 * tt);
+              v2h r0, r1; __builtin_memcpy(&r0, &r.x, 4); __builtin_memcpy(&r1, &r.y, 4);
+              acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
+            }
+            uint2 v;
+            if constexpr (EPI == EPI_ACT) { v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]); }
+            else { v.x = pack2(acc[0], acc[1]); v.y = pack2(acc[2], acc[3]); }
+            st64(dst + 8 * tt, v);
+          }
+        }
       }
     }
   }
@@ -411,7 +496,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       uint2 v; v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]);
       *reinterpret_cast<uint2*>(dst) = v;
     };
-    for (; j + 1 < jend; j += 2) {
+    for (; NW <= 8 && j + 1 < jend; j += 2) {
       uint2 tp0[9], tp1[9];
       char *d0, *d1;
       taps(j, tp0, d0);
@@ -424,7 +509,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       finish(acc0, d0);
       finish(acc1, d1);
     }
-    if (j < jend) {
+    for (; j < jend; ++j) {
       uint2 tp[9];
       char* dst;
       taps(j, tp, dst);
@@ -434,7 +519,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) acc = kstep(tp, ks, acc);
       finish(acc, dst);
-      ++j;
     }
   }
 }
@@ -459,7 +543,7 @@ __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
   constexpr int NB = RING ? (HR - 3) * RUN : (HR - 1) * RUN;
   constexpr int NC = RING ? (WR + 1) * PG + SG : 0;                   // last run
   constexpr int N1 = NA + NB + NC;
-  for (int i = tid; i < F * N1; i += NT) {
+  for (int i = NT - 1 - tid; i < F * N1; i += NT) {          // the last waves first (see fetch_w)
     const int f = (F == 1) ? 0 : (i >= N1 ? 1 : 0);
     const int k = i - f * N1;
     int off;
@@ -572,16 +656,11 @@ __device__ __forceinline__ void pool25_cols(char* lds0, int item) {
 struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; int stop; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds); stop: leave a frame behind barrier `stop` (YF16_STAGEPMC builds, 0 = never)
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params prm) {
+__global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Params prm) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NT = NW * 64;
   const int tid0 = threadIdx.x;
-  const uint8_t* __restrict__ tab = prm.tab;
-  auto conv = [&](int i) {                                        // stage descriptor: scalar loads out of the table head
-    typedef const __attribute__((address_space(4))) uint32_t* cu32;
-    const cu32 q = (cu32)(uintptr_t)(tab + i * sizeof(ConvT));
-    return ConvT{q[0], q[1]};
-  };
+  const uint8_t* __restrict__ tab0 = prm.tab;
   // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).
   // Everything the stages store is finite fp16, so clearing the arena once per workgroup is enough.
   for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
@@ -602,14 +681,13 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
 #else
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
-#define FETCH(K) fetch_w<K>(tab, conv(K).w_off, wave, lane)
+#define FETCH(K) fetch_w<K, NW>(tab, conv_at(K).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
   // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
 #if defined(YF16_BARPROF) || defined(YF16_STAGEPMC) || (YF16_WHATIF & 16)
 #define SYNC_KEEP_PREFETCH() SYNC()
 #else
-  static_assert((56 * 28 + NW * 64 - 1) / (NW * 64) == 4, "the wait count below is the number of prefetch load instructions");
-#define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads(); } while (0)
+#define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((56 * 28 + NW * 64 - 1) / (NW * 64)) : "memory"); __syncthreads(); } while (0)
 #endif
   // The next frame's input (12 bytes per item, IN_ITERS items per thread) is loaded into registers while a long stage of the current
   // frame runs -- conv2d_23 when the frame only parks its T15, conv2d_51 when it runs the tail -- instead of behind the barrier of the
@@ -634,6 +712,8 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     const bool parks = parked < 0 && fr + gridDim.x < prm.n;     // this frame leaves after conv2d_23 (its tail runs with the next frame's)
     int tid = tid0;
     asm volatile("" : "+v"(tid));       // per-lane index arithmetic is recomputed per frame instead of parked in VGPRs for the whole kernel
+    const uint8_t* tab = tab0;
+    asm volatile("" : "+s"(tab));       // likewise the stages' table addresses (base + compile-time offset): not 24 hoisted SGPR pairs
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* out_frame = prm.out + fr * (7 * 7 * 18);
@@ -663,39 +743,39 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     }
     SYNC();
     FETCH(1);
-    conv3x3_stage<0, NW, 2, B_IN, B_T1, 8, false>(lds, tab, conv(0), wave, lane);                    // conv2d_1
+    conv3x3_stage<0, NW, 2, B_IN, B_T1, 8, false>(lds, tab, conv_at(0), wave, lane);                    // conv2d_1
     SYNC();
     FETCH(2);
-    conv3x3_stage<1, NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv(1), wave, lane);                     // conv2d_3 (dw)
+    conv3x3_stage<1, NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv_at(1), wave, lane);                     // conv2d_3 (dw)
     SYNC();
     FETCH(3);
-    dense_stage<2, NW, 1, 1, B_T2, B_T3, 0, 4, EPI_LINEAR, B_T3>(lds, nullptr, tab, conv(2), wave, lane);   // conv2d_5 (4 ch)
+    dense_tile_stage<2, NW, 1, 1, B_T2, B_T3, 0, 4, EPI_LINEAR, B_T3, ZSLACK>(nullptr, wave, lane);   // conv2d_5 (4 ch)
     SYNC();
     FETCH(4);
     fill_halo<B_T4, false, NT>(lds, tid);
-    dense_stage<3, NW, YF16_TPJ_SET ? 5 : 3, 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4>(lds, nullptr, tab, conv(3), wave, lane);     // conv2d_6
+    dense_tile_stage<3, NW, (NW > 8 ? 3 : 5), 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4, ZSLACK>(nullptr, wave, lane);     // conv2d_6
     SYNC();
     pool8_h<NT>(lds, tid);
     SYNC();
     FETCH(5);
     pool8_v<NT>(lds, tid);                                                                            // pool_8 -> concat_22[0,18)
-    conv3x3_stage<4, NW, 2, B_T4, B_T6, 18, true>(lds, tab, conv(4), wave, lane);                     // conv2d_10 (dw, stride 2)
+    conv3x3_stage<4, NW, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave, lane);                     // conv2d_10 (dw, stride 2)
     SYNC();
     FETCH(6);
-    dense_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7>(lds, nullptr, tab, conv(5), wave, lane);   // conv2d_12
+    dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(nullptr, wave, lane);   // conv2d_12
     SYNC();
     FETCH(7);
     fill_halo<B_T8, true, NT>(lds, tid);
-    dense_stage<6, NW, YF16_TPJ_SET ? 5 : 3, 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8>(lds, nullptr, tab, conv(6), wave, lane);     // conv2d_13
+    dense_tile_stage<6, NW, (NW > 8 ? 3 : 5), 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8, ZSLACK>(nullptr, wave, lane);     // conv2d_13
     SYNC();
     FETCH(8);
-    conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv(7), wave, lane);                     // conv2d_15 (dw)
+    conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv_at(7), wave, lane);                     // conv2d_15 (dw)
     SYNC();
     FETCH(9);
-    dense_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7>(lds, nullptr, tab, conv(8), wave, lane);     // conv2d_17 + eltwise_18
+    dense_tile_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7, B_T8::OFF>(nullptr, wave, lane);     // conv2d_17 + eltwise_18
     SYNC();
     FETCH(10);
-    dense_stage<9, NW, YF16_TPJ_SET ? 3 : 2, 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14>(lds, nullptr, tab, conv(9), wave, lane); // conv2d_19 -> concat_22 conv half
+    dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(nullptr, wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
     FETCH(11);
     if (parks) prefetch_in(fr + gridDim.x);
@@ -703,7 +783,7 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
     // are dead since conv2d_19; the plain barrier behind this stage waits for it): as a copy loop behind the stage it was 1.6 k cycles of HBM latency
     else if (parked >= 0) fetch_park<NW>(prm.scratch + (long)blockIdx.x * TAIL_T15_BYTES, wave, lane);
     fill_halo<B_T15, false, NT>(lds, tid);
-    dense_stage<10, NW, 2, 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15>(lds, nullptr, tab, conv(10), wave, lane);  // conv2d_23
+    dense_tile_stage<10, NW, (NW > 8 ? 1 : 2), 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15, B_T8::OFF>(nullptr, wave, lane);  // conv2d_23
     if (parks) { SYNC_KEEP_PREFETCH(); } else { SYNC(); }
     // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
     // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
@@ -727,45 +807,45 @@ __global__ void __launch_bounds__(NW * 64, 4) yoloface56_f16_fused(const Params 
       constexpr int PW = pool25_waves<2>();
       static_assert(PW < NW, "waves left for conv2d_27");
       if (wave < PW) pool25_cols<2, TB::T15, TB::T30>(lds, wave * 64 + lane);
-      else conv3x3_stage<11, NW - PW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv(11), wave - PW, lane);
+      else conv3x3_stage<11, NW - PW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv_at(11), wave - PW, lane);
     }
     SYNC();
     FETCH(13);
-    dense_stage<12, NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, 2>(lds, nullptr, tab, conv(12), wave, lane);   // conv2d_29
+    dense_tile_stage<12, NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, TB::T15::OFF, 2>(nullptr, wave, lane);   // conv2d_29
     SYNC();
     FETCH(14);
     fill_halo<TB::T19, true, NT, 2>(lds, tid);
-    dense_stage<13, NW, YF16_TPJ_SET ? 3 : 1, 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(13), wave, lane);     // conv2d_30
+    dense_tile_stage<13, NW, (NW > 8 ? 2 : 3), 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_30
     SYNC();
     FETCH(15);
-    conv3x3_stage<14, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(14), wave, lane);          // conv2d_32 (dw)
+    conv3x3_stage<14, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(14), wave, lane);          // conv2d_32 (dw)
     SYNC();
     FETCH(16);
-    dense_stage<15, NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, 2>(lds, nullptr, tab, conv(15), wave, lane);      // conv2d_34 + eltwise_35
+    dense_tile_stage<15, NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, TB::T15::OFF, 2>(nullptr, wave, lane);      // conv2d_34 + eltwise_35
     SYNC();
     FETCH(17);
-    dense_stage<16, NW, YF16_TPJ_SET ? 3 : 1, 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(16), wave, lane);     // conv2d_36 (halo of T19 still zero)
+    dense_tile_stage<16, NW, (NW > 8 ? 2 : 3), 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_36 (halo of T19 still zero)
     SYNC();
     FETCH(18);
-    conv3x3_stage<17, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(17), wave, lane);          // conv2d_38 (dw)
+    conv3x3_stage<17, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(17), wave, lane);          // conv2d_38 (dw)
     SYNC();
     FETCH(19);
-    dense_stage<18, NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, 2>(lds, nullptr, tab, conv(18), wave, lane);      // conv2d_40 + eltwise_41
+    dense_tile_stage<18, NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, TB::T15::OFF, 2>(nullptr, wave, lane);      // conv2d_40 + eltwise_41
     SYNC();
     FETCH(20);
-    dense_stage<19, NW, YF16_TPJ_SET ? 2 : 1, 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, 2>(lds, nullptr, tab, conv(19), wave, lane);    // conv2d_42 -> concat_46[24,48)
+    dense_tile_stage<19, NW, (NW > 8 ? 1 : 2), 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, TB::T15::OFF, 2>(nullptr, wave, lane);    // conv2d_42 -> concat_46[24,48)
     SYNC();
     FETCH(21);
-    dense_stage<20, NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, 2>(lds, nullptr, tab, conv(20), wave, lane);     // conv2d_47
+    dense_tile_stage<20, NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_47
     SYNC();
     FETCH(22);
-    conv3x3_stage<21, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv(21), wave, lane);          // conv2d_49 (dw)
+    conv3x3_stage<21, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(21), wave, lane);          // conv2d_49 (dw)
     SYNC();
     FETCH(23);
     prefetch_in(fr + gridDim.x);
-    dense_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, 2>(lds, nullptr, tab, conv(22), wave, lane);     // conv2d_51
+    dense_tile_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_51
     SYNC_KEEP_PREFETCH();
-    dense_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, 2>(lds, out_frame, tab, conv(23), wave, lane, out_frame1);  // head: fp32 logits -> HBM
+    dense_tile_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, TB::T15::OFF, 2>(out_frame, wave, lane, out_frame1);  // head: fp32 logits -> HBM
   }
 #undef SYNC
 #undef SYNC_KEEP_PREFETCH
@@ -861,6 +941,7 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
     const size_t b_off = alloc((size_t)cp * 4);
     memcpy(blob.data() + b_off, bf, 4 * (size_t)cout);
     T.conv[i].b_off = (uint32_t)b_off;
+    if (T.conv[i].w_off != yf16::conv_at(i).w_off || T.conv[i].b_off != yf16::conv_at(i).b_off) return fail("blob layout differs from the one compiled into the kernel");
   }
   blob.resize((blob.size() + 15 + 64) & ~(size_t)15, 0);          // zeroed tail: 16-byte reads of the last row stay in bounds
   memcpy(blob.data(), &T, sizeof T);
@@ -871,7 +952,7 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return fail(std::string("unsupported GPU ") + prop.gcnArchName); }
   c->cus = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->d_tab, blob.size()) != hipSuccess || hipMemcpy(c->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<8>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_TOTAL) != hipSuccess) {
+      hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<YF16_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_TOTAL) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
   c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup; allocated per stream on first use
@@ -899,7 +980,7 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
   const size_t prof_bytes = (size_t)grid * 8 * 80 * sizeof(long long);
   if (prof_path) { HIPCHK(c, hipMalloc((void**)&prm.prof, prof_bytes)); HIPCHK(c, hipMemset(prm.prof, 0, prof_bytes)); }
 #endif
-  hipLaunchKernelGGL(yf16::yoloface56_f16_fused<8>, dim3((unsigned)grid), dim3(512), yf16::LDS_TOTAL, (hipStream_t)stream, prm);
+  hipLaunchKernelGGL(yf16::yoloface56_f16_fused<YF16_NW>, dim3((unsigned)grid), dim3(YF16_NW * 64), yf16::LDS_TOTAL, (hipStream_t)stream, prm);
   HIPCHK(c, hipGetLastError());
 #ifdef YF16_BARPROF
   if (prof_path) {
