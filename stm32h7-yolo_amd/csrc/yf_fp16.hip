@@ -24,17 +24,8 @@
 #include "yf_fp16.h"
 #include "yf_stream_scratch.h"
 
-#ifndef YF16_SCHED
-#define YF16_SCHED 0
-#endif
-#ifndef YF16_WHATIF
-#define YF16_WHATIF 0      /* timing-only what-if builds (wrong results): 1 no weight loads, 2 no halo fills, 4 tap loads fenced before the MFMAs */
-#endif
 #ifndef YF16_NW
 #define YF16_NW 8          /* waves per workgroup (one frame per workgroup, two workgroups per CU) */
-#endif
-#ifndef YF16_TPJ_SET
-#define YF16_TPJ_SET 1       /* 0: the round-2 passes-per-job of the small-grid 1x1 layers (A/B) */
 #endif
 namespace yf16 {
 
@@ -198,12 +189,8 @@ __device__ __forceinline__ uint2 lds_u64(const char* p) { return *reinterpret_ca
 // clock mode of 64-bit reads is lost); a volatile access is not merged and still gets its s_waitcnt from the compiler.
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 lds_tap64(const char* p) {
-#if YF16_WHATIF & 8
-  return *reinterpret_cast<const uint2*>(p);
-#else
   const v2u_t v = *(const volatile __attribute__((address_space(3))) v2u_t*)p;      // explicit LDS address space: a volatile access through a generic pointer becomes a flat load
   return uint2{v.x, v.y};
-#endif
 }
 typedef const __attribute__((address_space(4))) v4f* cv4f_ptr;
 __device__ __forceinline__ v4f uniform_f4(const void* p) { return *(cv4f_ptr)(uintptr_t)p; }
@@ -399,7 +386,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
   const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);
   const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;
   const bool a_on = (c >> 2) == g;
-#if !(YF16_WHATIF & 64)
   if constexpr (!DEPTHWISE) {
     // a dense 3x3 (conv2d_1): every output-channel group reads the SAME taps, so a job is a tile with ALL its groups -- the nine tap reads and
     // the pixel arithmetic once instead of once per group, NG independent MFMA chains in flight
@@ -447,7 +433,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     }
     return;
   }
-#endif
   int j, j1;
   job_range<JOBS, NW>(wave, j, j1);
   while (j < j1) {
@@ -455,13 +440,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     const int jend = min(j1, (cg + 1) * JPG);
     v4i a[5];                        // A fragments as dword vectors (bit-cast at the MFMA): as half vectors the compiler re-packs
                                      // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
-#if YF16_WHATIF & 32
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-      a[ks] = v4i{0, 0, 0, 0};
-      if (a_on) a[ks] = *reinterpret_cast<const v4i*>(lds + woff(K) + (((cg * 5 + ks) * 4 + (c & 3)) * 8) * 2);
-    }
-#else
     // the lanes whose fragment is all zero read it too -- from the input buffer's top halo row, which holds zeros while the stage runs --
     // at the same immediate offsets: no zero-filling moves, no exec masking per channel group (the int8 kernel's zero region)
     static_assert(IN::PT == 1 && IN::RS * IN::S >= 5 * 64 && IN::OFF % 16 == 0, "a zero halo row of at least five fragments");
@@ -470,7 +448,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) a[ks] = *reinterpret_cast<const v4i*>(abase + 64 * ks);
     }
-#endif
     v4f bias = uniform_f4(tab + t.b_off + 16 * cg);
     asm volatile("" : "+v"(bias));     // in VGPRs before the job loop: as SGPRs the accumulators' initial moves wait for the scalar load INSIDE it (lgkmcnt(0): every LDS read with it)
     // one job: nine tap reads -> five MFMAs -> LeakyReLU -> fp16 -> one 8-byte store.  TWO jobs run in flight per iteration: all
@@ -531,9 +508,6 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 // (the halo fills were 25 % of the kernel's VALU instructions).
 template <class B, bool RING, int NT, int F = 1>
 __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
-#if YF16_WHATIF & 2
-  return;
-#endif
   constexpr int S = B::S, WR = B::RS, HR = B::H + B::PT + (RING ? 1 : 0), SK = B::SK, ROWB = B::ROWB;
   constexpr int G = (S % 16 == 0 && B::OFF % 16 == 0 && SK % 16 == 0) ? 16 : 8, PG = S / G, SG = SK / G;       // granule bytes, granules per pixel / per row skew
   static_assert(S % G == 0 && B::OFF % G == 0 && SK % G == 0 && (F == 1 || B::FS % G == 0), "granules");
@@ -684,7 +658,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #define FETCH(K) fetch_w<K, NW>(tab, conv_at(K).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
   // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
-#if defined(YF16_BARPROF) || defined(YF16_STAGEPMC) || (YF16_WHATIF & 16)
+#if defined(YF16_BARPROF) || defined(YF16_STAGEPMC)
 #define SYNC_KEEP_PREFETCH() SYNC()
 #else
 #define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((56 * 28 + NW * 64 - 1) / (NW * 64)) : "memory"); __syncthreads(); } while (0)

@@ -20,21 +20,20 @@ net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n); torch.cuda.synchroniz
 del os.environ["YF16_PROF_OUT"]
 wgs, nw = (256 if os.environ.get('YF16_ONE_WG_PER_CU') else 512), 8
 p = np.fromfile(path, np.int64).reshape(wgs, nw, 40, 2).astype(np.float64)
-nb = int((p[0, 0, :, 0] > 0).sum())
-p = p[:, :, :nb, :]
 arrive, leave = p[..., 0], p[..., 1]
-body = np.zeros_like(arrive); body[:, :, 1:] = arrive[:, :, 1:] - leave[:, :, :-1]
-wait = leave - arrive
-span = leave[:, :, -1] - leave[:, :, 0]
-names = ["top of loop", "input staging + halo fills", "conv2d_1", "conv2d_3 (dw)", "conv2d_5", "conv2d_6", "pool_8 h", "pool_8 v + conv2d_10 (dw)",
-         "conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23",
-         "pool_25 + conv2d_27 (dw) [2 frames]", "conv2d_29 [2]", "conv2d_30 [2]", "conv2d_32 (dw) [2]", "conv2d_34+add [2]", "conv2d_36 [2]",
-         "conv2d_38 (dw) [2]", "conv2d_40+add [2]", "conv2d_42 [2]", "conv2d_47 [2]", "conv2d_49 (dw) [2]", "conv2d_51 [2]"]
-print(f"{wgs} workgroups x {nw} waves, {nb} barriers in a pair-closing frame; cycles from its first to its last barrier: mean {span.mean():.0f} "
-      f"(min {span.min():.0f} max {span.max():.0f}); the head stage (conv2d_53 + store) follows the last barrier")
-print(f"working {100 * body.sum(axis=2).mean() / span.mean():.1f}%  waiting in barriers {100 * wait[:, :, 1:].sum(axis=2).mean() / span.mean():.1f}%")
+# entries 0..13: the barriers of the workgroup's second frame (front stages); 20, 21: the two barriers of the tail phase of its first batch
+names = ["input staging + halo fills", "conv2d_1", "conv2d_3 (dw)", "conv2d_5", "conv2d_6", "pool_8 h", "pool_8 v + conv2d_10 (dw)",
+         "conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23", "pool_25 + conv2d_27 (dw) -> park slot"]
+front = leave[:, :, 13] - leave[:, :, 0]
+print(f"{wgs} workgroups x {nw} waves; front stages of one frame (first to last barrier, without the staging stage): mean {front.mean():.0f} cycles "
+      f"(min {front.min():.0f} max {front.max():.0f})")
 print(f"{'interval ending at barrier':44s} {'work mean':>10s} {'slowest':>9s} {'wait mean':>10s}   work per wave")
-for i in range(1, nb):
-    b, w = body[:, :, i], wait[:, :, i]
-    print(f"  {i:2d} {names[i] if i < len(names) else '':40s} {b.mean():10.0f} {b.max(axis=1).mean():9.0f} {w.mean():10.0f}   "
-          + " ".join(f"{b[:, k].mean():6.0f}" for k in range(nw)))
+tw = tb = 0.0
+for i in range(1, 14):
+    b, w = arrive[:, :, i] - leave[:, :, i - 1], leave[:, :, i] - arrive[:, :, i]
+    tw += b.mean(); tb += w.mean()
+    print(f"  {i:2d} {names[i]:40s} {b.mean():10.0f} {b.max(axis=1).mean():9.0f} {w.mean():10.0f}   " + " ".join(f"{b[:, k].mean():6.0f}" for k in range(nw)))
+print(f"front: working {100 * tw / (tw + tb):.1f}%  waiting in barriers {100 * tb / (tw + tb):.1f}%")
+b, w = arrive[:, :, 21] - leave[:, :, 20], leave[:, :, 21] - arrive[:, :, 21]
+setup = arrive[:, :, 20] - leave[:, :, 13]
+print(f"tail phase (one wave per frame, {nw} frames): chain mean {b.mean():.0f} slowest {b.max(axis=1).mean():.0f} wait {w.mean():.0f} cycles;  per wave " + " ".join(f"{b[:, k].mean():6.0f}" for k in range(nw)))
