@@ -371,8 +371,11 @@ __device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0,
 // conv1 (RGBX pixels, 8 bytes per tap) and the depthwise convs (4 channels = 8 bytes per tap and group): a k-step carries
 // two taps, nine taps take five k-steps (the last slot pair is empty: its weights are zero, its data whatever tap 8 was).
 // Jobs: 4 output rows x 16 columns (border blocks shifted inwards) x channel group.
-template <int K, int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1>
-__device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane) {
+// GOUT: the results go to global memory (gout + OUT's offsets + OUT_B0) instead of LDS -- conv2d_27 writes the frame's park slot.
+typedef __attribute__((address_space(1))) v2u_t* glb_v2u_p;
+typedef __attribute__((address_space(1))) uint32_t* glb_u32_p;
+template <int K, int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1, bool GOUT = false, int OUT_B0 = 0>
+__device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane, char* gout = nullptr) {
   constexpr int W = OUT::W, H = OUT::H;
   static_assert(WBYTES[K] == ((C + 3) / 4) * 320, "stage and weight block agree");
   constexpr int FL = (F == 2) ? 2 : 1;                             // two 7-wide frames side by side in the 16 lanes of a row tile
@@ -462,7 +465,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
 #pragma unroll
       for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
-      dst = lds + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg;
+      dst = (GOUT ? gout : lds) + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg + OUT_B0;
     };
     auto kstep = [&](const uint2 (&tp)[9], int ks, v4f acc) {
       const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
@@ -471,7 +474,8 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     };
     auto finish = [&](v4f acc, char* dst) {
       uint2 v; v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]);
-      *reinterpret_cast<uint2*>(dst) = v;
+      if constexpr (GOUT) *(glb_v2u_p)(uintptr_t)dst = v2u_t{v.x, v.y};
+      else *reinterpret_cast<uint2*>(dst) = v;
     };
     for (; NW <= 8 && j + 1 < jend; j += 2) {
       uint2 tp0[9], tp1[9];
@@ -601,8 +605,8 @@ __device__ __forceinline__ void pool25(char* lds0, int tid) {                 //
 // its 7 outputs: 56 loads per item instead of 7 x 16, no per-tap clamping.  F x 84 items: the first waves of the stage take them, the
 // others run conv2d_27, which reads the same T15.
 template <int F> constexpr int pool25_waves() { return (F * 84 + 63) / 64; }
-template <int F, class T15, class T30>
-__device__ __forceinline__ void pool25_cols(char* lds0, int item) {
+template <int F, class T15, class T30, bool GOUT = false>
+__device__ __forceinline__ void pool25_cols(char* lds0, int item, char* gout = nullptr) {
   static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7 && T15::FS == T30::FS, "pool_25 geometry");
   if (item >= F * 84) return;
   const int t = item / 12, d = item - 12 * t;
@@ -615,19 +619,146 @@ __device__ __forceinline__ void pool25_cols(char* lds0, int item) {
     const char* p = base + r * ROW;
     return pkmaxh(pkmaxh(lds_u32(p + c0), lds_u32(p + c1)), pkmaxh(lds_u32(p + c2), lds_u32(p + c3)));
   };
-  char* dst = lds + T30::OFF + ox * T30::S + 4 * d;
+  char* dst = (GOUT ? gout : lds) + T30::OFF + ox * T30::S + 4 * d;
   uint32_t prev = hrow(0);                                     // R[0] = max(h[-1 -> 0], h[0])
 #pragma unroll
   for (int oy = 0; oy < 7; ++oy) {
     uint32_t next = hrow(2 * oy + 1);                          // R[oy+1] = max(h[2oy+1], h[2oy+2 -> 13])
     if (2 * oy + 2 <= 13) next = pkmaxh(next, hrow(2 * oy + 2));
-    *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
+    if constexpr (GOUT) *(glb_u32_p)(uintptr_t)(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
+    else *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
     prev = next;
   }
 }
 
+// ------------------------------------------------------------------------------------------------ the 7x7 tail: one frame per WAVE, no barriers
+// Behind conv2d_27 every map of the network is 7 x 7: 49 pixels, ONE lane-private tile.  As barrier-separated workgroup stages the twelve layers
+// conv2d_29 .. conv2d_53 were twelve latency chains of 0.7-2.5 k cycles with 2-20 jobs for 8 waves (28 k cycles per PAIR of frames in round 3's tail
+// batching, a third of the kernel).  Here a wave owns a whole frame: lane = pixel, and because a lane-private pass leaves 4 output channels of the
+// lane's pixel in the lane's own accumulator, a 1x1 layer's packed fp16 outputs ARE the next 1x1 layer's B operand -- the chain runs in registers,
+// with no LDS round trip and no barrier.  Only the three depthwise 3x3 layers need other pixels: the wave writes its 40-channel input into a
+// PRIVATE halo'd exchange buffer (6.4 KB) and reads the nine taps back; LDS operations of one wave execute in order, so no barrier either.
+// The workgroup runs the front stages of up to NW frames one after the other (each leaves {pool_25 | conv2d_27} = 49 x 96 bytes in its park slot in
+// HBM), then ONE tail phase: the twelve tail layers' weights and biases (21.5 KB) become resident in LDS behind the NW exchange buffers, and wave w
+// runs the tail of the batch's frame w.  Arithmetic and its order are those of the staged form: results bit for bit equal.
+constexpr int PARK_PX = 96, PARK_BYTES = 49 * PARK_PX;        // a frame's park slot: 49 pixels x (24 pool_25 + 24 conv2d_27) fp16 channels
+typedef Buf<0, 7, 7, PARK_PX, 7, 0, 0> PARK;
+typedef Buf<0, 7, 7, 80, 9, 1, 1, 0, YF16_ROW_SKEW> XT;       // exchange buffer: T19's layout (40 channels, halo ring, skewed rows)
+constexpr int XB = (9 * XT::ROWB + 15) & ~15;                  // bytes per wave
+constexpr int TAILW0 = (int)conv_at(12).w_off, TAILW_BYTES = (int)conv_at(23).b_off + bias_bytes(23) - TAILW0;
+template <int NW> constexpr int tw(int k) { return NW * XB + (int)conv_at(k).w_off - TAILW0; }     // LDS address of tail conv k's rows / biases
+template <int NW> constexpr int tb(int k) { return NW * XB + (int)conv_at(k).b_off - TAILW0; }
+static_assert(XB % 16 == 0 && TAILW0 % 16 == 0 && TAILW_BYTES % 16 == 0 && 5 * 64 + 16 <= XT::ROWB && 16 * 6 <= XT::ROWB, "tail plan: aligned blocks, a zero halo row that covers every zero fragment");
+template <int NW>
+__device__ __forceinline__ void fetch_tailw(const uint8_t* __restrict__ tab, int wave, int lane) {
+  static_assert(NW * XB + TAILW_BYTES <= ZSLACK, "exchange buffers and resident tail weights fit the arena below its zero spot");
+  constexpr int NCHUNK = (TAILW_BYTES + 1023) / 1024;
+  for (int j = wave; j < NCHUNK; j += NW) {
+    const int off = j * 1024 + lane * 16;
+    if (off < TAILW_BYTES) {
+      const uint8_t* src = tab + TAILW0 + off;
+      const uint32_t dst = (uint32_t)(NW * XB + j * 1024);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+}
+__device__ __forceinline__ uint2 tap64(int a) {               // one ds_read_b64 (volatile: not merged into a ds_read2_b64, see lds_tap64)
+  const v2u_t v = *(const volatile __attribute__((address_space(3))) v2u_t*)(uintptr_t)(uint32_t)a;
+  return uint2{v.x, v.y};
+}
+struct TailLane { int scale, c3, zb, tapb; bool a_on; };       // per-lane constants of the tail: fragment selector, zero spot, tap base, ...
+// 1x1 layer K on the lane's pixel: in = NI packed dwords (8 channels per k-step), out = the layer's packed outputs from dword O0 on
+template <int NW, int K, int KS, int COUT, int EPI, int O0, int NI, int NO, int NA>
+__device__ __forceinline__ void dense_reg(const TailLane& L, const uint32_t (&in)[NI], uint32_t (&out)[NO], const uint32_t (&add)[NA], float* __restrict__ head) {
+  constexpr int NP = (COUT + 3) / 4, KROW = 8 * KS;
+  static_assert(NI == 4 * KS && (EPI == EPI_HEAD || O0 + 2 * NP <= NO) && (EPI != EPI_ADD || NA == 2 * NP), "operand sizes");
+  static_assert(WBYTES[K] == NP * 4 * KROW * 2 + NP * 16, "layer and weight block agree");
+  const int base = L.a_on ? tw<NW>(K) + L.c3 * (KROW * 2) : L.zb;
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int fa = base + __mul24(L.scale, ps * (4 * KROW * 2));
+    v4f acc = __builtin_bit_cast(v4f, ld128(tb<NW>(K) + 16 * ps));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const v4i b = {(int)in[4 * ks], (int)in[4 * ks + 1], (int)in[4 * ks + 2], (int)in[4 * ks + 3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, ld128(fa + 16 * ks)), __builtin_bit_cast(v8h, b), acc, 0, 0, 0);
+    }
+    if constexpr (EPI == EPI_HEAD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (4 * ps + q < COUT) head[4 * ps + q] = acc[q];
+    } else {
+      if constexpr (EPI == EPI_ADD) {
+        v2h r0, r1; __builtin_memcpy(&r0, &add[2 * ps], 4); __builtin_memcpy(&r1, &add[2 * ps + 1], 4);
+        acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
+      }
+      if constexpr (EPI == EPI_ACT) { out[O0 + 2 * ps] = leaky_pack2(acc[0], acc[1]); out[O0 + 2 * ps + 1] = leaky_pack2(acc[2], acc[3]); }
+      else { out[O0 + 2 * ps] = pack2(acc[0], acc[1]); out[O0 + 2 * ps + 1] = pack2(acc[2], acc[3]); }
+    }
+  }
+}
+// depthwise 3x3 (stride 1, 40 channels) K: the lane's pixel goes into the wave's exchange buffer, the nine taps come back per 4-channel group
+template <int NW, int K>
+__device__ __forceinline__ void dw_reg(const TailLane& L, const uint32_t (&in)[20], uint32_t (&out)[20]) {
+  static_assert(WBYTES[K] == 10 * 320, "a 40-channel depthwise block");
+#pragma unroll
+  for (int q = 0; q < 10; ++q) st64(L.tapb + XT::ROWB + XT::S + 8 * q, uint2{in[2 * q], in[2 * q + 1]});
+  const int base = L.a_on ? tw<NW>(K) + L.c3 * 16 : L.zb;
+#pragma unroll
+  for (int cg = 0; cg < 10; ++cg) {
+    const int fa = base + __mul24(L.scale, cg * 320);
+    v4f acc = __builtin_bit_cast(v4f, ld128(tb<NW>(K) + 16 * cg));
+    uint2 tp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tp[k] = tap64(L.tapb + (k / 3) * XT::ROWB + (k % 3) * XT::S + 8 * cg);
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
+      const v4i u = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, ld128(fa + 64 * ks)), __builtin_bit_cast(v8h, u), acc, 0, 0, 0);
+    }
+    out[2 * cg] = leaky_pack2(acc[0], acc[1]); out[2 * cg + 1] = leaky_pack2(acc[2], acc[3]);
+  }
+}
+// the tail of ONE frame on ONE wave: xb = the wave's exchange buffer (zeroed: its halo ring stays zero), park = the frame's park slot, head = its logits
+template <int NW>
+__device__ __forceinline__ void tail_chain(int xb, const char* __restrict__ park, float* __restrict__ head, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const int p = min(lane, 48), y = (p * 37) >> 8, x = p - 7 * y;                     // lanes 49..63 redo pixel 48
+  TailLane L;
+  L.a_on = (c >> 2) == g; L.c3 = c & 3; L.zb = xb; L.tapb = xb + y * XT::ROWB + x * XT::S;
+  L.scale = L.a_on ? 1 : 0;
+  asm("" : "+v"(L.scale));
+  uint32_t cat[24], t17[12];                                                          // concat_46: [pool_25 | conv2d_42]; conv2d_27's output
+  {
+    typedef const __attribute__((address_space(1))) v4i* glb_v4i_p;
+    const glb_v4i_p src = (glb_v4i_p)(uintptr_t)(park + p * PARK_PX);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const v4i v = __builtin_nontemporal_load(src + q);                              // written by other waves of this workgroup: past the vector L1
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { if (q < 3) cat[4 * q + e] = (uint32_t)v[e]; else t17[4 * (q - 3) + e] = (uint32_t)v[e]; }
+    }
+  }
+  const uint32_t none[1] = {0u};
+  uint32_t t18[4], t19[20], t20[20], t22[4], t26[4], t33[16];
+  dense_reg<NW, 12, 3,  8, EPI_LINEAR, 0>(L, t17, t18, none, nullptr);                // conv2d_29
+  dense_reg<NW, 13, 1, 40, EPI_ACT,    0>(L, t18, t19, none, nullptr);                // conv2d_30
+  dw_reg<NW, 14>(L, t19, t20);                                                        // conv2d_32 (dw)
+  dense_reg<NW, 15, 5,  8, EPI_ADD,    0>(L, t20, t22, t18, nullptr);                 // conv2d_34 + eltwise_35
+  dense_reg<NW, 16, 1, 40, EPI_ACT,    0>(L, t22, t19, none, nullptr);                // conv2d_36
+  dw_reg<NW, 17>(L, t19, t20);                                                        // conv2d_38 (dw)
+  dense_reg<NW, 18, 5,  8, EPI_ADD,    0>(L, t20, t26, t22, nullptr);                 // conv2d_40 + eltwise_41
+  dense_reg<NW, 19, 1, 24, EPI_ACT,   12>(L, t26, cat, none, nullptr);                // conv2d_42 -> concat_46[24,48)
+  dense_reg<NW, 20, 6, 40, EPI_ACT,    0>(L, cat, t19, none, nullptr);                // conv2d_47
+  dw_reg<NW, 21>(L, t19, t20);                                                        // conv2d_49 (dw)
+  dense_reg<NW, 22, 5, 32, EPI_ACT,    0>(L, t20, t33, none, nullptr);                // conv2d_51
+  dense_reg<NW, 23, 4, 18, EPI_HEAD,   0>(L, t33, t33, none, head + p * 18);          // conv2d_53: fp32 logits -> HBM
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
-struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; int stop; };   // scratch: gridDim.x * TAIL_T15_BYTES; prof: stage timeline (YF16_BARPROF builds); stop: leave a frame behind barrier `stop` (YF16_STAGEPMC builds, 0 = never)
+struct Params { const half_t* in; float* out; long n; const uint8_t* tab; char* scratch; long long* prof; int stop; };   // scratch: gridDim.x * NW * PARK_BYTES; prof: stage timeline (YF16_BARPROF builds); stop: leave a frame behind barrier `stop` (YF16_STAGEPMC builds, 0 = never)
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Params prm) {
@@ -635,9 +766,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
   constexpr int NT = NW * 64;
   const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab0 = prm.tab;
-  // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).
-  // Everything the stages store is finite fp16, so clearing the arena once per workgroup is enough.
-  for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
   // the barrier behind a stage also publishes the LDS-DMA of the next stage's weights, which the compiler does not see
 #ifdef YF16_BARPROF
   // stage timeline (tools/fp16_timeline.py): in the workgroup's second frame (the one that closes a pair and runs the tail) every wave
@@ -680,32 +808,40 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
       pin[k][0] = src[3 * i]; pin[k][1] = src[3 * i + 1]; pin[k][2] = src[3 * i + 2];
     }
   };
-  prefetch_in(blockIdx.x);
-  long parked = -1;                                               // frame whose T15 waits in the scratch
-  for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
-    const bool parks = parked < 0 && fr + gridDim.x < prm.n;     // this frame leaves after conv2d_23 (its tail runs with the next frame's)
+  const long G = gridDim.x;
+  // a BATCH: up to NW of the workgroup's frames (base + k G): their front stages one after the other, then one tail phase with a wave per frame
+  for (long base = blockIdx.x; base < prm.n; base += NW * G) {
+    const int nb = (int)min((long)NW, (prm.n - base + G - 1) / G);
+    // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).  Everything the
+    // stages store is finite fp16, but the tail phase leaves fp32 biases in the arena: it is cleared once per batch.
+    for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+    prefetch_in(base);
+#ifdef YF16_BARPROF
+    prof_on = false;
+#endif
+    SYNC();
+    for (int k = 0; k < nb; ++k) {
+    const long fr = base + k * G;
     int tid = tid0;
     asm volatile("" : "+v"(tid));       // per-lane index arithmetic is recomputed per frame instead of parked in VGPRs for the whole kernel
     const uint8_t* tab = tab0;
     asm volatile("" : "+s"(tab));       // likewise the stages' table addresses (base + compile-time offset): not 24 hoisted SGPR pairs
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* out_frame = prm.out + fr * (7 * 7 * 18);
 #ifdef YF16_BARPROF
-    bar_no = 0; prof_on = prof_out != nullptr && fr == (long)blockIdx.x + gridDim.x;
+    bar_no = 0; prof_on = prof_out != nullptr && base == (long)blockIdx.x && k == 1;
 #endif
 #ifdef YF16_STAGEPMC
     stage_no = 0;
 #endif
-    SYNC();                                                       // previous frame's buffers are dead
     FETCH(0);
     {   // input: fp16 [56][56][3] -> RGBX pixels with a zero top row and left column.  Two pixels (12 bytes) per item; the frame's
         // dwords were loaded into registers one long stage earlier (prefetch_in)
 #pragma unroll
-      for (int k = 0; k < IN_ITERS; ++k) {
-        const int i = tid0 + k * NT;
+      for (int kk = 0; kk < IN_ITERS; ++kk) {
+        const int i = tid0 + kk * NT;
         if (IN_ITERS * NT != 56 * 28 && i >= 56 * 28) break;
-        const uint32_t d0 = pin[k][0], d1 = pin[k][1], d2 = pin[k][2];
+        const uint32_t d0 = pin[kk][0], d1 = pin[kk][1], d2 = pin[kk][2];
         const int y = i / 28, x2 = (i - y * 28) * 2;
         uint4 px = {d0, d1 & 0xFFFFu, (d1 >> 16) | (d2 << 16), d2 >> 16};
         // pixels x2 and x2+1 of row y: halo'd pixel index (y + 1) * 57 + x2 + 1 (8 bytes each; the pair is 8-byte aligned only)
@@ -752,74 +888,35 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(nullptr, wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
     FETCH(11);
-    if (parks) prefetch_in(fr + gridDim.x);
-    // a pair-closing frame fetches its partner's parked T15 into tail set 1 NOW, by LDS-DMA behind conv2d_23 (the set's bytes -- T9 / T11's --
-    // are dead since conv2d_19; the plain barrier behind this stage waits for it): as a copy loop behind the stage it was 1.6 k cycles of HBM latency
-    else if (parked >= 0) fetch_park<NW>(prm.scratch + (long)blockIdx.x * TAIL_T15_BYTES, wave, lane);
+    const bool more = k + 1 < nb;
+    if (more) prefetch_in(fr + G);                                                                    // the next frame's input, behind this stage's weight DMA
     fill_halo<B_T15, false, NT>(lds, tid);
     dense_tile_stage<10, NW, (NW > 8 ? 1 : 2), 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15, B_T8::OFF>(nullptr, wave, lane);  // conv2d_23
-    if (parks) { SYNC_KEEP_PREFETCH(); } else { SYNC(); }
-    // ---- the 7x7 tail, once per PAIR of frames (tail batching, as in the int8 kernel): its stages have 2..20 jobs for 8 waves
-    // on one frame, so two frames cost far less than twice the time.  The first frame of a pair parks its T15 (10.8 KB with
-    // the halo) in a per-workgroup HBM scratch and skips the tail; the second fetches it into tail set 1 (half the arena
-    // behind set 0, which IS this frame's own T15 .. T33) and runs the tail for both.  A workgroup's unpaired last frame runs
-    // the tail alone (set 1 holds stale finite data, its logits are not stored).
-    constexpr int PV = TAIL_T15_BYTES / 16;
-    uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * PV;
-    if (parks) {
-      for (int i = tid; i < PV; i += NT) park[i] = reinterpret_cast<const uint4*>(lds)[i];
-      parked = fr;
-      continue;
-    }
-    float* out_frame1 = nullptr;
-    if (parked >= 0) {                          // its T15 is already in tail set 1 (fetch_park above)
-      out_frame1 = prm.out + parked * (7 * 7 * 18);
-      parked = -1;
-    }
-    FETCH(12);
-    {   // pool_25 -> concat_46[0,24) on the first waves (by columns), conv2d_27 (dw, stride 2) on the others: both only read T15
-      constexpr int PW = pool25_waves<2>();
+    if (more) { SYNC_KEEP_PREFETCH(); } else { SYNC(); }
+    {   // pool_25 (by columns, on the first waves) and conv2d_27 (dw, stride 2, on the others) both only read T15; their outputs -- the two
+        // inputs of the tail -- go straight to the frame's park slot in HBM (49 pixels x {24 | 24} channels)
+      constexpr int PW = pool25_waves<1>();
       static_assert(PW < NW, "waves left for conv2d_27");
-      if (wave < PW) pool25_cols<2, TB::T15, TB::T30>(lds, wave * 64 + lane);
-      else conv3x3_stage<11, NW - PW, 2, TB::T15, TB::T17, 24, true, 2>(lds, tab, conv_at(11), wave - PW, lane);
+      char* slot = prm.scratch + ((long)blockIdx.x * NW + k) * PARK_BYTES;
+      if (wave < PW) pool25_cols<1, B_T15, PARK, true>(lds, wave * 64 + lane, slot);
+      else conv3x3_stage<11, NW - PW, 2, B_T15, PARK, 24, true, 1, true, 48>(lds, tab, conv_at(11), wave - PW, lane, slot);
     }
-    SYNC();
-    FETCH(13);
-    dense_tile_stage<12, NW, 1, 3, TB::T17, TB::T18, 0, 8, EPI_LINEAR, TB::T18, TB::T15::OFF, 2>(nullptr, wave, lane);   // conv2d_29
-    SYNC();
-    FETCH(14);
-    fill_halo<TB::T19, true, NT, 2>(lds, tid);
-    dense_tile_stage<13, NW, (NW > 8 ? 2 : 3), 1, TB::T18, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_30
-    SYNC();
-    FETCH(15);
-    conv3x3_stage<14, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(14), wave, lane);          // conv2d_32 (dw)
-    SYNC();
-    FETCH(16);
-    dense_tile_stage<15, NW, 1, 5, TB::T20, TB::T22, 0, 8, EPI_ADD, TB::T18, TB::T15::OFF, 2>(nullptr, wave, lane);      // conv2d_34 + eltwise_35
-    SYNC();
-    FETCH(17);
-    dense_tile_stage<16, NW, (NW > 8 ? 2 : 3), 1, TB::T22, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_36 (halo of T19 still zero)
-    SYNC();
-    FETCH(18);
-    conv3x3_stage<17, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(17), wave, lane);          // conv2d_38 (dw)
-    SYNC();
-    FETCH(19);
-    dense_tile_stage<18, NW, 1, 5, TB::T20, TB::T26, 0, 8, EPI_ADD, TB::T22, TB::T15::OFF, 2>(nullptr, wave, lane);      // conv2d_40 + eltwise_41
-    SYNC();
-    FETCH(20);
-    dense_tile_stage<19, NW, (NW > 8 ? 1 : 2), 1, TB::T26, TB::T30, 24, 24, EPI_ACT, TB::T30, TB::T15::OFF, 2>(nullptr, wave, lane);    // conv2d_42 -> concat_46[24,48)
-    SYNC();
-    FETCH(21);
-    dense_tile_stage<20, NW, 1, 6, TB::T30, TB::T19, 0, 40, EPI_ACT, TB::T19, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_47
-    SYNC();
-    FETCH(22);
-    conv3x3_stage<21, NW, 1, TB::T19, TB::T20, 40, true, 2>(lds, tab, conv_at(21), wave, lane);          // conv2d_49 (dw)
-    SYNC();
-    FETCH(23);
-    prefetch_in(fr + gridDim.x);
-    dense_tile_stage<22, NW, 1, 5, TB::T20, TB::T33, 0, 32, EPI_ACT, TB::T33, TB::T15::OFF, 2>(nullptr, wave, lane);     // conv2d_51
-    SYNC_KEEP_PREFETCH();
-    dense_tile_stage<23, NW, 1, 4, TB::T33, TB::T33, 0, 18, EPI_HEAD, TB::T33, TB::T15::OFF, 2>(out_frame, wave, lane, out_frame1);  // head: fp32 logits -> HBM
+    SYNC();                                                       // this frame's buffers are dead, its park slot is written
+    }
+    {   // ---- tail phase: weights resident, exchange buffers zeroed, then wave w runs the whole tail of the batch's frame w
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef YF16_BARPROF
+      bar_no = 20; prof_on = prof_out != nullptr && base == (long)blockIdx.x;
+#endif
+      fetch_tailw<NW>(tab0, wave, lane);
+      for (int i = tid; i < NW * XB / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+      SYNC();
+      if (wave < nb) tail_chain<NW>(wave * XB, prm.scratch + ((long)blockIdx.x * NW + wave) * PARK_BYTES, prm.out + (base + wave * G) * (7 * 7 * 18), lane);
+      SYNC();                                                     // the next batch's clear overwrites the buffers
+    }
   }
 #undef SYNC
 #undef SYNC_KEEP_PREFETCH
@@ -929,7 +1026,7 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
       hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<YF16_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_TOTAL) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
-  c->park_region = (size_t)c->cus * 2 * yf16::TAIL_T15_BYTES;          // one parked frame per workgroup; allocated per stream on first use
+  c->park_region = (size_t)c->cus * 2 * YF16_NW * yf16::PARK_BYTES;    // a park slot per wave of every workgroup; allocated per stream on first use
   *out = c;
   return 0;
 }
