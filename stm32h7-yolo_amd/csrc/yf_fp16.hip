@@ -68,38 +68,11 @@ typedef Buf<  9408, 14, 14, 16, 14, 0, 0> B_T7;    // c12 out, 6 ch
 typedef Buf< 12544, 14, 14, 80, 16, 1, 1, 0, YF16_ROW_SKEW> B_T8;    // c13 out, 36 ch, halo ring; 16 rows of 1288 bytes
 typedef Buf< 33152, 14, 14, 80, 14, 0, 0> B_T9;    // dw15 out
 typedef Buf< 48832, 14, 14, 16, 14, 0, 0> B_T11;   // c17 + add out, 6 ch
-// Pixel strides of the tail: 96 bytes (concat_46's 48 channels) and 64 bytes (conv2d_51's 32) put the lanes of a ds_read_b128 / ds_write_b64
-// on every second / fourth group of banks (tools/probe/lds_banks.hip: 8.0 / 16.0 cycles per read instead of 4.1, 32 per store instead of 6);
-// 112 and 80 bytes are conflict-free.  T15's stride-2 tap reads (96 bytes between lanes) halve their conflicts with the row skew.
 typedef Buf<     0, 14, 14, 48, 15, 1, 1, 0, YF16_ROW_SKEW> B_T15;   // c23 out, 24 ch, top/left halo; 15 rows of 728 bytes
-typedef Buf< 10928,  7,  7, 112, 7, 0, 0> B_T30;   // concat: pool [0,24) | conv [24,48), 16 bytes of padding
-typedef Buf< 16416,  7,  7, 48,  7, 0, 0> B_T17;   // dw27 out, 24 ch
-typedef Buf< 18768,  7,  7, 16,  7, 0, 0> B_T18;   // c29 out, 8 ch
-typedef Buf< 19552,  7,  7, 80,  9, 1, 1, 0, YF16_ROW_SKEW> B_T19;   // c30 / c36 / c47 out, 40 ch, halo ring; 9 rows of 728 bytes
-typedef Buf< 26112,  7,  7, 80,  7, 0, 0> B_T20;   // dw32 / dw38 / dw49 out
-typedef Buf< 30032,  7,  7, 16,  7, 0, 0> B_T22;   // c34 + add out
-typedef Buf< 30816,  7,  7, 16,  7, 0, 0> B_T26;   // c40 + add out
-typedef Buf< 31600,  7,  7, 80,  7, 0, 0> B_T33;   // c51 out, 32 ch in an 80-byte pixel
 constexpr int LDS_BYTES = 76032;                    // end of B_T14, rounded up to 64
 constexpr int ZSLACK = 75984;                       // the 48 bytes between the end of B_T14 and LDS_BYTES: never written after the arena clear, i.e. always zero
 static_assert(ZSLACK == B_T14::OFF + 14 * 14 * 80 && ZSLACK + 48 <= LDS_BYTES && ZSLACK % 16 == 0, "zero spot of the dense stages with at most three k-steps");
-// The 7x7 tail works on one 33.7 KB SET per frame (the offsets of B_T15 .. B_T33 above); two sets fit the arena, the second
-// one FS = LDS_BYTES / 2 behind the first.
-constexpr int TAIL_FS = LDS_BYTES / 2, TAIL_T15_BYTES = (15 * B_T15::ROWB + 15) & ~15;
-struct TB {
-  typedef Buf<B_T15::OFF, 14, 14, 48, 15, 1, 1, TAIL_FS, YF16_ROW_SKEW> T15;
-  typedef Buf<B_T30::OFF,  7,  7, 112, 7, 0, 0, TAIL_FS> T30;
-  typedef Buf<B_T17::OFF,  7,  7, 48,  7, 0, 0, TAIL_FS> T17;
-  typedef Buf<B_T18::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T18;
-  typedef Buf<B_T19::OFF,  7,  7, 80,  9, 1, 1, TAIL_FS, YF16_ROW_SKEW> T19;
-  typedef Buf<B_T20::OFF,  7,  7, 80,  7, 0, 0, TAIL_FS> T20;
-  typedef Buf<B_T22::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T22;
-  typedef Buf<B_T26::OFF,  7,  7, 16,  7, 0, 0, TAIL_FS> T26;
-  typedef Buf<B_T33::OFF,  7,  7, 80,  7, 0, 0, TAIL_FS> T33;
-};
-static_assert(TAIL_FS >= B_T9::OFF && TAIL_FS + TAIL_T15_BYTES <= B_T14::OFF && TB::T33::OFF + 7 * 7 * 80 <= TAIL_FS && TAIL_T15_BYTES % 16 == 0 && TAIL_T15_BYTES <= B_T30::OFF, "a tail set fits half the arena");
-static_assert(B_T19::OFF + 9 * B_T19::ROWB <= B_T20::OFF && B_T20::OFF + 49 * 80 <= B_T22::OFF && B_T22::OFF + 49 * 16 <= B_T26::OFF && B_T26::OFF + 49 * 16 <= B_T33::OFF &&
-              B_T30::OFF + 49 * 112 <= B_T17::OFF && B_T17::OFF + 49 * 48 <= B_T18::OFF && B_T18::OFF + 49 * 16 <= B_T19::OFF && B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF, "skewed buffers do not run into their neighbours");
+static_assert(B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF && B_T15::OFF + 15 * B_T15::ROWB <= B_T8::OFF, "skewed buffers do not run into their neighbours");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
 static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROWB <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
 
@@ -108,22 +81,18 @@ static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROW
 // their fragments with ds_read_b128 (~100 cycles) instead of waiting 1.5-2.5 k cycles for a global load behind every barrier
 // and every channel-group switch (what-if without those loads: -9 % kernel time at one frame per workgroup).  Blocks k and k+1
 // are the only ones alive together, so even blocks grow up from the bottom of a 5.9 KB region behind the arena and odd blocks
-// down from its top; conv2d_47's 3.8 KB (next to dw49's 3.2 KB) sits in T20's dead bytes of tail set 0 (woff below).
+// down from its top.
 // (a dense 1x1 block carries its fp32 biases behind its rows: 16 bytes per pass of four output channels; the 3x3 stages read theirs with scalar loads)
 constexpr int WBYTES[24] = {640, 640, 80, 400, 1600, 416, 720, 2880, 672, 400, 2016, 1920, 416, 800, 3200, 672, 800, 3200, 672, 480, 4000, 3200, 2688, 1360};
 constexpr int RING0 = LDS_BYTES, LDS_TOTAL = 81920, RING_BYTES = LDS_TOTAL - LDS_BYTES;
-constexpr int TAIL_SET_END = TB::T33::OFF + 7 * 7 * 80;
-// conv2d_47's block (the largest, next to dw49's 3.2 KB) does not fit the ring: it sits in the bytes of T20 (and the first 80 of T22) of tail set 0, which
-// are dead from conv2d_40's barrier (last reader of dw38's output and of eltwise_35's) until conv2d_49 writes T20 again -- exactly the two stages
-// (conv2d_42: fetch, conv2d_47: use) the block lives
-constexpr int woff(int k) { return k == 20 ? B_T20::OFF : (k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]); }
+// The ring serves the FRONT stages (convs 0..11); the tail's blocks are resident during the tail phase.
+constexpr int woff(int k) { return k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]; }
 constexpr bool ring_ok() {
-  for (int k = 0; k + 1 < 24; ++k) {
+  for (int k = 0; k < 12; ++k) {
     if (WBYTES[k] % 16 != 0) return false;
-    if (k == 20 || k + 1 == 20) continue;
-    if (WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
+    if (k + 1 < 12 && WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
   }
-  return WBYTES[20] <= 49 * 80 + 49 * 16 && B_T22::OFF == B_T20::OFF + 49 * 80 && B_T20::OFF % 16 == 0 && RING0 % 16 == 0 && RING_BYTES % 16 == 0;
+  return RING0 % 16 == 0 && RING_BYTES % 16 == 0;
 }
 static_assert(ring_ok(), "adjacent weight blocks fit the ring side by side");
 // LDS-DMA of conv K's rows into its place in the ring: wave w moves bytes [1024 w, 1024 w + 1024).  The compiler does not see
@@ -152,21 +121,6 @@ enum { EPI_ACT = 0, EPI_LINEAR = 1, EPI_ADD = 2, EPI_HEAD = 3 };
 //   dense 1x1 (and conv1): rows [cout_pad4][KS*8] f16                   (KS k-steps of 8 input channels / 2 taps)
 //   depthwise: per 4-channel group [5 k-steps][4 rows][8] f16           (row j: w[tap 2ks][j] at slot j, w[tap 2ks+1][j] at slot 4+j)
 //   bias [cout_pad4] f32 behind the rows (16-byte aligned)
-// LDS-DMA of a parked T15 (TAIL_T15_BYTES at src) into tail set 1: wave w moves the 1 KB chunks w, w + NW, ...
-template <int NW>
-__device__ __forceinline__ void fetch_park(const char* __restrict__ src, int wave, int lane) {
-  constexpr int NCHUNK = (TAIL_T15_BYTES + 1023) / 1024;
-  for (int j = NW - 1 - wave; j < NCHUNK; j += NW) {
-    const int off = j * 1024 + lane * 16;
-    if (off < TAIL_T15_BYTES) {
-      const char* p = src + off;
-      const uint32_t dst = (uint32_t)(TAIL_FS + j * 1024);
-      uint32_t keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
-    }
-  }
-}
 struct ConvT { uint32_t w_off, b_off; };
 struct Tables { ConvT conv[24]; };
 // The blob's layout is fixed by the graph, so the kernel compiles it in (no descriptor load in front of a stage's weight DMA or bias loads):
@@ -584,22 +538,6 @@ __device__ __forceinline__ void pool8_v(char* lds, int tid) {                 //
                         [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = v; });
   }
 }
-template <int NT, int F = 1, class B_T15 = yf16::B_T15, class B_T30 = yf16::B_T30>
-__device__ __forceinline__ void pool25(char* lds0, int tid) {                 // T15 [14][14] x 24 ch -> pool half of concat_46
-  for (int i = tid; i < F * 49 * 12; i += NT) {
-    const int d = i % 12; const int pp = i / 12, p = pp % 49;
-    char* lds = lds0 + (pp / 49) * B_T15::FS;
-    const int oy = p / 7, ox = p - oy * 7;
-    uint32_t m = 0xFC00FC00u;                                                  // -inf, -inf
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx)
-        m = pkmaxh(m, lds_u32(lds + B_T15::at(min(max(2 * oy - 1 + ky, 0), 13), min(max(2 * ox - 1 + kx, 0), 13)) + 4 * d));
-    *reinterpret_cast<uint32_t*>(lds + B_T30::at_p(p) + 4 * d) = m;
-  }
-}
-
 // pool_25 by COLUMNS (as in the int8 kernel): one item = (frame, output column, channel dword) walks the 14 rows of T15 once -- per row
 // the horizontal 4-tap maximum (clamped columns), pairs of rows R[j] = max(h[2j-1], h[2j]), out[oy] = max(R[oy], R[oy+1]) -- and writes
 // its 7 outputs: 56 loads per item instead of 7 x 16, no per-tap clamping.  F x 84 items: the first waves of the stage take them, the
