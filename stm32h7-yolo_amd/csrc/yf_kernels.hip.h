@@ -1409,7 +1409,10 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
 #endif
 typedef Buf<0, 7, 7, 40, 9, 1, 1, 0, YF_ROW_SKEW> XT;           // a wave's exchange buffer
 constexpr int XB = (9 * XT::ROWB + 15) & ~15;                    // bytes per wave (the staged head of the wave's frame reuses it behind conv2d_49)
-constexpr int PARK_PX = 48, PARK_BYTES = 49 * PARK_PX;           // a frame's park slot: 49 pixels x (24 pool_25 + 24 conv2d_27) bytes
+// a frame's park slot: the two tail inputs as they lie in LDS -- concat_46's buffer (49 x 48 bytes: the pool half in the first 24 of a pixel) and conv2d_27's
+// output (49 x 32 bytes, 24 used) -- so that the copy is 245 contiguous 16-byte vectors per frame
+constexpr int PARK_T30 = 49 * 48, PARK_T17 = 49 * 32, PARK_BYTES = PARK_T30 + PARK_T17;
+static_assert(PARK_T30 % 16 == 0 && PARK_T17 % 16 == 0, "whole vectors");
 constexpr int TC_CS0 = 12, TC_BYTES = PLAN.vb_off[YF_N_CS - 1] + PLAN.vb_bytes[YF_N_CS - 1] - PLAN.vb_off[TC_CS0];
 constexpr bool tc_contiguous() { for (int cs = TC_CS0; cs + 1 < YF_N_CS; ++cs) if (PLAN.vb_off[cs] + PLAN.vb_bytes[cs] != PLAN.vb_off[cs + 1]) return false; return true; }
 static_assert(tc_contiguous() && TC_BYTES % 16 == 0 && XB % 16 == 0, "the tail's constant blocks are one contiguous, aligned piece of the table");
@@ -1430,9 +1433,9 @@ __device__ __forceinline__ void fetch_tail_consts(const uint8_t* __restrict__ ta
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   }
 }
-__device__ __forceinline__ uint32_t join4c(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {     // compiler-selected (join4 is inline assembly: its result must
-  return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);                                                    // not feed an MFMA: the VALU -> MFMA hazard would not be padded)
-}
+// A layer's packed outputs come out of join4 (inline assembly) and feed the next layer's MFMAs as B operands: hipcc pads the VALU-write -> MFMA-read
+// hazard only for instructions it selects itself, so every layer ends with the wait states itself (behind its last scheduling barrier: nothing moves across)
+__device__ __forceinline__ void layer_end() { asm volatile("s_nop 4" ::: "memory"); }
 // 1x1 layer of const-stage CS on the lane's pixel.  in: NI packed dwords (the layer's input channels in the order of its weight rows; k-slots past
 // them have zero weights); out: the packed results from dword O0 on.  TC = absolute LDS address of the resident blocks.
 template <int TC, int CS, int KS, int COUT, int EPI, int LUT_ID, int O0, int NI, int NO, int NA>
@@ -1443,7 +1446,7 @@ __device__ __forceinline__ void dense_reg(const TailLane& L, const uint8_t* __re
   static_assert(yf_cs_dense[CS] >= 0 && KROW == PLAN_KROW[yf_cs_dense[CS]] && NP == plan_passes(CS) && NI <= 4 * KS && NI > 4 * (KS - 1), "layer and constant block agree");
   static_assert((EPI == EPI_ADD) == (yf_cs_add[CS] >= 0) && (EPI == EPI_HEAD_LDS || O0 + NP <= NO) && (EPI != EPI_ADD || NA == NP), "operands");
   const uint32_t a_lane = L.a_on ? (uint32_t)BLK + L.a_on3 * KROW : (uint32_t)ZERO;
-  const uint8_t* sc = tab + PLAN.c_off[yf_cs_dense[CS]];
+  const uint8_t* sc = tab + PLAN.sb_off[CS];
   v4i b[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -1455,15 +1458,12 @@ __device__ __forceinline__ void dense_reg(const TailLane& L, const uint8_t* __re
     v4i acc = {ACC0, ACC0, ACC0, ACC0};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds_v4i(a_addr + 16 * ks), b[ks], acc, 0, 0, 0);
-    // the pass's constants: ALL by scalar loads (the yf_pass record: multipliers and zero-point terms too, moved into VGPRs) -- the chain is bound by
-    // the LDS pipe (every wave of the CU reads fragments, taps and LUT bytes at once), the scalar cache and eight v_mov are free
-    const uint8_t* s = sc + ps * (int)sizeof(yf_pass);
-    const v4i m2s = *(cv4i_ptr)(uintptr_t)s, zrs = *(cv4i_ptr)(uintptr_t)(s + 16);
-    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)(s + 32), *(cv4i_ptr)(uintptr_t)(s + 64)};
-    const v4u m2 = {(unsigned)m2s[0], (unsigned)m2s[1], (unsigned)m2s[2], (unsigned)m2s[3]}, zr = {(unsigned)zrs[0], (unsigned)zrs[1], (unsigned)zrs[2], (unsigned)zrs[3]};
+    const v4u m2 = lds_v4u((uint32_t)(PV + ps * 32)), zr = lds_v4u((uint32_t)(PV + ps * 32 + 16));
+    const uint8_t* s = sc + ps * (int)sizeof(yf_pass_s);
+    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     int idx[4];
     requant4<true>(acc, m2, zr, k.c64, k.rs, idx);
-    if constexpr (EPI == EPI_LUT) out[O0 + ps] = join4c(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+    if constexpr (EPI == EPI_LUT) out[O0 + ps] = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
     else if constexpr (EPI == EPI_RAW) out[O0 + ps] = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
     else if constexpr (EPI == EPI_ADD) {
       typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
@@ -1480,8 +1480,9 @@ __device__ __forceinline__ void dense_reg(const TailLane& L, const uint8_t* __re
       *(lds_u16w_ptr)(uint32_t)(headp + 4 * ps) = (uint16_t)v;
       if (4 * ps + 2 < 18) *(lds_u16w_ptr)(uint32_t)(headp + 4 * ps + 2) = (uint16_t)(v >> 16);
     }
-    if (ps % YF_CHAIN_ILP == YF_CHAIN_ILP - 1) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP passes at a time: left alone the scheduler hoists every later pass's loads (250 live registers, 230 spilled at the 128 cap)
+    if (ps % YF_CHAIN_ILP == YF_CHAIN_ILP - 1 || ps == NP - 1) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP passes at a time: left alone the scheduler hoists every later pass's loads (250 live registers, 230 spilled at the 128 cap)
   }
+  layer_end();
 }
 // depthwise 3x3 (stride 1, 40 channels) of const-stage CS: halo ring := zp, the lane's pixel into the exchange buffer, nine taps back per 4-channel group
 template <int TC, int CS, int LUT_ID>
@@ -1497,7 +1498,7 @@ __device__ __forceinline__ void dw_reg(const TailLane& L, const uint8_t* __restr
 #pragma unroll
   for (int d = 0; d < 10; ++d) *(lds_u32w_ptr)(uint32_t)(L.tapb + TR + TS + 4 * d) = in[d];
   const uint32_t a_lane = L.a_on ? (uint32_t)BLK + 4 * L.a_on3 : (uint32_t)ZERO;
-  const uint8_t* sc = tab + PLAN.g_off[yf_cs_dw[CS]];
+  const uint8_t* sc = tab + PLAN.sb_off[CS];
 #pragma unroll
   for (int cg = 0; cg < 10; ++cg) {
     const uint32_t wa = a_lane + L.a_step1 * (uint32_t)(cg * YF_DWV_GROUP_BYTES);
@@ -1512,15 +1513,15 @@ __device__ __forceinline__ void dw_reg(const TailLane& L, const uint8_t* __restr
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-    const uint8_t* s = sc + cg * YF_DW_GROUP_BYTES + 144;                              // the group's yf_pass, by scalar loads (see dense_reg)
-    const v4i m2s = *(cv4i_ptr)(uintptr_t)s, zrs = *(cv4i_ptr)(uintptr_t)(s + 16);
-    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)(s + 32), *(cv4i_ptr)(uintptr_t)(s + 64)};
-    const v4u m2 = {(unsigned)m2s[0], (unsigned)m2s[1], (unsigned)m2s[2], (unsigned)m2s[3]}, zr = {(unsigned)zrs[0], (unsigned)zrs[1], (unsigned)zrs[2], (unsigned)zrs[3]};
+    const v4u m2 = lds_v4u((uint32_t)(BLK + cg * YF_DWV_GROUP_BYTES + 144)), zr = lds_v4u((uint32_t)(BLK + cg * YF_DWV_GROUP_BYTES + 160));
+    const uint8_t* s = sc + cg * (int)sizeof(yf_pass_s);
+    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     int idx[4];
     requant4<true>(acc, m2, zr, k.c64, k.rs, idx);
-    out[cg] = join4c(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
-    if (cg % YF_CHAIN_ILP == YF_CHAIN_ILP - 1) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP channel groups at a time (see dense_reg)
+    out[cg] = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
+    if (cg % YF_CHAIN_ILP == YF_CHAIN_ILP - 1 || cg == 9) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP channel groups at a time (see dense_reg)
   }
+  layer_end();
 }
 // The tail of ONE frame on ONE wave.  TP0: absolute LDS address of the tail-phase area (the frame arenas); park: the frame's slot.  Returns with the
 // frame's 882 head bytes staged at the start of the wave's exchange buffer.
@@ -1536,13 +1537,12 @@ __device__ __forceinline__ void tail_chain(int wave, int lane, const uint8_t* __
   L.halo = L.xb + (int)HaloGeo<XT, true, 1>::entry(min(lane, 31));
   uint32_t cat[12], t17[6];                                                           // concat_46: [pool_25 | conv2d_42]; conv2d_27's output
   {
-    typedef const __attribute__((address_space(1))) v4i* glb_v4i_p;
-    const glb_v4i_p src = (glb_v4i_p)(uintptr_t)(park + p * PARK_PX);
+    typedef const __attribute__((address_space(1))) v2u* glb_v2u_p;                    // (written by other waves of this workgroup: past the vector L1)
+    const glb_v2u_p pa = (glb_v2u_p)(uintptr_t)(park + p * 48), pb = (glb_v2u_p)(uintptr_t)(park + PARK_T30 + p * 32);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const v4i v = __builtin_nontemporal_load(src + q);                              // written by other waves of this workgroup: past the vector L1
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { if (4 * q + e < 6) cat[4 * q + e] = (uint32_t)v[e]; else t17[4 * q + e - 6] = (uint32_t)v[e]; }
+      const v2u u = __builtin_nontemporal_load(pa + q), w = __builtin_nontemporal_load(pb + q);
+      cat[2 * q] = u[0]; cat[2 * q + 1] = u[1]; t17[2 * q] = w[0]; t17[2 * q + 1] = w[1];
     }
   }
   const uint32_t none[1] = {0u};
@@ -1875,13 +1875,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     if constexpr (WTAIL) {
 #if YF_V2 && YF_H0 == 56
-      {   // park: [49 pixels][pool_25 24 B | conv2d_27 24 B] per frame, slot = (group of the batch, frame of the group)
-        uint32_t* slots = reinterpret_cast<uint32_t*>(prm.scratch + ((long)blockIdx.x * NW + batch_groups * F) * v2::PARK_BYTES);
-        for (int i = tid_t; i < F * 49 * 12; i += NT) {
-          const int f = i / 588, r = i - f * 588;
-          const int px = r / 12, d = r - 12 * px;
-          const char* src = frames + f * FRAME_BYTES + (d < 6 ? U::T30::OFF + px * U::T30::S + 4 * d : U::T17::OFF + px * U::T17::S + 4 * (d - 6));
-          slots[i] = *reinterpret_cast<const uint32_t*>(src);
+      {   // park: concat_46's buffer and conv2d_27's output of every frame as they lie in LDS, slot = (group of the batch, frame of the group)
+        static_assert(U::T30::S == 48 && U::T17::S == 32 && U::T30::OFF % 16 == 0 && U::T17::OFF % 16 == 0 && FRAME_BYTES % 16 == 0, "the park slot mirrors the two buffers");
+        constexpr int V = v2::PARK_BYTES / 16, VA = v2::PARK_T30 / 16;
+        uint4* slots = reinterpret_cast<uint4*>(prm.scratch + ((long)blockIdx.x * NW + batch_groups * F) * v2::PARK_BYTES);
+        for (int i = tid_t; i < F * V; i += NT) {
+          const int f = i / V, r = i - f * V;
+          slots[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_BYTES + (r < VA ? U::T30::OFF + 16 * r : U::T17::OFF + 16 * (r - VA)));
         }
       }
       ++batch_groups;
