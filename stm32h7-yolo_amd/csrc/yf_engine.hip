@@ -98,11 +98,11 @@ typedef void (*fused_fn)(const yf::NetParams);
 static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
 struct Variant { int f, nw; bool dump; bool exp; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
 
-#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<F, NW, DUMP>(), \
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
 #define YF_VARIANT_CAM(F, NW) { F, NW, false, false, true, (fused_fn)yf::yoloface56_fused<F, NW, false, true>, yf::lds_bytes<F, NW, false>(), \
-                                yf::scratch_bytes_per_frame_slot<F, NW, false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input>" }
-#define YF_VARIANT_X(F, NW) { F, NW, false, true, false, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<F, NW, false>(), \
+                                yf::scratch_bytes_per_frame_slot<false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input>" }
+#define YF_VARIANT_X(F, NW) { F, NW, false, true, false, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<false>(), \
                               "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
 // production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
 const Variant k_variants[] = {

@@ -1393,175 +1393,6 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
     prev = next;
   }
 }
-#if YF_H0 == 56
-// ------------------------------------------------------------------------------------------------ the 7x7 tail: one frame per WAVE, no barriers
-// Behind conv2d_27 every map is 7 x 7 -- 49 pixels, ONE lane-private tile.  As barrier-separated workgroup stages the twelve layers conv2d_29 ..
-// conv2d_53 were twelve latency chains with 4-20 jobs for 8 waves: 46 k cycles per four frames in round 3's tail batching, 29 % of the kernel.  Here a
-// wave owns a whole frame: lane = pixel.  A lane-private pass leaves four output channels of the lane's pixel in the lane's own accumulator, so a 1x1
-// layer's requantised bytes, packed four to a dword, ARE the next 1x1 layer's B operand: the chain runs in registers, with no LDS round trip and no
-// barrier.  Only the three depthwise 3x3 layers need other pixels: the wave writes its 40-channel input into a PRIVATE exchange buffer (T19's halo'd
-// layout, 3.2 KB; the halo ring holds the layer's zero point) and reads the nine taps back -- LDS operations of one wave execute in order.
-// The workgroup runs the front stages of NW / F groups one after the other (each frame leaves {pool_25 | conv2d_27} = 49 x 48 bytes in a park slot in
-// HBM), then ONE tail phase: the constant blocks of the twelve tail stages (17.5 KB, contiguous in the table) become resident in LDS behind the NW
-// exchange buffers, and wave w runs the tail of the batch's frame w, copies its head out and decodes its boxes.  Same arithmetic, same tables: bit-exact.
-#ifndef YF_CHAIN_ILP
-#define YF_CHAIN_ILP 2
-#endif
-typedef Buf<0, 7, 7, 40, 9, 1, 1, 0, YF_ROW_SKEW> XT;           // a wave's exchange buffer
-constexpr int XB = (9 * XT::ROWB + 15) & ~15;                    // bytes per wave (the staged head of the wave's frame reuses it behind conv2d_49)
-// a frame's park slot: the two tail inputs as they lie in LDS -- concat_46's buffer (49 x 48 bytes: the pool half in the first 24 of a pixel) and conv2d_27's
-// output (49 x 32 bytes, 24 used) -- so that the copy is 245 contiguous 16-byte vectors per frame
-constexpr int PARK_T30 = 49 * 48, PARK_T17 = 49 * 32, PARK_BYTES = PARK_T30 + PARK_T17;
-static_assert(PARK_T30 % 16 == 0 && PARK_T17 % 16 == 0, "whole vectors");
-constexpr int TC_CS0 = 12, TC_BYTES = PLAN.vb_off[YF_N_CS - 1] + PLAN.vb_bytes[YF_N_CS - 1] - PLAN.vb_off[TC_CS0];
-constexpr bool tc_contiguous() { for (int cs = TC_CS0; cs + 1 < YF_N_CS; ++cs) if (PLAN.vb_off[cs] + PLAN.vb_bytes[cs] != PLAN.vb_off[cs + 1]) return false; return true; }
-static_assert(tc_contiguous() && TC_BYTES % 16 == 0 && XB % 16 == 0, "the tail's constant blocks are one contiguous, aligned piece of the table");
-// tail-phase LDS layout, byte offsets from the start of the frame arenas: [NW exchange buffers][constant blocks of const-stages 12..23][decode tables]
-template <int NW> struct TailLay { static constexpr int TC = NW * XB, DT = TC + TC_BYTES, END = DT + 2048; };
-struct TailLane { uint32_t a_on3, a_step1; int xb, tapb, halo; bool a_on; };   // per-lane constants: (c & 3) or the zero region, row step 1 or 0, exchange buffer, tap base, halo pixel
-// LDS-DMA of the twelve constant blocks and of the decode's two tables; the compiler does not see it: YF_SYNC follows
-template <int NW>
-__device__ __forceinline__ void fetch_tail_consts(const uint8_t* __restrict__ tab, uint32_t lds0, int wave, int lane, bool decode) {
-  constexpr int NCHUNK = (TC_BYTES + 1023) / 1024;
-  for (int j = wave; j < NCHUNK + 2; j += NW) {
-    const int off = j * 1024 + lane * 16;
-    const uint8_t* src; uint32_t dst;
-    if (j < NCHUNK) { if (off >= TC_BYTES) continue; src = tab + PLAN.vb_off[TC_CS0] + off; dst = lds0 + TailLay<NW>::TC + j * 1024; }
-    else { if (!decode) continue; src = reinterpret_cast<const uint8_t*>(j == NCHUNK ? yfdec::d_sig_bits : yfdec::d_exp_bits) + 16 * lane; dst = lds0 + TailLay<NW>::DT + (j - NCHUNK) * 1024; }
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-  }
-}
-// A layer's packed outputs come out of join4 (inline assembly) and feed the next layer's MFMAs as B operands: hipcc pads the VALU-write -> MFMA-read
-// hazard only for instructions it selects itself, so every layer ends with the wait states itself (behind its last scheduling barrier: nothing moves across)
-__device__ __forceinline__ void layer_end() { asm volatile("s_nop 4" ::: "memory"); }
-// 1x1 layer of const-stage CS on the lane's pixel.  in: NI packed dwords (the layer's input channels in the order of its weight rows; k-slots past
-// them have zero weights); out: the packed results from dword O0 on.  TC = absolute LDS address of the resident blocks.
-template <int TC, int CS, int KS, int COUT, int EPI, int LUT_ID, int O0, int NI, int NO, int NA>
-__device__ __forceinline__ void dense_reg(const TailLane& L, const uint8_t* __restrict__ tab, const uint32_t (&in)[NI], uint32_t (&out)[NO], const uint32_t (&add)[NA],
-                                          const AddK ad, int headp) {
-  constexpr int NP = (COUT + 3) / 4, KROW = 16 * KS;
-  constexpr int BLK = TC + PLAN.vb_off[CS] - PLAN.vb_off[TC_CS0], WB = plan_wbytes(CS), PV = BLK + WB, LA = PV + NP * (int)sizeof(yf_pass_v);
-  static_assert(yf_cs_dense[CS] >= 0 && KROW == PLAN_KROW[yf_cs_dense[CS]] && NP == plan_passes(CS) && NI <= 4 * KS && NI > 4 * (KS - 1), "layer and constant block agree");
-  static_assert((EPI == EPI_ADD) == (yf_cs_add[CS] >= 0) && (EPI == EPI_HEAD_LDS || O0 + NP <= NO) && (EPI != EPI_ADD || NA == NP), "operands");
-  const uint32_t a_lane = L.a_on ? (uint32_t)BLK + L.a_on3 * KROW : (uint32_t)ZERO;
-  const uint8_t* sc = tab + PLAN.sb_off[CS];
-  v4i b[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[ks][e] = (4 * ks + e < NI) ? (int)in[4 * ks + e] : any_value();
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const uint32_t a_addr = a_lane + L.a_step1 * (uint32_t)(ps * 4 * KROW);
-    v4i acc = {ACC0, ACC0, ACC0, ACC0};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds_v4i(a_addr + 16 * ks), b[ks], acc, 0, 0, 0);
-    const v4u m2 = lds_v4u((uint32_t)(PV + ps * 32)), zr = lds_v4u((uint32_t)(PV + ps * 32 + 16));
-    const uint8_t* s = sc + ps * (int)sizeof(yf_pass_s);
-    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
-    int idx[4];
-    requant4<true>(acc, m2, zr, k.c64, k.rs, idx);
-    if constexpr (EPI == EPI_LUT) out[O0 + ps] = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
-    else if constexpr (EPI == EPI_RAW) out[O0 + ps] = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-    else if constexpr (EPI == EPI_ADD) {
-      typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
-      const uint32_t o = add[ps] ^ 0x80808080u;
-      v4i sum;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sum[j] = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255)) + *(lds_i32_ptr)(uint32_t)(LA + 1024 + 4 * idx[j]);
-      int r[4];
-      requant4<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro}, v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
-      out[O0 + ps] = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
-    } else {   // the head: 18 bytes per pixel, staged in the wave's exchange buffer (2-byte granules)
-      typedef __attribute__((address_space(3))) uint16_t* lds_u16w_ptr;
-      const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-      *(lds_u16w_ptr)(uint32_t)(headp + 4 * ps) = (uint16_t)v;
-      if (4 * ps + 2 < 18) *(lds_u16w_ptr)(uint32_t)(headp + 4 * ps + 2) = (uint16_t)(v >> 16);
-    }
-    if (ps % YF_CHAIN_ILP == YF_CHAIN_ILP - 1 || ps == NP - 1) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP passes at a time: left alone the scheduler hoists every later pass's loads (250 live registers, 230 spilled at the 128 cap)
-  }
-  layer_end();
-}
-// depthwise 3x3 (stride 1, 40 channels) of const-stage CS: halo ring := zp, the lane's pixel into the exchange buffer, nine taps back per 4-channel group
-template <int TC, int CS, int LUT_ID>
-__device__ __forceinline__ void dw_reg(const TailLane& L, const uint8_t* __restrict__ tab, int zp, const uint32_t (&in)[10], uint32_t (&out)[10], int lane) {
-  typedef __attribute__((address_space(3))) uint32_t* lds_u32w_ptr;
-  constexpr int BLK = TC + PLAN.vb_off[CS] - PLAN.vb_off[TC_CS0], TS = XT::S, TR = XT::ROWB;
-  static_assert(yf_cs_dw[CS] >= 0 && plan_passes(CS) == 10, "a 40-channel depthwise block");
-  if (lane < 32) {
-    const uint32_t v = (uint32_t)(zp & 255) * 0x01010101u;
-#pragma unroll
-    for (int d = 0; d < 10; ++d) *(lds_u32w_ptr)(uint32_t)(L.halo + 4 * d) = v;
-  }
-#pragma unroll
-  for (int d = 0; d < 10; ++d) *(lds_u32w_ptr)(uint32_t)(L.tapb + TR + TS + 4 * d) = in[d];
-  const uint32_t a_lane = L.a_on ? (uint32_t)BLK + 4 * L.a_on3 : (uint32_t)ZERO;
-  const uint8_t* sc = tab + PLAN.sb_off[CS];
-#pragma unroll
-  for (int cg = 0; cg < 10; ++cg) {
-    const uint32_t wa = a_lane + L.a_step1 * (uint32_t)(cg * YF_DWV_GROUP_BYTES);
-    const v4i a0 = {(int)*(lds_u32_ptr)(wa), (int)*(lds_u32_ptr)(wa + 16), (int)*(lds_u32_ptr)(wa + 32), (int)*(lds_u32_ptr)(wa + 48)};
-    const v4i a1 = {(int)*(lds_u32_ptr)(wa + 64), (int)*(lds_u32_ptr)(wa + 80), (int)*(lds_u32_ptr)(wa + 96), (int)*(lds_u32_ptr)(wa + 112)};
-    v4i a2 = {0, 0, 0, 0}; a2[0] = (int)*(lds_u32_ptr)(wa + 128);
-    const uint32_t t0 = (uint32_t)(L.tapb + 4 * cg);
-    const v4i b0 = {(int)*(lds_u32_ptr)(t0), (int)*(lds_u32_ptr)(t0 + TS), (int)*(lds_u32_ptr)(t0 + 2 * TS), (int)*(lds_u32_ptr)(t0 + TR)};
-    const v4i b1 = {(int)*(lds_u32_ptr)(t0 + TR + TS), (int)*(lds_u32_ptr)(t0 + TR + 2 * TS), (int)*(lds_u32_ptr)(t0 + 2 * TR), (int)*(lds_u32_ptr)(t0 + 2 * TR + TS)};
-    const v4i b2 = {(int)*(lds_u32_ptr)(t0 + 2 * TR + 2 * TS), any_value(), any_value(), any_value()};
-    v4i acc = {ACC0, ACC0, ACC0, ACC0};
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-    const v4u m2 = lds_v4u((uint32_t)(BLK + cg * YF_DWV_GROUP_BYTES + 144)), zr = lds_v4u((uint32_t)(BLK + cg * YF_DWV_GROUP_BYTES + 160));
-    const uint8_t* s = sc + cg * (int)sizeof(yf_pass_s);
-    const PassS k = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
-    int idx[4];
-    requant4<true>(acc, m2, zr, k.c64, k.rs, idx);
-    out[cg] = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
-    if (cg % YF_CHAIN_ILP == YF_CHAIN_ILP - 1 || cg == 9) __builtin_amdgcn_sched_barrier(0);       // YF_CHAIN_ILP channel groups at a time (see dense_reg)
-  }
-  layer_end();
-}
-// The tail of ONE frame on ONE wave.  TP0: absolute LDS address of the tail-phase area (the frame arenas); park: the frame's slot.  Returns with the
-// frame's 882 head bytes staged at the start of the wave's exchange buffer.
-template <int NW, int TP0>
-__device__ __forceinline__ void tail_chain(int wave, int lane, const uint8_t* __restrict__ tab, const char* __restrict__ park, const AddK ad35, const AddK ad41) {
-  constexpr int TC = TP0 + TailLay<NW>::TC;
-  const int g = lane >> 4, c = lane & 15;
-  const int p = min(lane, 48), y = DivW<7>::div(p), x = p - 7 * y;                  // lanes 49..63 redo pixel 48 (same values, same addresses)
-  TailLane L;
-  L.a_on = (c >> 2) == g; L.a_on3 = (uint32_t)(c & 3); L.a_step1 = L.a_on ? 1u : 0u;
-  asm("" : "+v"(L.a_step1));                                                          // opaque: a fragment address stays one multiply-add
-  L.xb = TP0 + wave * XB; L.tapb = L.xb + y * XT::ROWB + x * XT::S;
-  L.halo = L.xb + (int)HaloGeo<XT, true, 1>::entry(min(lane, 31));
-  uint32_t cat[12], t17[6];                                                           // concat_46: [pool_25 | conv2d_42]; conv2d_27's output
-  {
-    typedef const __attribute__((address_space(1))) v2u* glb_v2u_p;                    // (written by other waves of this workgroup: past the vector L1)
-    const glb_v2u_p pa = (glb_v2u_p)(uintptr_t)(park + p * 48), pb = (glb_v2u_p)(uintptr_t)(park + PARK_T30 + p * 32);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const v2u u = __builtin_nontemporal_load(pa + q), w = __builtin_nontemporal_load(pb + q);
-      cat[2 * q] = u[0]; cat[2 * q + 1] = u[1]; t17[2 * q] = w[0]; t17[2 * q + 1] = w[1];
-    }
-  }
-  const uint32_t none[1] = {0u};
-  const AddK no_add = {};
-  uint32_t t18[2], t19[10], t20[10], t22[2], t26[2], t33[8];
-  dense_reg<TC, 12, 2,  8, EPI_RAW, 0,            0>(L, tab, t17, t18, none, no_add, 0);                                  // conv2d_29
-  dense_reg<TC, 13, 1, 40, EPI_LUT, YF_L_LEAKY31, 0>(L, tab, t18, t19, none, no_add, 0);                                  // conv2d_30
-  dw_reg<TC, 14, YF_L_LEAKY33>(L, tab, load_halo_zp(tab, YF_W_DW32), t19, t20, lane);                                     // conv2d_32
-  dense_reg<TC, 15, 3,  8, EPI_ADD, YF_A_ADD35,   0>(L, tab, t20, t22, t18, ad35, 0);                                     // conv2d_34 + eltwise_35
-  dense_reg<TC, 16, 1, 40, EPI_LUT, YF_L_LEAKY37, 0>(L, tab, t22, t19, none, no_add, 0);                                  // conv2d_36
-  dw_reg<TC, 17, YF_L_LEAKY39>(L, tab, load_halo_zp(tab, YF_W_DW38), t19, t20, lane);                                     // conv2d_38
-  dense_reg<TC, 18, 3,  8, EPI_ADD, YF_A_ADD41,   0>(L, tab, t20, t26, t22, ad41, 0);                                     // conv2d_40 + eltwise_41
-  dense_reg<TC, 19, 1, 24, EPI_LUT, YF_L_L43Q44,  6>(L, tab, t26, cat, none, no_add, 0);                                  // conv2d_42 -> concat_46[24,48)
-  dense_reg<TC, 20, 3, 40, EPI_LUT, YF_L_LEAKY48, 0>(L, tab, cat, t19, none, no_add, 0);                                  // conv2d_47
-  dw_reg<TC, 21, YF_L_LEAKY50>(L, tab, load_halo_zp(tab, YF_W_DW49), t19, t20, lane);                                     // conv2d_49
-  dense_reg<TC, 22, 3, 32, EPI_LUT, YF_L_LEAKY52, 0>(L, tab, t20, t33, none, no_add, 0);                                  // conv2d_51
-  dense_reg<TC, 23, 2, 18, EPI_HEAD_LDS, 0,       0>(L, tab, t33, t33, none, no_add, L.xb + p * 18);                      // conv2d_53 -> the staged head
-}
-#endif
 }  // namespace v2
 #ifndef YF_GENERIC
 
@@ -1621,7 +1452,10 @@ constexpr int STAGE_PRIO[27] = {YF_PRIO_LIST};
 template <int K> __device__ __forceinline__ void stage_prio() {
   if constexpr (K == 0 || STAGE_PRIO[K] != STAGE_PRIO[K - 1]) __builtin_amdgcn_s_setprio(STAGE_PRIO[K]);
 }
-template <bool DUMP> constexpr bool wave_tail() { return !DUMP && YF_V2; }
+#ifndef YF_TAIL_BATCH
+#define YF_TAIL_BATCH 1
+#endif
+template <bool DUMP> constexpr bool tail_batch() { return !DUMP && (YF_TAIL_BATCH); }
 
 // CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
 // preparation runs inside the input staging (stage_input_cam).
@@ -1629,21 +1463,19 @@ template <int F, int NW, bool DUMP, bool CAM = false>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
-  constexpr bool WTAIL = wave_tail<DUMP>();              // production builds: the 7x7 tail runs one frame per wave (v2::tail_chain); debug builds keep it staged
-  constexpr bool BATCH = false;                          // (the staged tail's buffers: one set per frame arena)
-  constexpr int FT = F;                                  // frames per staged tail run
-  typedef TailBufs<FRAME_BYTES> U;
-  constexpr int OUT_ALL_BYTES = WTAIL ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // the wave-private tail stages a head in its wave's exchange buffer
+  constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
+  constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
+  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
 #if YF_V2
-  constexpr int PRE = v2::pre_bytes<F, false>();         // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
+  constexpr int PRE = v2::pre_bytes<F, tail_batch<DUMP>()>();   // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
 #else
   constexpr int PRE = LUT_BYTES;                         // LUTs | residual-add tables
 #endif
   char* out_all = smem + PRE;
   char* frames = smem + PRE + OUT_ALL_BYTES;
-  constexpr int NB = NW / F;                             // WTAIL: groups per batch (one tail phase per NB groups: a wave per frame)
-  int batch_groups = 0;                                  // groups of the current batch whose park slots are written
+  long parked_first = -1;                                // first frame of the group whose T15 waits in the scratch
   const int tid0 = threadIdx.x;
   const uint8_t* __restrict__ tab = prm.tab;
   int vz = 0;
@@ -1661,14 +1493,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + F * FRAME_BYTES;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
   if constexpr (DUMP) { if (tid0 < YF_DBG_LUT_BYTES / 16) reinterpret_cast<uint4*>(smem + DBG_LUT)[tid0] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off + YF_N_LUT * 256 + YF_ADDLUT_BYTES)[tid0]; }
   {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
-    typedef v2::JobTabs<F, false> JTS;
+    typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
     typedef typename JTS::U UT;
     v2::fill_jobtab<F, 1, B_T1, B_T2, JTS::JT_DW3>(smem, tid0);
     v2::fill_jobtab<F, 2, B_T4, B_T6, JTS::JT_DW10>(smem, tid0);
     v2::fill_jobtab<F, 1, B_T8, B_T9, JTS::JT_DW15>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 2, typename UT::T15, typename UT::T17, JTS::JT_DW27>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 1, typename UT::T19, typename UT::T20, JTS::JT_DW32>(smem, tid0);
-    typedef v2::HaloTabs<F, false> HTS;                    // halo pixel lists of the five depthwise inputs
+    typedef v2::HaloTabs<F, tail_batch<DUMP>()> HTS;       // halo pixel lists of the five depthwise inputs
     v2::build_halotab<typename HTS::G1, HTS::H_T1, NT>(smem, tid0);
     v2::build_halotab<typename HTS::G4, HTS::H_T4, NT>(smem, tid0);
     v2::build_halotab<typename HTS::G8, HTS::H_T8, NT>(smem, tid0);
@@ -1750,7 +1582,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     const long first = grp * F;
 #ifdef YF_BARPROF
     bar_no = 0;
-    prof_on = !DUMP && prm.dump != nullptr && grp == (long)blockIdx.x + (WTAIL ? NB - 1 : 1) * (long)gridDim.x;   // WTAIL: the group that closes the first batch (its tail phase follows)
+    prof_on = !DUMP && prm.dump != nullptr && grp == (long)blockIdx.x + gridDim.x;
 #endif
     // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
     // results in VGPRs for the whole kernel.  YF_LAUNDER selects stage groups (1 front 28x28, 2 middle 14x14, 4 tail
@@ -1846,20 +1678,63 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     YF_PRIO(13);
+    // BATCH: the parked group's T15 goes from the scratch straight into the odd tail sets by LDS-DMA (no registers), issued
+    // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through.  The wait that guards it is the explicit
+    // s_waitcnt vmcnt(0) in front of the barrier behind conv2d_23 (this toolchain also waits at conv2d_23's first LDS access: its
+    // alias analysis cannot tell the DMA's destination from the stage's buffers, so the transfer overlaps less than it could).
+    // One wave-instruction moves 64 x 16 contiguous bytes.
+    if constexpr (BATCH) {
+      if (parked_first >= 0) {
+        constexpr int PV = TailBufs<FRAME_BYTES>::T15_BYTES / 16, WI = (PV + 63) / 64;      // vectors / wave-instructions per frame
+        const char* park = prm.scratch + (long)blockIdx.x * (F * PV * 16);
+        for (int j = W_m; j < F * WI; j += NW) {
+          const int f = j / WI, k0 = (j - f * WI) * 64;
+          if (k0 + L_m < PV)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(park + (f * PV + k0 + L_m) * 16),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(PRE + (2 * f + 1) * U::T15::FS + 16 * k0),
+                                             16, 0, 0);
+        }
+      }
+    }
     YF_HALO(B_T15, false, F, G15, H_T15, YF_W_DW27, tid_m);
     YF_FETCH(11, W_m, L_m);
     YF_DENSE(F, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
+    if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
-    // ---- the 7x7 tail.  pool_25 and conv2d_27 still read other pixels (T15): they run here, as a workgroup stage.  Production builds (WTAIL) then
-    // copy their outputs -- the two inputs of the rest of the tail -- to the frames' park slots and go on with the next group; after NB groups the
-    // tail phase below runs conv2d_29 .. conv2d_53 of the batch's NW frames, one frame per wave.  Debug builds run the staged tail right here.
-    auto frame_of = [&](int f) -> long { const long id = first + f; return id < prm.n ? id : -1; };
+    // ---- the 7x7 tail.  BATCH: it runs once per PAIR of groups on FT = 2F frames.  Its thirteen stages are latency chains
+    // (98 pixels per group: one or two jobs per wave), so twice the jobs per stage cost far less than twice the time.  The
+    // first group of a pair parks its T15 (5.4 KB per frame) in a per-workgroup HBM scratch and skips the tail; the second
+    // group fetches it back into the odd tail sets -- set f of the tail sits at f * FRAME_BYTES / 2, so the even sets ARE the
+    // arenas' own T15 -- and runs the tail for both.  A workgroup's last group runs the tail alone when it has no partner.
+    long odd_first = -1;                          // first frame of the odd sets (the parked group), -1: none
+    if constexpr (BATCH) {
+      constexpr int V = U::T15_BYTES / 16;
+      uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * (F * V);
+      if (parked_first < 0 && grp + gridDim.x < n_groups) {
+        for (int i = tid_t; i < F * V; i += NT) {
+          const int f = i / V, k = i - f * V;
+          park[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_BYTES + 16 * k);
+        }
+        parked_first = first;
+        continue;
+      }
+      if (parked_first >= 0) {                  // its T15 is already in the odd sets (LDS-DMA issued before conv2d_23)
+        odd_first = parked_first;
+        parked_first = -1;
+      }
+    }
+    // frame number of tail set f (BATCH: even sets = this group, odd sets = the parked one), -1 = nothing to write
+    auto frame_of = [&](int f) -> long {
+      long id = first + f;
+      if constexpr (BATCH) id = (f & 1) ? (odd_first >= 0 ? odd_first + (f >> 1) : -1) : first + (f >> 1);
+      return id < prm.n ? id : -1;
+    };
 #define YF_DUMP_T(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
     YF_PRIO(14);
 #if YF_V2
-    if constexpr (!WTAIL) YF_FETCH(12, W_t, L_t);
+    YF_FETCH(12, W_t, L_t);
     {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
       constexpr int PW = v2::pool25_waves<FT>();
       static_assert(PW < NW, "waves left for conv2d_27");
@@ -1873,52 +1748,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #endif
     YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T30, 24, P25, 24) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
-    if constexpr (WTAIL) {
-#if YF_V2 && YF_H0 == 56
-      {   // park: concat_46's buffer and conv2d_27's output of every frame as they lie in LDS, slot = (group of the batch, frame of the group)
-        static_assert(U::T30::S == 48 && U::T17::S == 32 && U::T30::OFF % 16 == 0 && U::T17::OFF % 16 == 0 && FRAME_BYTES % 16 == 0, "the park slot mirrors the two buffers");
-        constexpr int V = v2::PARK_BYTES / 16, VA = v2::PARK_T30 / 16;
-        uint4* slots = reinterpret_cast<uint4*>(prm.scratch + ((long)blockIdx.x * NW + batch_groups * F) * v2::PARK_BYTES);
-        for (int i = tid_t; i < F * V; i += NT) {
-          const int f = i / V, r = i - f * V;
-          slots[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_BYTES + (r < VA ? U::T30::OFF + 16 * r : U::T17::OFF + 16 * (r - VA)));
-        }
-      }
-      ++batch_groups;
-      if (batch_groups < NB && grp + gridDim.x < n_groups) continue;
-      // ---- tail phase: the batch's groups are grp - (batch_groups - 1 - gi) * gridDim.x, gi = 0 .. batch_groups - 1; wave w takes slot w
-      YF_PRIO(14);
-      constexpr int TP0 = PRE + OUT_ALL_BYTES;
-      YF_SYNC();                                   // park slots written (vmcnt), every arena dead
-      v2::fetch_tail_consts<NW>(tab, (uint32_t)TP0, W_t, L_t, prm.dets != nullptr);
-      YF_SYNC();
-      {
-        int lt = L_t;
-        asm volatile("" : "+v"(lt));               // the chain's per-lane constants are computed here, not hoisted to the kernel's entry (and spilled)
-        const int gi = W_t / F, f = W_t - gi * F;
-        const long id = gi < batch_groups ? (grp - (long)(batch_groups - 1 - gi) * gridDim.x) * F + f : -1;
-        if (id >= 0 && id < prm.n) {
-          v2::tail_chain<NW, TP0>(W_t, lt, tab, prm.scratch + ((long)blockIdx.x * NW + W_t) * v2::PARK_BYTES, addctx(YF_A_ADD35), addctx(YF_A_ADD41));
-          // the frame's 882 head bytes: exchange buffer -> HBM (2-byte granules), then its boxes
-          const char* hl = smem + TP0 + W_t * v2::XB;
-          uint16_t* dst = reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES);
-          for (int i = lt; i < OUT_FRAME_BYTES / 2; i += 64) dst[i] = *reinterpret_cast<const uint16_t*>(hl + 2 * i);
-          if (prm.dets != nullptr)
-            yfdec::decode_frame_lds(reinterpret_cast<const int8_t*>(hl), id, lt, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap,
-                                    (uint32_t)(TP0 + v2::TailLay<NW>::DT), prm.q_thr);
-        }
-      }
-      batch_groups = 0;
-#ifdef YF_BARPROF
-      YF_SYNC();                                   // profiling builds: the end of the chain as a barrier record
-#endif
-      continue;                                    // (the barrier at the top of the group loop guards the arenas)
-#endif
-    }
     YF_PRIO(15);
     YF_FETCH(13, W_t, L_t);
     YF_DENSE(FT, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18, YF_D_C29, no_add, W_t, L_t, 12);   // conv2d_29
-    decode_prev(W_t, L_t);                                                                          // previous group's boxes
+    if constexpr (!BATCH) decode_prev(W_t, L_t);                                                    // previous group's boxes
     YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
     YF_STAGE_END()
     YF_PRIO(16);
@@ -1986,11 +1819,22 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(25);
     YF_FETCH(23, W_t, L_t);
+    // the decode's two look-up tables (2 KB) -> the first bytes of the frame arenas, dead since conv2d_47 (T15 / T30 of set 0), two stages ahead of
+    // the decode: the barrier behind this stage waits for the transfer, the one behind conv2d_53 would do so on the critical path
+    if (BATCH && prm.dets != nullptr && W_t < 2) {
+      int dl = L_t;
+      asm volatile("" : "+v"(dl));
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(W_t == 0 ? yfdec::d_sig_bits : yfdec::d_exp_bits) + 16 * dl;
+      const uint32_t dst = (uint32_t)(PRE + OUT_ALL_BYTES + 1024 * W_t);
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
     YF_DENSE(FT, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33, YF_D_C51, no_add, W_t, L_t, 22);   // conv2d_51
     YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
     YF_STAGE_END()
     YF_PRIO(26);
-    {
+    if constexpr (!BATCH) {
       YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
       YF_SYNC();
       // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
@@ -2000,10 +1844,34 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       const uint16_t* srcp = reinterpret_cast<const uint16_t*>(out_all);
       for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
       prev_first = first;
+    } else {
+      YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::HEAD, 0, 18, EPI_HEAD_LDS, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
+      YF_SYNC();
+      // heads: 882 bytes per frame from its set -> HBM, 2-byte granules; the boxes of set w are decoded by wave w meanwhile
+      constexpr int H16 = OUT_FRAME_BYTES / 2;
+      // with a decode the first FT waves decode (one frame each) while the other waves copy the heads; without one every wave copies
+      const bool split = prm.dets != nullptr && FT < NW;
+      const int c0 = split ? tid_t - FT * 64 : tid_t, cstep = split ? NT - FT * 64 : NT;
+      if (!split || W_t >= FT) {
+        for (int i = c0; i < FT * H16; i += cstep) {
+          const int f = i / H16, k = i - f * H16;
+          const long id = frame_of(f);
+          if (id >= 0) reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES)[k] = *reinterpret_cast<const uint16_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF + 2 * k);
+        }
+      }
+      for (int f = W_t; f < FT; f += NW) {
+        const long id = frame_of(f);
+        if (prm.dets != nullptr && id >= 0) {
+          int dl = L_t;
+          asm volatile("" : "+v"(dl));
+          yfdec::decode_frame_lds(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap,
+                                  (uint32_t)(PRE + OUT_ALL_BYTES), prm.q_thr);
+        }
+      }
     }
 #undef YF_DUMP_T
   }
-  if constexpr (!WTAIL) {   // boxes of this workgroup's last group
+  if constexpr (!BATCH) {   // boxes of this workgroup's last group
     const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     decode_prev(wave, lane);
   }
@@ -2019,23 +1887,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() {
-#if YF_V2
-  constexpr size_t arenas = (size_t)F * FRAME_BYTES, tailp = wave_tail<DUMP>() ? (size_t)v2::TailLay<NW>::END : 0;     // the tail phase lives on the (dead) frame arenas
-  return (size_t)v2::pre_bytes<F, false>() + (wave_tail<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (arenas > tailp ? arenas : tailp) + (DUMP ? YF_DBG_LUT_BYTES : 0);
-#else
-  return (size_t)LUT_BYTES + ((F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES;
-#endif
-}
-// park slots of the wave-private tail: NW per workgroup (bytes per workgroup / F: the engine multiplies by the grid and F)
-template <int F, int NW, bool DUMP>
-constexpr size_t scratch_bytes_per_frame_slot() {
-#if YF_V2
-  return wave_tail<DUMP>() ? (size_t)NW * v2::PARK_BYTES / F : 0;
-#else
-  return 0;
-#endif
-}
+constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::pre_bytes<F, tail_batch<DUMP>()>() : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES + (DUMP ? YF_DBG_LUT_BYTES : 0); }
+template <bool DUMP>
+constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 
 #else   // YF_GENERIC
 // ------------------------------------------------------------------------------------------------ layer-by-layer form

@@ -29,11 +29,11 @@ span = leave[:, :, -1] - leave[:, :, 0]
 print(f"{wgs} workgroups x {nw} waves, {nb} barriers per group; cycles from the first to the last barrier of a group: "
       f"mean {span.mean():.0f} (min {span.min():.0f} max {span.max():.0f})")
 print(f"working {100 * body.sum(axis=2).mean() / span.mean():.1f}%  waiting in barriers {100 * wait[:, :, 1:].sum(axis=2).mean() / span.mean():.1f}%")
-# the profiled group is the one that closes the workgroup's first batch: its front stages, the pool_25 + conv2d_27 stage, then the two barriers of the
-# tail phase (park slots written / constants resident) and -- as the time up to the NEXT group's top barrier, which is not recorded -- nothing more:
-# the chain's duration is printed from the last recorded barrier to the end of the kernel's timeline where available
-labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_10 (dw)"] + [f"{nm}" for nm in NAMES[7:13]] + \
-         ["pool_25 + conv2d_27 (dw)", "park copy -> tail phase barrier 1", "constants resident (barrier 2)", "tail chain + head + decode (to the next top-of-loop barrier)"]
+labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_10 (dw)"] + [f"{nm}" for nm in NAMES[7:]]
+# tail batching: the profiled (second) group of a workgroup fetches the parked group's T15 behind conv2d_23 and then runs the
+# tail for four frames; its interval times are per PAIR of groups
+k23 = next(i for i, nm in enumerate(labels) if nm.startswith("conv2d_23"))
+labels = labels[:k23 + 1] + [nm + "   [4 frames]" for nm in labels[k23 + 1:]]    # the parked T15 returns by LDS-DMA during conv2d_23
 print(f"{'interval ending at barrier':44s} {'work mean':>10s} {'slowest':>9s} {'wait mean':>10s}   work per wave")
 for i in range(1, nb):
     b, w = body[:, :, i], wait[:, :, i]
