@@ -606,33 +606,55 @@ __device__ __forceinline__ uint2 tap64(int a) {               // one ds_read_b64
   const v2u_t v = *(const volatile __attribute__((address_space(3))) v2u_t*)(uintptr_t)(uint32_t)a;
   return uint2{v.x, v.y};
 }
-struct TailLane { int scale, c3, zb, tapb; bool a_on; };       // per-lane constants of the tail: fragment selector, zero spot, tap base, ...
-// 1x1 layer K on the lane's pixel: in = NI packed dwords (8 channels per k-step), out = the layer's packed outputs from dword O0 on
+struct TailLane { int scale, c3, zb, tapb; bool a_on; int base32, scale32; };       // per-lane constants of the tail: fragment selectors (16x16 and 32x32 forms), zero spot, tap base
+typedef float v16f __attribute__((ext_vector_type(16)));
+// 1x1 layer K on the lane's pixel: in = NI packed dwords (8 channels per k-step), out = the layer's packed outputs from dword O0 on.
+// The chain is bound by the LDS pipe -- every MFMA of the sixteen waves of a CU wants its own 1 KB A fragment -- so the 1x1 layers use the 32x32x16 form
+// here: lane (kb = lane / 32, i = lane % 32) supplies k-slots 8 kb .. 8 kb + 7 from its own pixel, A row i carries W[16 q + 4 (i >> 3) + (i & 3)] in the slots
+// of block ((i >> 2) & 1) only, and the lane's sixteen accumulators are output channels 16 q .. 16 q + 15 of its pixel: SIXTEEN channels per fragment read
+// instead of four (conv2d_47: 18 fragments and MFMAs instead of 60).  Same products, same k-step order: bit for bit the results of the 16x16x32 form
+// (tools/probe/mfma_f16_shapes.hip: 0 of 2 048 000 results differ).  Rows past the layer's channels read whatever follows the block: they only reach
+// accumulators that are never stored.
 template <int NW, int K, int KS, int COUT, int EPI, int O0, int NI, int NO, int NA>
 __device__ __forceinline__ void dense_reg(const TailLane& L, const uint32_t (&in)[NI], uint32_t (&out)[NO], const uint32_t (&add)[NA], float* __restrict__ head) {
-  constexpr int NP = (COUT + 3) / 4, KROW = 8 * KS;
+  constexpr int NP = (COUT + 3) / 4, KROW = 8 * KS, NQ = (COUT + 15) / 16;
   static_assert(NI == 4 * KS && (EPI == EPI_HEAD || O0 + 2 * NP <= NO) && (EPI != EPI_ADD || NA == 2 * NP), "operand sizes");
   static_assert(WBYTES[K] == NP * 4 * KROW * 2 + NP * 16, "layer and weight block agree");
-  const int base = L.a_on ? tw<NW>(K) + L.c3 * (KROW * 2) : L.zb;
+  const int base = L.base32 >= 0 ? tw<NW>(K) + L.base32 * (KROW * 2) : L.zb;        // row 4 (i >> 3) + (i & 3) of the block, or the zero spot
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    const int fa = base + __mul24(L.scale, ps * (4 * KROW * 2));
-    v4f acc = __builtin_bit_cast(v4f, ld128(tb<NW>(K) + 16 * ps));
+  for (int q = 0; q < NQ; ++q) {
+    const int fa = base + __mul24(L.scale32, q * (16 * KROW * 2));
+    v16f acc;
+#pragma unroll
+    for (int v4 = 0; v4 < 4; ++v4) {
+      const v4f bq = __builtin_bit_cast(v4f, ld128(tb<NW>(K) + 64 * q + 16 * v4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * v4 + e] = bq[e];
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const v4i b = {(int)in[4 * ks], (int)in[4 * ks + 1], (int)in[4 * ks + 2], (int)in[4 * ks + 3]};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, ld128(fa + 16 * ks)), __builtin_bit_cast(v8h, b), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, ld128(fa + 16 * ks)), __builtin_bit_cast(v8h, b), acc, 0, 0, 0);
     }
-    if constexpr (EPI == EPI_HEAD) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (4 * ps + q < COUT) head[4 * ps + q] = acc[q];
-    } else {
-      if constexpr (EPI == EPI_ADD) {
-        v2h r0, r1; __builtin_memcpy(&r0, &add[2 * ps], 4); __builtin_memcpy(&r1, &add[2 * ps + 1], 4);
-        acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
+    for (int v4 = 0; v4 < 4; ++v4) {
+      const int ps = 4 * q + v4;
+      if (ps < NP) {
+        float c0 = acc[4 * v4], c1 = acc[4 * v4 + 1], c2 = acc[4 * v4 + 2], c3 = acc[4 * v4 + 3];
+        if constexpr (EPI == EPI_HEAD) {
+          if (4 * ps + 0 < COUT) head[4 * ps + 0] = c0;
+          if (4 * ps + 1 < COUT) head[4 * ps + 1] = c1;
+          if (4 * ps + 2 < COUT) head[4 * ps + 2] = c2;
+          if (4 * ps + 3 < COUT) head[4 * ps + 3] = c3;
+        } else {
+          if constexpr (EPI == EPI_ADD) {
+            v2h r0, r1; __builtin_memcpy(&r0, &add[2 * ps], 4); __builtin_memcpy(&r1, &add[2 * ps + 1], 4);
+            c0 += (float)r0[0]; c1 += (float)r0[1]; c2 += (float)r1[0]; c3 += (float)r1[1];
+          }
+          if constexpr (EPI == EPI_ACT) { out[O0 + 2 * ps] = leaky_pack2(c0, c1); out[O0 + 2 * ps + 1] = leaky_pack2(c2, c3); }
+          else { out[O0 + 2 * ps] = pack2(c0, c1); out[O0 + 2 * ps + 1] = pack2(c2, c3); }
+        }
       }
-      if constexpr (EPI == EPI_ACT) { out[O0 + 2 * ps] = leaky_pack2(acc[0], acc[1]); out[O0 + 2 * ps + 1] = leaky_pack2(acc[2], acc[3]); }
-      else { out[O0 + 2 * ps] = pack2(acc[0], acc[1]); out[O0 + 2 * ps + 1] = pack2(acc[2], acc[3]); }
     }
   }
 }
@@ -668,6 +690,13 @@ __device__ __forceinline__ void tail_chain(int xb, const char* __restrict__ park
   L.a_on = (c >> 2) == g; L.c3 = c & 3; L.zb = xb; L.tapb = xb + y * XT::ROWB + x * XT::S;
   L.scale = L.a_on ? 1 : 0;
   asm("" : "+v"(L.scale));
+  {
+    const int i = lane & 31, kb = lane >> 5;
+    const bool on32 = ((i >> 2) & 1) == kb;
+    L.base32 = on32 ? 4 * (i >> 3) + (i & 3) : -1;
+    L.scale32 = on32 ? 1 : 0;
+    asm("" : "+v"(L.scale32));
+  }
   uint32_t cat[24], t17[12];                                                          // concat_46: [pool_25 | conv2d_42]; conv2d_27's output
   {
     typedef const __attribute__((address_space(1))) v4i* glb_v4i_p;
