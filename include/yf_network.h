@@ -282,6 +282,11 @@ YF_API long yf_network_time_stages(ai_handle network, const void* d_in, void* d_
 YF_API int  yf_network_fp16_init(ai_handle network, const void* yfw, size_t bytes);
 YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, void* d_out_f32, long n, void* stream);
 /* Text of the last HIP/runtime failure (empty string if none). */
+/* Device scratch (the fused kernels' park slots, the 160x160 arena) is owned by the launch stream and bounded: at most eight regions per kind, a region
+ * whose last launch has completed is handed to the next stream that asks.  Release a stream's regions before destroying the stream; the second call
+ * reports the bytes held right now.  (The reference has one context and no streams: network.c:2929-2939.) */
+YF_API int yf_network_release_stream(ai_handle network, void* stream);
+YF_API size_t yf_network_scratch_bytes(ai_handle network);
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);
 /* Name of the kernel shape a batch of n frames runs (see yf_network_configure). */

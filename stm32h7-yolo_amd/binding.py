@@ -87,7 +87,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_last_error_text",
+           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_release_stream", "yf_network_scratch_bytes", "yf_network_last_error_text",
            "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id",
            "ai_platform_observer_node_info", "ai_platform_observer_register", "ai_platform_observer_register_s",
            "ai_platform_observer_unregister", "ai_platform_observer_unregister_s",
@@ -198,6 +198,10 @@ def load():
     lib.yf_network_fp16_init.argtypes = [vp, vp, ctypes.c_size_t]
     lib.yf_network_fp16_run_device.restype = cl
     lib.yf_network_fp16_run_device.argtypes = [vp, vp, vp, cl, vp]
+    lib.yf_network_release_stream.restype = ctypes.c_int
+    lib.yf_network_release_stream.argtypes = [vp, vp]
+    lib.yf_network_scratch_bytes.restype = ctypes.c_size_t
+    lib.yf_network_scratch_bytes.argtypes = [vp]
     lib.yf_network_last_error_text.restype = ctypes.c_char_p
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
@@ -336,6 +340,14 @@ class Network:
         self._yfw = open(path, "rb").read()
         if self.lib.yf_network_fp16_init(self.handle, self._yfw, len(self._yfw)) != 0:
             self._raise("yf_network_fp16_init")
+
+    def release_stream(self, stream):
+        """Hand the scratch regions of a stream back before destroying it (bounded per-stream scratch, include/yf_network.h)."""
+        if self.lib.yf_network_release_stream(self.handle, stream) != 0:
+            self._raise("yf_network_release_stream")
+
+    def scratch_bytes(self):
+        return int(self.lib.yf_network_scratch_bytes(self.handle))
 
     def fp16_run_device(self, d_in_f16, d_out_f32, n, stream=None):
         if self.lib.yf_network_fp16_run_device(self.handle, d_in_f16, d_out_f32, n, stream) != n:

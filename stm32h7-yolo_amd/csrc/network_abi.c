@@ -473,6 +473,21 @@ YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, 
   return n;
 }
 
+/* Scratch regions (tail-batching slots, the fp16 park slots, the 160x160 arena) belong to the launch STREAM and are bounded (at most eight per kind,
+ * recycled once their last launch has completed).  A caller that destroys a stream hands its regions back first. */
+YF_API int yf_network_release_stream(ai_handle network, void* stream) {
+  yf_context* c = acquire(network);
+  if (!c || !c->engine) return -1;
+  int rc = yf_engine_release_stream(c->engine, stream);
+  if (c->fp16 && yf_fp16_release_stream(c->fp16, stream) != 0) rc = -1;
+  return rc == 0 ? 0 : -1;
+}
+YF_API size_t yf_network_scratch_bytes(ai_handle network) {
+  yf_context* c = acquire(network);
+  if (!c || !c->engine) return 0;
+  return yf_engine_scratch_bytes(c->engine) + (c->fp16 ? yf_fp16_scratch_bytes(c->fp16) : 0);
+}
+
 YF_API const char* yf_network_last_error_text(ai_handle network) {
   yf_context* c = acquire(network);
   /* with the reference's generated network.c in front (runtime-level path) the caller's handle is ITS ai_network object,

@@ -43,6 +43,9 @@ int  yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out
                                  void* d_dets, void* d_counts, int cap, void* stream);
 /* 160x160 frames (int8 [n][160][160][3] -> [n][20][20][18]): layer-by-layer over an engine-owned HBM arena */
 int  yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n, void* stream);
+/* scratch regions are owned by launch streams (yf_stream_scratch.h): give a stream's regions back before destroying it; bytes held right now */
+int  yf_engine_release_stream(yf_engine* e, void* stream);
+size_t yf_engine_scratch_bytes(yf_engine* e);
 long yf_engine_dump_bytes(void);
 /* debug: dump build on n host frames; heads and the per-stage dump records come back to host memory (per-node observer) */
 int  yf_engine_run_host_dump(yf_engine* e, const void* h_in, void* h_out, void* h_dump, long n);

@@ -123,6 +123,8 @@ struct yf_engine {
   const Variant* var_dump = nullptr;
   void* d_in = nullptr; void* d_out = nullptr; long stage_cap = 0;
   bool layerwise160 = false;
+  long chunk160 = 1024;                          // frames per 160x160 arena chunk (289 KB per frame: 296 MB for BASELINE's 1024-frame batch; the arena is sized by the
+                                                 // actual batch).  YF_160_CHUNK overrides: 512 costs 3.5 %, 256 costs 22 % of the 1024-frame rate (three launches per chunk)
   yf_stream_scratch arena160;                    // 160x160 per-frame HBM arena, one per launch stream (yf_stream_scratch.h)
   yf_stream_scratch park; size_t park_region = 0;   // tail batching scratch of the fused kernel, one region per launch stream
   hipStream_t own_stream = nullptr;
@@ -260,11 +262,14 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   if (device < 0 || device >= ndev) return fail("device index out of range", YF_ENG_ERR_ARG);
   yf_engine* e = new yf_engine();
   e->device = device; e->ix = *ix;
-  auto bail = [&](hipError_t r, const char* what) { std::string m = std::string(what) + ": " + hipGetErrorString(r); delete e; return fail(m, YF_ENG_ERR_HIP); };
+  e->arena160.max_regions = 4;                   // at most four streams' 160x160 arenas at a time (others wait for the one used longest ago)
+  // every failure path releases what has been acquired so far (ai_network_init may be called again and again: network.c:3385-3399)
+  auto bail = [&](hipError_t r, const char* what) { std::string m = std::string(what) + ": " + hipGetErrorString(r); yf_engine_destroy(e); return fail(m, YF_ENG_ERR_HIP); };
+  auto quit = [&](const std::string& m, int code) { yf_engine_destroy(e); return fail(m, code); };
   if ((rc = hipSetDevice(device)) != hipSuccess) return bail(rc, "hipSetDevice");
   hipDeviceProp_t prop;
   if ((rc = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(rc, "hipGetDeviceProperties");
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return fail(std::string("unsupported GPU ") + prop.gcnArchName + " (this library is gfx950 only)", YF_ENG_ERR_NO_DEVICE); }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return quit(std::string("unsupported GPU ") + prop.gcnArchName + " (this library is gfx950 only)", YF_ENG_ERR_NO_DEVICE);
   e->cus = prop.multiProcessorCount;
   {   // the kernels address the tables at compiled-in offsets (yf_kernels.hip.h, TablePlan): the blob must be laid out that way
     bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
@@ -272,7 +277,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     for (int i = 0; i < YF_N_DW; ++i) same = same && (int)ix->dw[i].g_off == yf::PLAN.g_off[i];
     for (int i = 0; i < YF_N_CS; ++i)
       same = same && (int)ix->cs_v_off[i] == yf::PLAN.vb_off[i] && (int)ix->cs_v_bytes[i] == yf::PLAN.vb_bytes[i] && (int)ix->cs_s_off[i] == yf::PLAN.sb_off[i];
-    if (!same) { delete e; return fail("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG); }
+    if (!same) return quit("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG);
   }
   if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
   if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
@@ -287,20 +292,20 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     // i.e. the kernel must not have picked up any static LDS.
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, (const void*)v.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
-    if (at.sharedSizeBytes != 0) { delete e; return fail(std::string(v.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP); }
+    if (at.sharedSizeBytes != 0) return quit(std::string(v.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP);
     if ((rc = hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds)) != hipSuccess)
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
   }
   {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, (const void*)yf160::generic_stage_kernel<1, 8>)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
-    if (at.sharedSizeBytes != 0) { delete e; return fail("generic stage kernel has static LDS", YF_ENG_ERR_HIP); }
+    if (at.sharedSizeBytes != 0) return quit("generic stage kernel has static LDS", YF_ENG_ERR_HIP);
   }
   { const char* sp = getenv("YF_160_SPLIT_K23"); g_split_k23 = sp && sp[0] == '1'; }
   auto prepare_band = [&](BandKernel& k) -> int {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, k.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
-    if (at.sharedSizeBytes != 0) { delete e; return fail(std::string(k.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP); }
+    if (at.sharedSizeBytes != 0) return quit(std::string(k.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP);
     if ((rc = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds)) != hipSuccess)
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
     int occ = 0;
@@ -311,6 +316,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   for (BandKernel& k : k_band) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
   for (BandKernel& k : k_band_fused) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
   { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // A/B and debugging only
+  { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
     for (const Variant& v : k_variants) park = v.park > park ? v.park : park;
@@ -438,6 +444,7 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   }
   hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->nw * 64), v->lds, s, prm);
   HIPCHK(e, hipGetLastError());
+  if (v->park) HIPCHK(e, e->park.mark(s));                   // the region is busy until this launch has completed (yf_stream_scratch.h)
   return YF_ENG_OK;
 }
 
@@ -611,7 +618,7 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
   if (n == 0) return YF_ENG_OK;
   if (((uintptr_t)d_in & 3) != 0 || ((uintptr_t)d_out & 1) != 0) { e->err = "input must be 4-byte, output 2-byte aligned"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
-  const long cap = n < 1024 ? n : 1024;                       // frames per chunk of the HBM arena
+  const long cap = n < e->chunk160 ? n : e->chunk160;         // frames per chunk of the HBM arena (289 KB per frame)
   const size_t per_frame = e->layerwise160 ? (size_t)yf160::FRAME_BYTES : (size_t)yf160::band::ARENA_BYTES;
   char* arena = nullptr;                                     // owned by the launch stream: overlapping launches never share it
   HIPCHK(e, e->arena160.get((hipStream_t)stream, (size_t)cap * per_frame, &arena));
@@ -633,8 +640,19 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
     }
     if (rc) return rc;
   }
+  HIPCHK(e, e->arena160.mark((hipStream_t)stream));
   return YF_ENG_OK;
 }
+
+int yf_engine_release_stream(yf_engine* e, void* stream) {
+  if (!e) return YF_ENG_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, e->park.release_stream((hipStream_t)stream));
+  HIPCHK(e, e->arena160.release_stream((hipStream_t)stream));
+  return YF_ENG_OK;
+}
+
+size_t yf_engine_scratch_bytes(yf_engine* e) { return e ? e->park.bytes_held() + e->arena160.bytes_held() : 0; }
 
 int yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch) {
   if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;

@@ -998,6 +998,14 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
   return 0;
 }
 
+int yf_fp16_release_stream(yf_fp16* c, void* stream) {
+  if (!c) return -2;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->park.release_stream((hipStream_t)stream));
+  return 0;
+}
+size_t yf_fp16_scratch_bytes(yf_fp16* c) { return c ? c->park.bytes_held() : 0; }
+
 // d_in: fp16 [n][56][56][3] (pixel / 255), d_out: fp32 logits [n][7][7][18]
 int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* stream) {
   if (!c || !d_in || !d_out || n < 0) return -2;
@@ -1020,6 +1028,7 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
 #endif
   hipLaunchKernelGGL(yf16::yoloface56_f16_fused<YF16_NW>, dim3((unsigned)grid), dim3(YF16_NW * 64), yf16::LDS_TOTAL, (hipStream_t)stream, prm);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, c->park.mark((hipStream_t)stream));               // the region is busy until this launch has completed (yf_stream_scratch.h)
 #ifdef YF16_BARPROF
   if (prof_path) {
     std::vector<long long> h(prof_bytes / sizeof(long long));

@@ -1,53 +1,97 @@
-// Device scratch keyed by the launch stream (host side, HIP).
+// Device scratch keyed by the launch stream (host side, HIP), BOUNDED.
 //
-// The fused kernels park intermediate tensors in HBM (tail batching: a workgroup's slot is indexed by blockIdx.x; the 160x160
-// banded kernels: a per-frame arena).  Two launches may use the same bytes only if they cannot run at the same time.  Launches
-// issued to ONE stream serialise, launches on different streams may overlap in any order and for any length -- so the scratch
-// is owned by the stream: a small stream -> region map, a region allocated on the first launch from a stream and grown when a
-// later launch needs more.  The reference has one context and no streams at all (network.c:2929-2939); an entry point that
-// accepts a stream has to be safe on any.  The map is mutex-protected (launches may come from several host threads).
+// The fused kernels park intermediate tensors in HBM (int8 tail batching: a workgroup's slot is indexed by blockIdx.x; the fp16 kernel's
+// park slots; the 160x160 banded kernels: a per-frame arena).  Two launches may use the same bytes only if they cannot run at the same
+// time.  Launches issued to ONE stream serialise, launches on different streams may overlap in any order and for any length -- so a
+// region is owned by a stream for as long as a launch on it may still run.  The reference has one context and no streams at all
+// (network.c:2929-2939); an entry point that accepts a stream has to be safe on any, and a host that creates a stream per request must
+// not grow the footprint without bound (round 3 kept one region per stream handle ever seen):
+//   - every launch records an event on its region (mark()); a region whose event has completed is IDLE and is handed to the next
+//     stream that asks (no allocation);
+//   - at most max_regions regions exist; when all are busy on other streams the caller waits for the one marked longest ago;
+//   - release_stream() gives a stream's region back at once (yf_network_release_stream);
+//   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread).
+// The first launch on a new stream may allocate (a blocking hipMalloc): INTEGRATION.md says so.  The map is mutex-protected.
 #ifndef YF_STREAM_SCRATCH_H
 #define YF_STREAM_SCRATCH_H
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 struct yf_stream_scratch {
-  struct Region { hipStream_t stream; char* ptr; size_t bytes; };
+  size_t max_regions = 8;                          // the owner may lower it (the 160x160 arena: 4)
+  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; };
   std::mutex mu;
   std::vector<Region> regions;
+  unsigned long long clock = 0;
 
-  // Region of at least `bytes` bytes for launches on `s`.  Growing frees the old block first; hipFree waits for the device,
-  // so no launch still reads the block that goes away.
+  static size_t thread_key(hipStream_t s) { return s == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0; }
+  Region* find(hipStream_t s, size_t tk) { for (Region& r : regions) if (r.stream == s && r.thread == tk) return &r; return nullptr; }
+  static bool idle(const Region& r) { return !r.marked || hipEventQuery(r.done) == hipSuccess; }
+
+  // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls mark(s).
   hipError_t get(hipStream_t s, size_t bytes, char** out) {
     std::lock_guard<std::mutex> lock(mu);
-    for (Region& r : regions) {
-      if (r.stream != s) continue;
-      if (r.bytes < bytes) {
-        if (r.ptr) (void)hipFree(r.ptr);
-        r.ptr = nullptr; r.bytes = 0;
-        const hipError_t rc = hipMalloc((void**)&r.ptr, bytes);
+    const size_t tk = thread_key(s);
+    Region* r = find(s, tk);
+    if (!r) {
+      for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
+      if (!r && regions.size() < max_regions) {
+        Region n = {s, tk, nullptr, 0, nullptr, false, 0};
+        const hipError_t rc = hipEventCreateWithFlags(&n.done, hipEventDisableTiming);
         if (rc != hipSuccess) return rc;
-        r.bytes = bytes;
+        regions.push_back(n);
+        r = &regions.back();
       }
-      *out = r.ptr;
-      return hipSuccess;
+      if (!r) {                                                                       // all busy on other streams: wait for the one marked longest ago
+        r = &regions[0];
+        for (Region& c : regions) if (c.stamp < r->stamp) r = &c;
+        const hipError_t rc = hipEventSynchronize(r->done);
+        if (rc != hipSuccess) return rc;
+      }
+      r->stream = s; r->thread = tk; r->marked = false;
     }
-    Region r = {s, nullptr, 0};
-    const hipError_t rc = hipMalloc((void**)&r.ptr, bytes);
-    if (rc != hipSuccess) return rc;
-    r.bytes = bytes;
-    regions.push_back(r);
-    *out = r.ptr;
+    if (r->bytes < bytes) {                                                           // grow: hipFree waits for the device, nothing still reads the old block
+      if (r->ptr) (void)hipFree(r->ptr);
+      r->ptr = nullptr; r->bytes = 0;
+      const hipError_t rc = hipMalloc((void**)&r->ptr, bytes);
+      if (rc != hipSuccess) return rc;
+      r->bytes = bytes;
+    }
+    r->stamp = ++clock;
+    *out = r->ptr;
     return hipSuccess;
   }
-  size_t count() {
+  // after the launch(es) that use the region obtained for `s`
+  hipError_t mark(hipStream_t s) {
     std::lock_guard<std::mutex> lock(mu);
-    return regions.size();
+    Region* r = find(s, thread_key(s));
+    if (!r) return hipSuccess;
+    r->marked = true;
+    return hipEventRecord(r->done, s);
   }
+  // the caller is done with `s` (about to destroy it): its region is freed once its last launch has completed
+  hipError_t release_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    const size_t tk = thread_key(s);
+    for (size_t i = 0; i < regions.size(); ++i) {
+      Region& r = regions[i];
+      if (r.stream != s || r.thread != tk) continue;
+      if (r.marked) (void)hipEventSynchronize(r.done);
+      if (r.ptr) (void)hipFree(r.ptr);
+      (void)hipEventDestroy(r.done);
+      regions.erase(regions.begin() + (long)i);
+      return hipSuccess;
+    }
+    return hipSuccess;
+  }
+  size_t count() { std::lock_guard<std::mutex> lock(mu); return regions.size(); }
+  size_t bytes_held() { std::lock_guard<std::mutex> lock(mu); size_t b = 0; for (const Region& r : regions) b += r.bytes; return b; }
   void release() {
     std::lock_guard<std::mutex> lock(mu);
-    for (Region& r : regions) if (r.ptr) (void)hipFree(r.ptr);
+    for (Region& r : regions) { if (r.ptr) (void)hipFree(r.ptr); if (r.done) (void)hipEventDestroy(r.done); }
     regions.clear();
   }
 };

@@ -255,6 +255,48 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
             assert np.array_equal(d_outs[k][it].cpu().numpy(), refs[k]), (k, it)
 
 
+def test_short_lived_streams_keep_the_scratch_bounded(network, oracle, torch_cuda):
+    """A host that creates a stream per request (yf_stream_scratch.h): 64 streams, each used for one int8, one fp16 and one 160x160
+    launch and then dropped WITHOUT a release call.  Regions of completed launches change hands, at most eight regions per kind
+    exist, so the footprint stays under 8 x (park slots + fp16 park slots + one 160x160 arena chunk) whatever the number of
+    streams (round 3 kept one region per stream handle ever seen: 64 x 43 MB here, 64 x 320 MB with 1024-frame 160x160 batches).  Every int8 head is compared with the oracle;
+    an explicit release of a stream returns its bytes at once."""
+    torch = torch_cuda
+    block = rnd(41, 512)
+    ref = oracle.run(block, threads=16)
+    blk160 = np.random.default_rng(42).integers(-128, 128, (4, 160, 160, 3), dtype=np.int8)
+    ref160 = oracle.run(blk160, threads=16)
+    network.fp16_init()
+    d_in = torch.from_numpy(block).cuda()
+    d_f16 = torch.from_numpy((np.random.default_rng(43).integers(0, 256, (64, 56, 56, 3)) / 255.0).astype(np.float16)).cuda()
+    d_160 = torch.from_numpy(np.tile(blk160, (16, 1, 1, 1))).cuda()
+    torch.cuda.synchronize()
+    outs = []
+    peak = 0
+    for k in range(64):
+        st = torch.cuda.Stream()
+        o = torch.empty((512, 7, 7, 18), dtype=torch.int8, device="cuda")      # (no fill kernel on the default stream racing the launches on `st`)
+        of = torch.empty((64, 7, 7, 18), dtype=torch.float32, device="cuda")
+        o160 = torch.empty((64, 20, 20, 18), dtype=torch.int8, device="cuda")
+        network.configure(2, 8)                         # the batched shape: it parks T15 tensors in the stream's region
+        network.run_device(d_in.data_ptr(), o.data_ptr(), 512, st.cuda_stream)
+        network.fp16_run_device(d_f16.data_ptr(), of.data_ptr(), 64, st.cuda_stream)
+        network.run_device_hw(160, 160, d_160.data_ptr(), o160.data_ptr(), 64, st.cuda_stream)
+        outs.append((o, o160, st))
+        peak = max(peak, network.scratch_bytes())
+    torch.cuda.synchronize()
+    network.configure(-1, 0)
+    for o, o160, _ in outs:
+        assert np.array_equal(o.cpu().numpy(), ref)
+        assert np.array_equal(o160.cpu().numpy(), np.tile(ref160, (16, 1, 1, 1)))
+    # eight regions per kind: a 64-frame 160x160 arena chunk (18.5 MB at 289 KB per frame), the int8 park slots (5.5 MB), the fp16 park slots (19.3 MB)
+    bound = 8 * 48 * 2 ** 20
+    assert 0 < peak <= bound, (peak, bound)
+    before = network.scratch_bytes()
+    network.release_stream(outs[-1][2].cuda_stream)
+    assert network.scratch_bytes() < before
+
+
 def test_asymmetric_launches_on_several_streams(network, oracle, torch_cuda):
     """Scratch ownership by stream (yf_stream_scratch.h).  ONE long launch on stream A (65 535 frames, ~2.7 ms) is followed,
     without synchronisation, by five 4096-frame launches on stream B and three on stream C: with scratch regions handed out
