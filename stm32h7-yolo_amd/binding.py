@@ -101,12 +101,32 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_sum_f32", "ai_sum_buffer_INT8"]
 
 
+def expected_build_id(extra_hipflags="", extra_fp16flags=""):
+    """The id csrc/Makefile bakes into the library (yf_network_build_id): sha256 over the device sources, flags.mk and the extra flags."""
+    import hashlib
+    csrc = os.path.join(_PKG, "csrc")
+    flags = open(os.path.join(csrc, "flags.mk"), "rb").read()
+    srcs = [ln.split(b"=", 1)[1].split() for ln in flags.splitlines() if ln.startswith(b"DEVICE_SRCS")][0]
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(open(os.path.join(csrc, f.decode()), "rb").read())
+    h.update(flags)
+    h.update(f"{extra_hipflags}|{extra_fp16flags}\n".encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
-    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force:
-        subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "clean"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "-j4", "all", "../lib/libyf_hostprep.so"],
-                          stdout=subprocess.DEVNULL)
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU).  One build at a time: the processes that share a checkout
+    (the two ranks of bench.py's self-launch, parallel test workers, profiler-wrapped tools) serialise on a lock file in the output directory."""
+    import fcntl
+    out = os.path.join(_PKG, "lib")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force:
+            subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "clean"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "-j4", "all", "../lib/libyf_hostprep.so"],
+                              stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -141,10 +161,25 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    check_id = False
     if not os.environ.get("YF_LIB_PATH"):
-        build()                  # `make`: a no-op when the library is current, so a stale .so is never loaded under fresh sources
+        try:
+            build()              # `make`: a no-op when the library is current, so a stale .so is never loaded under fresh sources
+        except (OSError, subprocess.CalledProcessError) as e:
+            # no make / no hipcc on this box (or the build failed): an existing library is used if -- and only if -- it was built from these
+            # sources with these flags (its baked-in id against the id computed here)
+            if not os.path.exists(LIB_PATH):
+                raise
+            import warnings
+            warnings.warn(f"stm32h7-yolo_amd: could not run the build ({e}); loading the existing library after checking its build id")
+            check_id = True
     _one_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
+    if check_id:
+        lib.yf_network_build_id.restype = ctypes.c_char_p
+        have, want = (lib.yf_network_build_id() or b"").decode(), expected_build_id()
+        if have != want:
+            raise RuntimeError(f"{LIB_PATH} was built from other sources or flags (build id {have}, expected {want}) and cannot be rebuilt here")
     vp, cl = ctypes.c_void_p, ctypes.c_long
     lib.ai_network_create.restype = AiError
     lib.ai_network_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(AiBuffer)]

@@ -113,6 +113,50 @@ def test_product_fails_loudly_without_gpu(yf):
     net.destroy()
 
 
+@pytest.mark.skipif(not _no_gpu(), reason="checks the behaviour WITHOUT a GPU")
+def test_repeated_init_without_gpu_does_not_grow(yf):
+    """ai_network_init may be called again and again (network.c:3385-3399): every failure path of the engine's creation gives back
+    what it had acquired (yf_engine_create -> yf_engine_destroy), so a hundred refused initialisations leave the process where it was."""
+    import resource
+    net = yf.Network()
+    def attempt():
+        with pytest.raises(yf.NetworkError):
+            net.init()
+    for _ in range(5):
+        attempt()
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for _ in range(100):
+        attempt()
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert after - before < 2048, (before, after)            # KiB
+    net.destroy()
+
+
+def test_load_without_a_build_tool_checks_the_build_id():
+    """binding.load() on a box without make / hipcc: an existing library is loaded if its baked-in build id equals the id computed
+    from the sources and flags (binding.expected_build_id), and refused otherwise."""
+    import subprocess
+    import sys
+    code = (
+        "import importlib, os, sys, warnings\n"
+        "os.environ['PATH'] = '/nonexistent'\n"
+        "b = importlib.import_module('stm32h7-yolo_amd.binding')\n"
+        "if sys.argv[1] == 'bad': b.expected_build_id = lambda *a: '0' * 16\n"
+        "with warnings.catch_warnings(record=True) as w:\n"
+        "    warnings.simplefilter('always')\n"
+        "    try:\n"
+        "        lib = b.load()\n"
+        "        print('LOADED', sum('could not run the build' in str(x.message) for x in w), lib.yf_network_build_id().decode() == b.expected_build_id())\n"
+        "    except RuntimeError as e:\n"
+        "        print('REFUSED', 'build id' in str(e))\n")
+    env = dict(os.environ)
+    env.pop("YF_LIB_PATH", None)
+    ok = subprocess.run([sys.executable, "-c", code, "good"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert ok.stdout.strip() == "LOADED 1 True", ok.stdout + ok.stderr
+    bad = subprocess.run([sys.executable, "-c", code, "bad"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert bad.stdout.strip() == "REFUSED True", bad.stdout + bad.stderr
+
+
 def test_handle_and_param_validation(yf):
     lib = yf.load()
     b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")

@@ -101,15 +101,18 @@ def test_st_luts_are_float_rounded_leaky_and_differ_from_tflite(oracle):
 @pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
 def test_fixtures_match_reference_data_files():
     """Weights blob / LUT fixture regenerate identically from the reference's data (tools/gen_model.py asserts the
-    blob against network_data.c)."""
+    blob against network_data.c).  The generator writes into a temporary directory: the tree (and the mtimes the
+    library's Makefile looks at) stays untouched."""
     import subprocess
     import sys
-    before = {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest() for f in (
-        "oracle/model/yoloface_int8.yfm", "tests/golden/st_leaky_luts.bin", "tests/golden/decode_tables_f32.bin",
-        "stm32h7-yolo_amd/csrc/gen/yf_model_gen.h", "stm32h7-yolo_amd/csrc/gen/yf_weights_blob_gen.c")}
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_model.py")], stdout=subprocess.DEVNULL)
-    for f, h in before.items():
-        assert hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest() == h, f
+    import tempfile
+    files = ("oracle/model/yoloface_int8.yfm", "tests/golden/st_leaky_luts.bin", "tests/golden/decode_tables_f32.bin",
+             "stm32h7-yolo_amd/csrc/gen/yf_model_gen.h", "stm32h7-yolo_amd/csrc/gen/yf_weights_blob_gen.c",
+             "stm32h7-yolo_amd/csrc/gen/yf_decode_tables_gen.h")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_model.py"), "--out-root", tmp], stdout=subprocess.DEVNULL)
+        for f in files:
+            assert open(os.path.join(tmp, f), "rb").read() == open(os.path.join(ROOT, f), "rb").read(), f
 
 
 def test_golden_vectors(oracle, golden):

@@ -39,6 +39,7 @@ TFL = f"{REF}/yoloface/tflite/yoloface_int8.tflite"
 NETC = f"{REF}/stm32/X-CUBE-AI/App/network.c"
 NETD = f"{REF}/stm32/X-CUBE-AI/App/network_data.c"
 PKG = os.path.join(ROOT, "stm32h7-yolo_amd")
+OUT_ROOT = ROOT        # --out-root DIR: write everything under DIR (same relative paths) instead of into the tree (tests compare the bytes)
 
 OPCODE = {"ADD": 0, "CONCATENATION": 2, "CONV_2D": 3, "DEPTHWISE_CONV_2D": 4, "MAX_POOL_2D": 17,
           "PAD": 34, "LEAKY_RELU": 98, "QUANTIZE": 114}
@@ -118,7 +119,8 @@ def st_blob():
 def main():
     m = read_tflite(TFL)
     T = m["tensors"]
-    write_yfm(m, os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+    os.makedirs(os.path.join(OUT_ROOT, "oracle", "model"), exist_ok=True)
+    write_yfm(m, os.path.join(OUT_ROOT, "oracle", "model", "yoloface_int8.yfm"))
 
     # ---- conv table: tflite op index -> ST c-layer id -----------------------
     convs = [(i, op) for i, op in enumerate(m["ops"]) if op["op"] in ("CONV_2D", "DEPTHWISE_CONV_2D")]
@@ -147,7 +149,7 @@ def main():
     assert bytes(blob) == ref_blob
     print(f"blob rebuilt from tflite == ST blob (11304 B; {len(mism)} alignment-pad bytes taken from ST)")
 
-    gen = os.path.join(PKG, "csrc", "gen")
+    gen = os.path.join(OUT_ROOT, "stm32h7-yolo_amd", "csrc", "gen")
     os.makedirs(gen, exist_ok=True)
 
     # ---- weight blob as a byte array (own formatting; identical bytes) ---------------------------
@@ -220,7 +222,7 @@ def main():
     luts = st_luts()
     leaky_ops = [i for i, op in enumerate(m["ops"]) if op["op"] == "LEAKY_RELU"]
     assert len(leaky_ops) == 17 and sorted(luts) == [i - 1 for i in leaky_ops]
-    gold = os.path.join(ROOT, "tests", "golden")
+    gold = os.path.join(OUT_ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     np.stack([luts[i - 1] for i in leaky_ops]).tofile(os.path.join(gold, "st_leaky_luts.bin"))
 
@@ -248,4 +250,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--out-root" in sys.argv:
+        OUT_ROOT = os.path.abspath(sys.argv[sys.argv.index("--out-root") + 1])
     main()
