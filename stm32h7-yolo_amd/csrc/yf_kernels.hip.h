@@ -1527,7 +1527,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   bool prof_on = false;
   int bar_no = 0;
   long long* prof_out = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 80;
-#define YF_SYNC() do { if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
+#define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the LDS-DMA of the next stage's constants, as in the shipped form of YF_SYNC: the stamp follows it */ \
+                       if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
                        if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
 #elif YF_V2
   // the barrier behind a stage also publishes the LDS-DMA of the NEXT stage's constants, which the compiler does not see

@@ -315,3 +315,33 @@ def test_prepare_rejects_bad_arguments(prep):
     small = (ctypes.c_uint8 * 100)()
     assert lib.yf_prepare_tables(small, 100, ctypes.byref(out), ctypes.byref(ix)) == 1
     assert lib.yf_prepare_tables(None, 11304, ctypes.byref(out), ctypes.byref(ix)) == 1
+
+
+def test_fp16_prefetch_wait_count_matches_the_isa(tmp_path):
+    """yf_fp16.hip: the barrier behind a stage that issued the next frame's input prefetch waits with s_waitcnt vmcnt(N), N = the number
+    of prefetch load instructions per thread -- it must cover the stage's weight DMA (older) and may leave the N prefetch loads (younger) in
+    flight.  Fewer than N vector loads between the DMA and that wait would leave the DMA unwaited.  The ISA is checked, not assumed."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "stm32h7-yolo_amd", "csrc")
+    flags = [ln.split("=", 1)[1].split() for ln in open(os.path.join(csrc, "flags.mk")) if ln.startswith("FP16FLAGS_BASE")][0]
+    asm = tmp_path / "f16.s"
+    subprocess.check_call([hipcc, *flags, "-S", "--cuda-device-only", os.path.join(csrc, "yf_fp16.hip"), "-o", str(asm)], stderr=subprocess.DEVNULL)
+    lines = [ln.strip() for ln in open(asm) if ln.strip() and not ln.strip().startswith(";")]
+    waits = [i for i, ln in enumerate(lines) if re.match(r"s_waitcnt vmcnt\([1-9]\d*\)", ln) and "lgkmcnt" not in ln]
+    checked = 0
+    for i in waits:
+        n = int(re.search(r"vmcnt\((\d+)\)", lines[i]).group(1))
+        nxt = next(k for k in range(i, len(lines)) if lines[k].startswith("s_barrier") or lines[k].startswith("v_") or lines[k].startswith("ds_"))
+        if not lines[nxt].startswith("s_barrier"):
+            continue                                        # a compiler-placed counted wait in front of a use, not the stage barrier
+        dma = max(k for k in range(i) if lines[k].startswith("global_load_lds_dwordx4"))
+        loads = [ln for ln in lines[dma + 1:i] if re.match(r"(global|flat|buffer)_load_dword", ln)]
+        stores = [ln for ln in lines[dma + 1:i] if re.match(r"(global|flat|buffer|scratch)_store", ln)]
+        assert len(loads) >= n and not stores, (n, loads, stores)
+        checked += 1
+    assert checked >= 1
