@@ -233,10 +233,11 @@ def load():
     lib.yf_network_fp16_init.argtypes = [vp, vp, ctypes.c_size_t]
     lib.yf_network_fp16_run_device.restype = cl
     lib.yf_network_fp16_run_device.argtypes = [vp, vp, vp, cl, vp]
-    lib.yf_network_release_stream.restype = ctypes.c_int
-    lib.yf_network_release_stream.argtypes = [vp, vp]
-    lib.yf_network_scratch_bytes.restype = ctypes.c_size_t
-    lib.yf_network_scratch_bytes.argtypes = [vp]
+    if hasattr(lib, "yf_network_release_stream"):          # (an older library loaded through YF_LIB_PATH for an A/B run does without)
+        lib.yf_network_release_stream.restype = ctypes.c_int
+        lib.yf_network_release_stream.argtypes = [vp, vp]
+        lib.yf_network_scratch_bytes.restype = ctypes.c_size_t
+        lib.yf_network_scratch_bytes.argtypes = [vp]
     lib.yf_network_last_error_text.restype = ctypes.c_char_p
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p

@@ -13,43 +13,16 @@
 #include "yf_stream_scratch.h"
 #include "yf_decode.hip.h"
 #define YF_NS yf
-#define YF_EXP 0
 #include "yf_kernels.hip.h"
 #undef YF_NS
-#undef YF_EXP
-#undef YF_STAGE_FN
-#define YF_NS yfx
-#ifndef YF_EXP_X
-#define YF_EXP_X 1
-#endif
-#define YF_EXP YF_EXP_X
-#ifndef YF_LAUNDER_X
-#define YF_LAUNDER_X 0      /* 7: no hoisting of per-lane index arithmetic in the experimental build */
-#endif
-#undef YF_LAUNDER
-#define YF_LAUNDER YF_LAUNDER_X
-#ifdef YF_PRIO_LIST_X       /* another priority ladder for the experimental namespace (A/B) */
-#undef YF_PRIO_LIST
-#define YF_PRIO_LIST YF_PRIO_LIST_X
-#endif
-#ifdef YF_V2_X              /* 0: the experimental namespace keeps the round-2 stage forms (constants from global memory) for A/B */
-#define YF_V2 YF_V2_X
-#endif
-#include "yf_kernels.hip.h"
-#undef YF_V2
-#undef YF_LAUNDER
-#undef YF_NS
-#undef YF_EXP
 #undef YF_STAGE_FN
 #undef YF_H0
-// 160x160 (BASELINE configs[4]): same stage code, layer by layer over an HBM arena
+// 160x160 (BASELINE configs[4]): the same stage code on band-local buffers (three banded kernels; YF_LAB: also layer by layer over an HBM arena)
 #define YF_NS yf160
-#define YF_EXP 0
 #define YF_H0 160
 #define YF_GENERIC 1
 #include "yf_kernels.hip.h"
 #undef YF_NS
-#undef YF_EXP
 #undef YF_H0
 #undef YF_GENERIC
 #include "gen/yf_decode_tables_gen.h"
@@ -95,21 +68,19 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 }
 
 typedef void (*fused_fn)(const yf::NetParams);
-static_assert(sizeof(yf::NetParams) == sizeof(yfx::NetParams), "A/B builds share the launch record");
-struct Variant { int f, nw; bool dump; bool exp; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
+struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
 
-#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
+#define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
-#define YF_VARIANT_CAM(F, NW) { F, NW, false, false, true, (fused_fn)yf::yoloface56_fused<F, NW, false, true>, yf::lds_bytes<F, NW, false>(), \
+#define YF_VARIANT_CAM(F, NW) { F, NW, false, true, (fused_fn)yf::yoloface56_fused<F, NW, false, true>, yf::lds_bytes<F, NW, false>(), \
                                 yf::scratch_bytes_per_frame_slot<false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input>" }
-#define YF_VARIANT_X(F, NW) { F, NW, false, true, false, (fused_fn)yfx::yoloface56_fused<F, NW, false>, yfx::lds_bytes<F, NW, false>(), yfx::scratch_bytes_per_frame_slot<false>(), \
-                              "yoloface56_fused<F=" #F ",NW=" #NW ",EXPERIMENTAL>" }
-// production shapes, their debug (per-stage dump / stop_stage) builds, and the experimental (YF_EXP) build for in-process A/B
+// The product: the batched shape <2,8>, the one-frame-per-workgroup shape <1,8> for small batches, the camera-input form of <2,8> and ONE debug
+// (per-stage dump / stop_stage) build for the per-node observer.  A -DYF_LAB build (make lab) adds the other shapes for tools and tests.
 const Variant k_variants[] = {
-  YF_VARIANT(1, 4, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 4, false), YF_VARIANT(2, 8, false), YF_VARIANT(4, 8, false),
-  YF_VARIANT(2, 4, true), YF_VARIANT(2, 8, true),
-  YF_VARIANT_X(2, 8),
-  YF_VARIANT_CAM(2, 8),           // camera-format input (112x112 RGB565), the shipped shape only
+  YF_VARIANT(2, 8, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 8, true), YF_VARIANT_CAM(2, 8),
+#ifdef YF_LAB
+  YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 8, false), YF_VARIANT(2, 4, true),
+#endif
 };
 
 }  // namespace
@@ -197,11 +168,12 @@ struct Downloader {
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
 static const Variant* shape_for(const yf_engine* e, long n);
-static const Variant* find_variant(int f, int nw, bool dump, bool exp = false, bool cam = false) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.exp == exp && v.cam == cam) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool cam = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.cam == cam) return &v;
   return nullptr;
 }
 
+#ifdef YF_LAB
 // 160x160 variant: launches the 27 per-stage kernels in order
 template <int ST>
 static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned grid, hipStream_t s) {
@@ -214,7 +186,9 @@ static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned gr
   }
 }
 
-// 160x160, banded form: four kernels, each fusing a group of stages over row bands staged through LDS
+#endif
+
+// 160x160, banded form: three kernels, each fusing a group of stages over row bands staged through LDS
 struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; int wgs_per_cu; };
 #ifndef YF_K1_NW
 #define YF_K1_NW 8
@@ -225,21 +199,9 @@ static BandKernel k_band_fused[3] = {            // round 3: K2 and K3 fused (th
   {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS, 1},
   {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
 };
-static BandKernel k_band[4] = {
-#ifndef YF_K1_NW
-#define YF_K1_NW 8
-#endif
-  {(const void*)yf160::band::band_k1<YF_K1_NW>,  "band_k1", YF_K1_NW * 64,  (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
-  {(const void*)yf160::band::band_k2<8>,  "band_k2", 512,  (size_t)yf160::band::K2_LDS, yf160::band::K2_BANDS, 1},
-  {(const void*)yf160::band::band_k3<8>,  "band_k3", 512,  (size_t)yf160::band::K3_LDS, yf160::band::K3_BANDS, 1},
-  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
-};
-static bool g_split_k23 = false;                 // YF_160_SPLIT_K23=1: the round-2 form with separate band_k2 / band_k3 (A/B, debugging)
 static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
-  const BandKernel* list = g_split_k23 ? k_band : k_band_fused;
-  const int count = g_split_k23 ? 4 : 3;
-  for (int i = 0; i < count; ++i) {
-    const BandKernel& k = list[i];
+  for (int i = 0; i < 3; ++i) {
+    const BandKernel& k = k_band_fused[i];
     const long jobs = prm.n * k.jobs_per_frame;
     const long full = (long)e->cus * k.wgs_per_cu;           // persistent grid: every workgroup resident, jobs grid-strided
     const unsigned grid = (unsigned)(jobs < full ? jobs : full);
@@ -296,12 +258,14 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     if ((rc = hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds)) != hipSuccess)
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
   }
+#ifdef YF_LAB
   {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, (const void*)yf160::generic_stage_kernel<1, 8>)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
     if (at.sharedSizeBytes != 0) return quit("generic stage kernel has static LDS", YF_ENG_ERR_HIP);
   }
-  { const char* sp = getenv("YF_160_SPLIT_K23"); g_split_k23 = sp && sp[0] == '1'; }
+  { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // the lab library's layer-by-layer form (debugging)
+#endif
   auto prepare_band = [&](BandKernel& k) -> int {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, k.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
@@ -313,9 +277,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     k.wgs_per_cu = occ > 0 ? occ : 1;
     return YF_ENG_OK;
   };
-  for (BandKernel& k : k_band) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
   for (BandKernel& k : k_band_fused) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
-  { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // A/B and debugging only
   { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
@@ -372,10 +334,7 @@ int yf_engine_table_plan(int32_t* out, int cap) {
   return need;
 }
 
-int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) {
-  const bool exp = frames_per_wg >= 200;
-  return find_variant(exp ? frames_per_wg - 200 : frames_per_wg, waves_per_wg, false, exp) != nullptr;
-}
+int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) { return find_variant(frames_per_wg, waves_per_wg, false) != nullptr; }
 
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
@@ -383,16 +342,12 @@ int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
     e->var = find_variant(2, 8, false); e->var_dump = find_variant(2, 8, true); e->var_small = find_variant(1, 8, false);
     return YF_ENG_OK;
   }
-  /* frames_per_wg + 200 selects the experimental (YF_EXP) build of the same shape */
-  const bool exp = frames_per_wg >= 200;
-  if (exp) frames_per_wg -= 200;
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
-  const Variant* v = find_variant(f, nw, false, exp);
+  const Variant* v = find_variant(f, nw, false);
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
   e->var_small = nullptr;                        /* an explicitly configured shape runs every batch size */
-  e->var_dump = exp ? nullptr : find_variant(f, nw, true);   /* debug build of the SAME shape, or none: the dump / stage-timing
-                                                                 entry points refuse instead of running another shape */
+  e->var_dump = find_variant(f, nw, true);       /* debug build of the SAME shape, or none: the dump / stage-timing entry points refuse instead of running another shape */
   return YF_ENG_OK;
 }
 
@@ -475,7 +430,7 @@ int yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out,
   if (d_dets && (!d_counts || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST))) return YF_ENG_ERR_ARG;
   if (((uintptr_t)d_rgb565 & 15) != 0) { e->err = "camera frames must be 16-byte aligned"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
-  const Variant* v = find_variant(e->var->f, e->var->nw, false, false, true);
+  const Variant* v = find_variant(e->var->f, e->var->nw, false, true);
   if (!v) { e->err = "no camera-input build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
   const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
   return launch(e, v, d_rgb565, d_out, nullptr, n, (hipStream_t)stream, -1, d_dets ? &dec : nullptr);
@@ -619,19 +574,26 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
   if (((uintptr_t)d_in & 3) != 0 || ((uintptr_t)d_out & 1) != 0) { e->err = "input must be 4-byte, output 2-byte aligned"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
   const long cap = n < e->chunk160 ? n : e->chunk160;         // frames per chunk of the HBM arena (289 KB per frame)
+#ifdef YF_LAB
   const size_t per_frame = e->layerwise160 ? (size_t)yf160::FRAME_BYTES : (size_t)yf160::band::ARENA_BYTES;
+#else
+  const size_t per_frame = (size_t)yf160::band::ARENA_BYTES;
+#endif
   char* arena = nullptr;                                     // owned by the launch stream: overlapping launches never share it
   HIPCHK(e, e->arena160.get((hipStream_t)stream, (size_t)cap * per_frame, &arena));
   for (long done = 0; done < n; done += cap) {
     const long m = (n - done) < cap ? (n - done) : cap;
     int rc;
+#ifdef YF_LAB
     if (e->layerwise160) {
       yf160::GenParams prm;
       prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
       prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;
       prm.n = m; prm.tab = e->d_tab; prm.arena = arena;
       rc = launch160_from<0>(e, prm, (unsigned)m, (hipStream_t)stream);
-    } else {
+    } else
+#endif
+    {
       yf160::band::Params prm;
       prm.in = (const int8_t*)d_in + done * yf160::IN_FRAME_BYTES;
       prm.out = (int8_t*)d_out + done * yf160::OUT_FRAME_BYTES;

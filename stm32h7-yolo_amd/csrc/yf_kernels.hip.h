@@ -15,8 +15,9 @@
 //   max-pool              : separable, packed 2x int16 max on the byte lanes, clamped coordinates
 //   residual add          : TFLite int8 ADD arithmetic in the producing conv's epilogue
 //   concat                : producers write straight into the concat buffer (no copy)
-// Included twice by yf_engine.hip (namespaces yf and yfx) so that an experimental variant (YF_EXP 1) can be A/B-timed
-// against the shipped code in ONE process on ONE device (cdna_hip_programming.md 5.4 rule 24).
+// Included twice by yf_engine.hip: namespace yf (56x56: the fused kernel) and namespace yf160 (YF_H0 160: the banded kernels).
+// -DYF_LAB (make lab -> lib_lab/) adds what only tools and two debugging tests use: the other fused shapes and the layer-by-layer 160x160 form with
+// the round-2 stage forms it is written in.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -27,12 +28,7 @@
 #ifndef YF_LAUNDER
 #define YF_LAUNDER 0
 #endif
-// A/B toggles of the experimental build (namespace yfx, YF_EXP 1): bits of YF_EXP_MASK, all off in the shipped build
-#ifndef YF_EXP_MASK
-#define YF_EXP_MASK 0
-#endif
-#define YF_TOGGLED(bit) ((YF_EXP == 1) && ((YF_EXP_MASK) & (bit)))
-#define YF_ROW_SKEW (YF_TOGGLED(256) ? 0 : 4)      /* bytes; the experimental build with mask bit 256 runs without the skew (A/B) */
+#define YF_ROW_SKEW 4      /* bytes of row skew in the depthwise inputs with 8- / 40-byte pixels (T1, T19: Buf::SK) */
 namespace YF_NS {
 
 // Stage functions are inlined (measured: real calls remove the scratch spills of the 128-VGPR builds but cost
@@ -186,11 +182,7 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
 #define YF_RQ4_OPS : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(cy0), "=&s"(cy1), "=&s"(cy2), "=&s"(cy3) \
                    : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(m2[0]), "v"(m2[1]), "v"(m2[2]), "v"(m2[3]), \
                      "s"(c64[0]), "s"(c64[1]), "s"(c64[2]), "s"(c64[3])
-#if YF_EXP == 10   // what-if (hazard not padded)
-  if constexpr (AFTER_MFMA) asm(YF_RQ4_MADS YF_RQ4_OPS);
-#else
   if constexpr (AFTER_MFMA) asm("s_nop 7\n\ts_nop 1\n\t" YF_RQ4_MADS YF_RQ4_OPS);
-#endif
   else asm(YF_RQ4_MADS YF_RQ4_OPS);
 #undef YF_RQ4_MADS
 #undef YF_RQ4_OPS
@@ -204,26 +196,10 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
 // the four requantised channels of a pass as LUT indices / unsigned bytes (q + 128)
 template <bool AFTER_MFMA>
 __device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[4]) {
-#if YF_EXP == 4    // what-if (wrong results): no requantisation arithmetic
-#pragma unroll
-  for (int j = 0; j < 4; ++j) idx[j] = acc[j] & 255;
-#elif YF_EXP == 12 // what-if (wrong results): constants loaded and consumed by ONE cheap op per channel, no real arithmetic
-#pragma unroll
-  for (int j = 0; j < 4; ++j) idx[j] = (acc[j] + (int)m2[j] + (int)zr[j] + (int)c64[j] + rs[j]) & 255;
-#elif YF_EXP == 8  // what-if: 32-bit multiply-high + add instead of the 64-bit multiply-add with carry
-#pragma unroll
-  for (int j = 0; j < 4; ++j) idx[j] = min(max((int)(__umulhi((unsigned)acc[j], m2[j]) + zr[j] + (unsigned)c64[j]) >> rs[j], 0), 255);
-#elif YF_EXP == 9  // what-if: no shift, no clamp
-  int t[4];
-  rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) idx[j] = t[j] & 255;
-#else
   int t[4];
   rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
 #pragma unroll
   for (int j = 0; j < 4; ++j) idx[j] = min(max(t[j] >> rs[j], 0), 255);     // v_ashrrev, v_med3_i32
-#endif
 }
 // the same for TWO channels: the last pass of a layer with 4k + 2 output channels (6, 18) carries two padding channels whose
 // requantisation, LUT reads and packing would be thrown away
@@ -266,11 +242,7 @@ __device__ __forceinline__ uint32_t join4(uint32_t b0, uint32_t b1, uint32_t b2,
 typedef const __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
 template <int LUT_ID>
 __device__ __forceinline__ uint32_t lutb(int idx) {
-#if YF_EXP == 3    // what-if (wrong results): no LUT read
-  return (uint32_t)idx;
-#else
   return *(lds_u8_ptr)(uint32_t)(LUT_ID * 256 + idx);
-#endif
 }
 __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {          // v_pk_max_i16
   v2s x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
@@ -316,33 +288,22 @@ __device__ __forceinline__ uint32_t uniform_u32(const void* p) { return *(cu32_p
 // yf_pass (80 B): mult2[4] and zr[4] go to VGPRs (vz is a zero the compiler cannot see through, which keeps the load a
 // vector load), c64[4] and rshift[4] to SGPRs
 struct PassV { v4u m2, zr; };
+#ifdef YF_LAB
 __device__ __forceinline__ PassV load_pass_v(const uint8_t* pass, int vz) {
-#if YF_EXP == 2 || YF_EXP == 11     // what-if (wrong results): constants without a memory access
-  const unsigned u = (unsigned)(uintptr_t)pass + vz;
-  return PassV{v4u{u | 0x80000000u, u | 0x80000001u, u | 0x80000002u, u | 0x80000003u}, v4u{u, u, u, u}};
-#else
   const v4u* p = reinterpret_cast<const v4u*>(pass + vz);
   return PassV{p[0], p[1]};
-#endif
 }
 __device__ __forceinline__ v4i load_wfrag(const uint8_t* p, int vz) {
-#if YF_EXP == 2 || YF_EXP == 11
-  const int u = (int)(uintptr_t)p + vz;
-  return v4i{u, u + 1, u + 2, u + 3};
-#else
   (void)vz;
   return *reinterpret_cast<const v4i*>(p);
-#endif
 }
+#endif
 struct PassS { v4ul c64; v4i rs; };
+#ifdef YF_LAB
 __device__ __forceinline__ PassS load_pass_s(const uint8_t* pass) {
-#if YF_EXP == 11   // what-if (wrong results): scalar constants without a memory access
-  const unsigned long u = (unsigned long)(uintptr_t)pass;
-  return PassS{v4ul{u * 3, u * 5, u * 7, u * 9}, v4i{7, 8, 9, 7}};
-#else
   return PassS{*(cv4ul_ptr)(uintptr_t)(pass + 32), *(cv4i_ptr)(uintptr_t)(pass + 64)};
-#endif
 }
+#endif
 // stage descriptors out of the index at the head of the table blob, as scalar loads (offsets stay in SGPRs)
 // Table layout, compiled in.  The blob is laid out by yf_prepare_tables (yf_host_prep.c) stage by stage with 16-byte
 // alignment, and every size in it follows from the network's architecture alone -- so the byte offsets are constants of the
@@ -376,6 +337,7 @@ constexpr TablePlan make_plan() {
   return p;
 }
 constexpr TablePlan PLAN = make_plan();
+#ifdef YF_LAB
 __device__ __forceinline__ yf_dense load_dense(const uint8_t*, int i) {
   yf_dense d = {};
   d.w_off = (uint32_t)PLAN.w_off[i]; d.c_off = (uint32_t)PLAN.c_off[i];
@@ -386,6 +348,7 @@ __device__ __forceinline__ yf_dw load_dw(const uint8_t*, int i) {
   d.g_off = (uint32_t)PLAN.g_off[i];
   return d;
 }
+#endif
 __device__ __forceinline__ int load_halo_zp(const uint8_t* tab, int i) {
   return (int)uniform_u32(tab + offsetof(yf_table_index, halo_zp) + 4 * i);
 }
@@ -538,9 +501,12 @@ YF_STAGE_FN void stage_input_cam(char* frames, const uint8_t* __restrict__ cam, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------ epilogue store
 // residual add (tflite ADD): the final requantisation's constants are the same for every channel (yf_add, device form)
 struct AddK { uint32_t mo2, zro; unsigned long c64o; int rso; };
+
+#ifdef YF_LAB
+// ==== round-2 stage forms (constants from global memory, per-job index arithmetic): what the layer-by-layer 160x160 kernels are written in
+// ------------------------------------------------------------------------------------------------ epilogue store
 
 // idx[4]: the pass's four requantised channels as unsigned bytes q + 128 (= LUT indices) of pixel p of frame f
 template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
@@ -624,12 +590,6 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
     v4i b[KS];
     {
       const char* src = fbase + IN::at_p(p);
-#if YF_EXP == 5
-      { const int u = (int)(uintptr_t)src;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[ks] = v4i{u + ks, u + 1, u + 2, u + 3}; }
-      if (false)
-#endif
       {
 #pragma unroll
       for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
@@ -645,13 +605,8 @@ YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restr
       if (ps < NP) {                                          // uniform
         const PassS k = ksr[t];
         v4i acc = {ACC0, ACC0, ACC0, ACC0};
-#if YF_EXP == 7
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc += a[t][ks] + b[ks];
-#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
-#endif
         int idx[4];                         // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
         requant4<true>(acc, pv[t].m2, pv[t].zr, k.c64, k.rs, idx);
         epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, out_all, f, p, ps * 4, idx, ad);
@@ -750,13 +705,9 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
     v4i a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;                // k-steps: taps 0-3, 4-7, 8
     if (a_on) {
       const uint32_t* wl = wg + (c & 3);                    // masked weight dwords of channel c&3: wl[4*tap]
-#if YF_EXP == 2 || YF_EXP == 11
-      a0 = load_wfrag((const uint8_t*)wl, vz); a1 = load_wfrag((const uint8_t*)(wl + 16), vz); a2[0] = a1[1] + 5;
-#else
       a0 = v4i{(int)wl[0], (int)wl[4], (int)wl[8], (int)wl[12]};
       a1 = v4i{(int)wl[16], (int)wl[20], (int)wl[24], (int)wl[28]};
       a2[0] = (int)wl[32];
-#endif
     }
     const PassV pv = load_pass_v(grp + 144, vz);
     const PassS k = load_pass_s(grp + 144);
@@ -769,24 +720,16 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
       char* fb = frames + fp * FL * IN::FS;
       const char* src = fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + 4 * cg + lane_in;
-#if YF_EXP == 5    // what-if (wrong results): no LDS reads of the taps
-      { const int u = (int)(uintptr_t)src; b0 = v4i{u, u + 1, u + 2, u + 3}; b1 = v4i{u + 4, u + 5, u + 6, u + 7}; b2[0] = u + 8; }
-#else
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
       b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
-#endif
       dst = fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg;
     };
     auto conv = [&](const v4i& b0, const v4i& b1, const v4i& b2) {
-#if YF_EXP == 7    // what-if (wrong results): no MFMA
-      return b0 + b1 + b2 + a0;
-#else
       v4i acc = {ACC0, ACC0, ACC0, ACC0};
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
       return __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-#endif
     };
     auto finish = [&](const v4i& acc, char* dst) {
       int idx[4];
@@ -812,6 +755,8 @@ YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, co
     }
   }
 }
+
+#endif   // YF_LAB
 
 // ------------------------------------------------------------------------------------------------ max-pools
 // pool_8: 8x8 stride 2 pad 3 on T4 (28x28x18) -> separable; the vertical pass applies QUANTIZE#21 and writes the
@@ -871,6 +816,7 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
                                  });
   }
 }
+#ifdef YF_LAB   // (the direct 4x4 form: the layer-by-layer 160x160 kernels)
 // pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
 template <int F, int NT, class T15 = B_T15, class T30 = B_T30>
 YF_STAGE_FN void pool25(char* frames, int tid) {
@@ -891,6 +837,8 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
   }
 }
 
+#endif   // YF_LAB
+
 // ================================================================================================ lean stages (round 3)
 // The 56x56 fused kernel's own forms of the dense and depthwise stages.  What changes against dense_stage / dw_mfma_stage
 // (which the 160x160 kernels keep using):
@@ -904,9 +852,6 @@ YF_STAGE_FN void pool25(char* frames, int tid) {
 //     a lane's pixel offsets are per-lane constants and a tile adds a scalar frame offset -- no per-job index arithmetic.
 //   * the depthwise stages read the offsets of a job (row block, column segment, frame pair) from a small LDS table built once
 //     per workgroup instead of deriving them with ~35 scalar instructions per job.
-#ifndef YF_V2
-#define YF_V2 1
-#endif
 namespace v2 {
 constexpr int LUT_B = YF_N_LUT * 256;                         // byte LUTs at LDS offset 0 (absolute addressing, as before)
 constexpr int JT = LUT_B, JT_B = 896;                         // depthwise job tables
@@ -1012,7 +957,7 @@ __device__ __forceinline__ void epilogue2_half(char* dstpix, const char* addpix,
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(r[0], r[1]) ^ 0x8080u;
   }
 }
-#define YF_HALF_PASS (!YF_TOGGLED(512))          /* the experimental build with mask bit 512 requantises the padding channels too (A/B) */
+#define YF_HALF_PASS 1          /* the last pass of a layer with 4k + 2 output channels requantises its two real channels only */
 
 // ---- dense 1x1 (lane-private MFMA, see dense_stage), constants from ring slot CS
 // STASH_OFF >= 0 (debug builds, residual-add stages): the convolution's own requantised output of pixel p also goes to byte
@@ -1452,10 +1397,7 @@ constexpr int STAGE_PRIO[27] = {YF_PRIO_LIST};
 template <int K> __device__ __forceinline__ void stage_prio() {
   if constexpr (K == 0 || STAGE_PRIO[K] != STAGE_PRIO[K - 1]) __builtin_amdgcn_s_setprio(STAGE_PRIO[K]);
 }
-#ifndef YF_TAIL_BATCH
-#define YF_TAIL_BATCH 1
-#endif
-template <bool DUMP> constexpr bool tail_batch() { return !DUMP && (YF_TAIL_BATCH); }
+template <bool DUMP> constexpr bool tail_batch() { return !DUMP; }
 
 // CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
 // preparation runs inside the input staging (stage_input_cam).
@@ -1468,11 +1410,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
   constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
-#if YF_V2
   constexpr int PRE = v2::pre_bytes<F, tail_batch<DUMP>()>();   // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
-#else
-  constexpr int PRE = LUT_BYTES;                         // LUTs | residual-add tables
-#endif
   char* out_all = smem + PRE;
   char* frames = smem + PRE + OUT_ALL_BYTES;
   long parked_first = -1;                                // first frame of the group whose T15 waits in the scratch
@@ -1486,7 +1424,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   // to conv2d_23, 1 for the first six tail stages, 0 for the rest.  The two workgroups of a CU are in different phases; the one
   // in the VALU-bound front stages then issues ahead of the one in the latency-bound tail, which only needs the slots left
   // over.  -6.8 % kernel time in-run (A/B 1.073 against no ladder); every placement of the three steps tried gave 6.0-7.3 %.
-#if YF_V2
   for (int i = tid0; i < v2::LUT_B / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
   for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
@@ -1507,10 +1444,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     v2::build_halotab<typename HTS::G15, HTS::H_T15, NT>(smem, tid0);
     v2::build_halotab<typename HTS::G19, HTS::H_T19, NT>(smem, tid0);
   }
-#else
-  for (int i = tid0; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
-#endif
 
   const long n_groups = (prm.n + F - 1) / F;
   const AddK no_add = {};
@@ -1530,42 +1463,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the LDS-DMA of the next stage's constants, as in the shipped form of YF_SYNC: the stamp follows it */ \
                        if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
                        if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
-#elif YF_V2
+#else
   // the barrier behind a stage also publishes the LDS-DMA of the NEXT stage's constants, which the compiler does not see
 #define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
-#else
-#define YF_SYNC() __syncthreads()
 #endif
-  // Stage calls: the lean forms (constants from an LDS ring slot, fetched one stage ahead by YF_FETCH) or the round-2 forms
-#if YF_V2
+  // Stage calls: constants from an LDS ring slot, fetched one stage ahead by YF_FETCH
 #define YF_HALO(B, RING, FR, G, HOFF, WI, TID) \
   v2::fill_halo_t<B, typename v2::HaloTabs<F, BATCH>::G, v2::HaloTabs<F, BATCH>::HOFF>(frames, load_halo_zp(tab, WI), TID)
-#else
-#define YF_HALO(B, RING, FR, G, HOFF, WI, TID) fill_halo<B, RING, FR, NT>(frames, load_halo_zp(tab, WI), TID)
-#endif
-#if YF_V2
 #define YF_FETCH(CS, WV, LN) v2::fetch_consts<CS>(tab, WV, LN)
 #define YF_CONV1(WV, LN, CS) v2::conv1_2_stage<F, NW, CS>(frames, tab, WV, LN)
 #define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
   v2::dense2_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS>(frames, out_all, tab, AD, WV, LN)
 #define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) v2::dw2_stage<FR, NW, STRIDE, IN, OUT, C, LUT, CS, v2::JobTabs<F, BATCH>::JTOFF>(frames, tab, WV, LN)
-#else
-#define YF_FETCH(CS, WV, LN) do {} while (0)
-#define YF_CONV1(WV, LN, CS) conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), WV, LN, vz)
-#define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
-  dense_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB>(frames, out_all, tab, load_dense(tab, DI), AD, WV, LN, vz)
-#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) dw_mfma_stage<FR, NW, STRIDE, IN, OUT, C, LUT>(frames, tab, load_dw(tab, WI), WV, LN, vz)
-#endif
 #define YF_DUMP(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
   int stage_no = 0;
 #define YF_STAGE_END() if constexpr (DUMP) { if (++stage_no == prm.stop_stage) continue; }
-  // Priority ladder (toggle bit 8 of YF_EXP_MASK switches it OFF in the experimental build)
-#if !YF_TOGGLED(8)
 #define YF_PRIO(K) stage_prio<K>()
-#else
-#define YF_PRIO(K) do {} while (0)
-#endif
 
   // Fused box decode: the staged heads of group g stay in out_all until conv2d_53 of group g+1, so they are decoded by
   // the last F waves DURING conv2d_29 of the next group (a 4-job stage: those waves are idle there), off the critical
@@ -1632,7 +1546,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_PRIO(4);
     YF_HALO(B_T4, false, F, G4, H_T4, YF_W_DW10, tid_f);
     YF_FETCH(4, W_f, L_f);
-    YF_DENSE(F, (YF_TOGGLED(1024) ? 3 : 5), 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50; experimental bit 1024: three)
+    YF_DENSE(F, 5, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50; experimental bit 1024: three)
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     YF_PRIO(5);
@@ -1665,17 +1579,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(11);
     YF_FETCH(9, W_m, L_m);
-#if YF_V2
     if constexpr (DUMP)   // debug builds: conv2d_17's own output is parked in the (still unwritten) conv half of concat_22 for the dump
       v2::dense2_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, 8, B_T14::OFF + YF_T14_CONV_BASE, B_T14::S>(frames, out_all, tab, addctx(YF_A_ADD18), W_m, L_m);
     else
-#endif
     YF_DENSE(F, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, YF_D_C17, addctx(YF_A_ADD18), W_m, L_m, 8);   // conv2d_17 + eltwise_18
     YF_SYNC(); YF_DUMP(B_T11, 6, T11) YF_DUMP(B_T14, 6, C17, YF_T14_CONV_BASE)
     YF_STAGE_END()
     YF_PRIO(12);
     YF_FETCH(10, W_m, L_m);
-    YF_DENSE(F, (YF_TOGGLED(4096) ? 2 : 3), 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
+    YF_DENSE(F, 3, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
     YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
     YF_STAGE_END()
     YF_PRIO(13);
@@ -1734,7 +1646,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 #define YF_DUMP_T(BUF, C, OFF, ...) \
   if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
     YF_PRIO(14);
-#if YF_V2
     YF_FETCH(12, W_t, L_t);
     {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
       constexpr int PW = v2::pool25_waves<FT>();
@@ -1742,11 +1653,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30, DUMP>(frames, W_t * 64 + L_t);
       else v2::dw2_stage<FT, NW - PW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, 11, v2::JobTabs<F, BATCH>::JT_DW27>(frames, tab, W_t - PW, L_t);
     }
-#else
-    pool25<FT, NT, typename U::T15, typename U::T30>(frames, tid_t);                                  // pool_25 + QUANTIZE#45
-    YF_FETCH(12, W_t, L_t);
-    YF_DW(FT, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, YF_W_DW27, W_t, L_t, 11, JT_DW27);    // conv2d_27
-#endif
     YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T30, 24, P25, 24) YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
     YF_PRIO(15);
@@ -1758,7 +1664,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_PRIO(16);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW32, tid_t);
     YF_FETCH(14, W_t, L_t);
-    YF_DENSE(FT, (YF_TOGGLED(2048) ? 3 : 5), 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
+    YF_DENSE(FT, 5, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
     YF_STAGE_END()
     YF_PRIO(17);
@@ -1768,18 +1674,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(18);
     YF_FETCH(16, W_t, L_t);
-#if YF_V2
     if constexpr (DUMP)   // debug builds: conv2d_34's own output -> the conv half of concat_46 (written by conv2d_42 only)
       v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, 15, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD35), W_t, L_t);
     else
-#endif
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, YF_D_C34, addctx(YF_A_ADD35), W_t, L_t, 15);   // conv2d_34 + eltwise_35
     YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22) YF_DUMP_T(typename U::T30, 8, C34, 24)
     YF_STAGE_END()
     YF_PRIO(19);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
     YF_FETCH(17, W_t, L_t);
-    YF_DENSE(FT, (YF_TOGGLED(2048) ? 3 : 5), 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
+    YF_DENSE(FT, 5, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
     YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
     YF_STAGE_END()
     YF_PRIO(20);
@@ -1789,22 +1693,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_STAGE_END()
     YF_PRIO(21);
     YF_FETCH(19, W_t, L_t);
-#if YF_V2
     if constexpr (DUMP)
       v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, 18, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD41), W_t, L_t);
     else
-#endif
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, YF_D_C40, addctx(YF_A_ADD41), W_t, L_t, 18);   // conv2d_40 + eltwise_41
     YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26) YF_DUMP_T(typename U::T30, 8, C40, 24)
     YF_STAGE_END()
     YF_PRIO(22);
     YF_FETCH(20, W_t, L_t);
-#if YF_V2
     if constexpr (DUMP)   // debug builds: LEAKY_RELU #43's output (through the debug LUT) -> T20's slot, dead since conv2d_40
       v2::dense2_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, 19, U::T20::OFF, U::T20::S, DBG_LUT>(frames, out_all, tab, no_add, W_t, L_t);
     else
-#endif
-    YF_DENSE(FT, (YF_TOGGLED(2048) ? 2 : 3), 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
+    YF_DENSE(FT, 3, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
     YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) YF_DUMP_T(typename U::T20, 24, L43)
     YF_STAGE_END()
     YF_PRIO(23);
@@ -1888,11 +1788,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)(YF_V2 ? v2::pre_bytes<F, tail_batch<DUMP>()>() : LUT_BYTES) + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES + (DUMP ? YF_DBG_LUT_BYTES : 0); }
+constexpr size_t lds_bytes() { return (size_t)v2::pre_bytes<F, tail_batch<DUMP>()>() + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES + (DUMP ? YF_DBG_LUT_BYTES : 0); }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 
 #else   // YF_GENERIC
+#ifdef YF_LAB
 // ------------------------------------------------------------------------------------------------ layer-by-layer form
 // For input sizes whose activations do not fit in LDS (160x160: conv2d_6's output alone is 131 KB) the SAME stage
 // functions run one kernel per fused stage over a per-frame arena in HBM (one workgroup per frame and stage, frames
@@ -1998,6 +1899,8 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
   }
 }
 
+#endif   // YF_LAB
+
 // ------------------------------------------------------------------------------------------------ banded form
 // Second form for sizes that do not fit in LDS (160x160): FOUR kernels, each fusing a group of stages over a BAND of rows of
 // one frame.  A workgroup copies the band of its input tensor (with the halo rows the group needs) from the per-frame HBM
@@ -2012,14 +1915,7 @@ __global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenPara
 // halo with them and interior band edges bring real neighbour rows; the producer fills halo columns (and the first / last
 // band the top / bottom halo row) before the copy-out.
 namespace band {
-#ifndef YF_BAND_LADDER
-#define YF_BAND_LADDER 1
-#endif
-#if YF_BAND_LADDER
 #define YF_BAND_PRIO(P) __builtin_amdgcn_s_setprio(P)      // priority ladder over a band job's stages (see the 56x56 kernel)
-#else
-#define YF_BAND_PRIO(P) do {} while (0)
-#endif
 constexpr int LB = LUT_BYTES;                                   // LUTs at LDS offset 0 (absolute addressing)
 // per-frame HBM arena of the banded form (bytes); rows are padded to multiples of 16 bytes so bands move as 16-byte vectors
 constexpr int T4_RS = G1 + 4, T8_RS = G2 + 4, T15_RS = G2 + 2;   // pixels per halo'd row
@@ -2104,9 +2000,6 @@ __device__ __forceinline__ void pf_commit_rows(const Prefetch<NT, CNT>& p, char*
 // jobs with the same few stages, so the vector-side blocks of those stages (1.4 KB for band_k1, 8 KB for band_k23) are loaded once per
 // workgroup -- into bytes of the LUT / residual-add-table area [0, LB) that the kernel's own stages never index -- instead of fetched from
 // global memory behind every stage boundary of every job (1.5-2.5 k cycles each; the band jobs ran at half the 56x56 kernel's per-pixel rate).
-#ifndef YF_BAND_LEAN
-#define YF_BAND_LEAN 1
-#endif
 template <int CS0, int CS1, int BASE_, int ZERO_, int JT_, int JT_BYTES_>
 struct BandLay {
   static constexpr int ZERO = ZERO_, JT = JT_, JT_BYTES = JT_BYTES_, FIRST = CS0, LAST = CS1, BASE = BASE_;
@@ -2166,11 +2059,9 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
   int vz = 0;
   asm volatile("" : "+v"(vz));
   load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-#if YF_BAND_LEAN
   __syncthreads();                                                // the LUT area is written; its unused bytes now take the resident pieces
   load_resident<LayK1, NT>(smem, tab, tid);
   v2::fill_jobtab<1, 1, L1_T1, L1_T2, 0, LayK1>(smem, tid);
-#endif
   const AddK no_add = {};
   const uint32_t z_in = splat((int)uniform_u32(tab + offsetof(yf_table_index, in_zp)));
   const uint32_t z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
@@ -2215,11 +2106,7 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     if (tid < K1_NIN) *reinterpret_cast<uint32_t*>(frames + L1_IN::OFF + tid * RSW * 4 + 12) = z_in;        // halo column (dword 3)
     lds_barrier();
     if (job + gridDim.x < jobs) fetch(job + gridDim.x);
-#if YF_BAND_LEAN
     v2::conv1_2_stage<F, NW, 0, L1_IN, L1_T1, LayK1>(frames, tab, wave, lane);
-#else
-    conv1_stage<F, NW, L1_IN, L1_T1>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
-#endif
     fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
     fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
     lds_barrier();
@@ -2227,201 +2114,17 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * K1_T1_ROW, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
     if (a == 0 || a + K1_BH == G1) lds_barrier();
     YF_BAND_PRIO(2);
-#if YF_BAND_LEAN
     v2::dw2_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4, 1, 0, LayK1>(frames, tab, wave, lane);
     lds_barrier();
     YF_BAND_PRIO(1);
     v2::dense2_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3, 2, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
     lds_barrier();
     v2::dense2_stage<F, NW, YF_BAND_TPJ ? 5 : 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4, 3, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
-#else
-    dw_mfma_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(1);
-    dense_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3>(frames, nullptr, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4>(frames, nullptr, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
-#endif
     fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
     lds_barrier();
     YF_BAND_PRIO(0);
     store_rows<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);              // halo'd rows a+1 ..
     if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
-  }
-}
-
-// ---- K2 ----------------------------------------------------------------------------------------------------------------
-constexpr int K2_BP = 8, K2_BANDS = G2 / K2_BP, K2_NR = 2 * K2_BP + 6;
-static_assert(G2 % K2_BP == 0 && K2_BP % 4 == 0, "band height must divide the grid; the vertical pool pass sweeps 4 rows");
-typedef Buf<LB,                                G1, K2_NR, 20, T4_RS,  0, 1> L2_T4;      // local row l = T4 row 2p-3+l (global halo'd row 2p-2+l)
-typedef Buf<LB + 2 * T4_ROW,                   G1, K2_NR, 20, T4_RS,  0, 1> L2_T4_DW;   // the same rows as conv2d_10 addresses them: halo'd row 2p = local 2
-typedef Buf<L2_T4::OFF + K2_NR * T4_ROW,       G2, K2_NR, 20, G2,     0, 0> L2_HB;
-typedef Buf<L2_HB::OFF,                        G2, K2_BP, 32, G2,     0, 0> L2_T6;      // aliases HB (dead after the vertical pool pass)
-typedef Buf<L2_HB::OFF + K2_NR * G2 * 20,      G2, K2_BP, 20, G2,     0, 0> L2_P8;
-typedef Buf<L2_P8::OFF + K2_BP * G2 * 20,      G2, K2_BP,  8, G2,     0, 0> L2_T7;
-typedef Buf<LB,                                G2, K2_BP, 36, T8_RS,  0, 1> L2_T8;      // aliases T4 (dead after conv2d_10)
-constexpr int K2_LDS = L2_T7::OFF + K2_BP * G2 * 8;
-static_assert(K2_BP * G2 * 32 <= K2_NR * G2 * 20 && K2_BP * T8_ROW <= K2_NR * T4_ROW, "aliases fit");
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k2(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  const AddK no_add = {};
-  const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15));
-  char* frames = smem;
-  const long jobs = prm.n * K2_BANDS;
-  Prefetch<NT, K2_NR * T4_ROW / 16> pre;
-  // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
-  auto range = [&](long job, const char*& src, int& lo_local, int& n16) {
-    const long fr = job / K2_BANDS;
-    const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;
-    const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K2_NR, G1 + 1);
-    src = prm.arena + fr * (long)ARENA_BYTES + A_T4 + lo * T4_ROW;
-    lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
-  };
-  long job = blockIdx.x;
-  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
-  for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K2_BANDS;
-    const int p0 = (int)(job - fr * K2_BANDS) * K2_BP;             // first 40x40 row of the band
-    char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    lds_barrier();
-    YF_BAND_PRIO(3);
-    { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L2_T4::OFF + ll * T4_ROW, n16, tid); }
-    lds_barrier();
-    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
-    {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
-      constexpr int NO = 5, NCH = G2 / NO;
-      static_assert(G2 % NO == 0, "sweeps of 5 outputs");
-      for (int i = tid; i < K2_NR * NCH * 5; i += NT) {
-        const int cg = i % 5; int t = i / 5;
-        const int k = t % NCH; const int l = t / NCH;
-        const char* row = frames + L2_T4::OFF + l * T4_ROW + 20 + 4 * cg;                 // pixel 0 sits behind the halo column
-        char* dst = frames + L2_HB::OFF + l * (G2 * 20) + 4 * cg;
-        pool8_sweep<NO, G1 - 1>(k * NO, [&](int x) { return lds_u32(row + x * 20); },
-                                [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
-      }
-    }
-    lds_barrier();
-    {   // vertical pass: output rows p0 .. p0+BP-1 need T4 rows 2p0-3 .. 2p0+2BP+2 clamped to the image = the band rows
-      constexpr int NO = 4, NSW = K2_BP / NO;
-      for (int i = tid; i < NSW * G2 * 5; i += NT) {
-        const int cg = i % 5; int t = i / 5;
-        const int ox = t % G2; const int sw = t / G2;
-        const char* col = frames + L2_HB::OFF + ox * 20 + 4 * cg;
-        char* dst = frames + L2_P8::OFF + ox * 20 + 4 * cg;
-        pool8_sweep<NO, G1 - 1>(p0 + sw * NO, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
-                                [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 20)) = lut4_raw<YF_L_Q21>(v); });
-      }
-    }
-    lds_barrier();                                                 // T6 (written next) aliases HB
-    YF_BAND_PRIO(2);
-    dw_mfma_stage<F, NW, 2, L2_T4_DW, L2_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(1);
-    dense_stage<F, NW, 1, 2, 16, L2_T6, L2_T7, 0, 6, EPI_RAW, 0, L2_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 3, 1, 8, L2_T7, L2_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L2_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
-    fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, 0, K2_BP, z_t8, tid);
-    fill_column<NT, T8_ROW, 36>(frames + L2_T8::OFF, G2 + 1, K2_BP, z_t8, tid);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    store_rows<NT>(arena + A_P8 + p0 * (G2 * 20), frames + L2_P8::OFF, K2_BP * G2 * 20, tid);
-    store_rows<NT>(arena + A_T7 + p0 * (G2 * 8), frames + L2_T7::OFF, K2_BP * G2 * 8, tid);
-    store_rows<NT>(arena + A_T8 + (p0 + 1) * T8_ROW, frames + L2_T8::OFF, K2_BP * T8_ROW, tid);              // halo'd rows p0+1 ..
-    if (p0 == 0) fill_dwords<NT>(arena + A_T8, z_t8, T8_ROW, tid);
-    if (p0 + K2_BP == G2) fill_dwords<NT>(arena + A_T8 + (G2 + 1) * T8_ROW, z_t8, T8_ROW, tid);
-  }
-}
-
-// ---- K3 ----------------------------------------------------------------------------------------------------------------
-constexpr int K3_BP = 8, K3_BANDS = G2 / K3_BP;
-static_assert(G2 % K3_BP == 0, "band height must divide the grid");
-typedef Buf<LB,                                  G2, K3_BP + 2, 36, T8_RS,  0, 1> L3_T8;    // halo'd rows p0 .. p0+BP+1
-typedef Buf<L3_T8::OFF + (K3_BP + 2) * T8_ROW,   G2, K3_BP,     48, G2,     0, 0> L3_T9;
-typedef Buf<L3_T9::OFF + K3_BP * G2 * 48,        G2, K3_BP,      8, G2,     0, 0> L3_T7;
-typedef Buf<L3_T7::OFF + K3_BP * G2 * 8,         G2, K3_BP,      8, G2,     0, 0> L3_T11;
-typedef Buf<L3_T11::OFF + K3_BP * G2 * 8,        G2, K3_BP,     48, G2,     0, 0> L3_T14;
-typedef Buf<L3_T14::OFF + K3_BP * G2 * 48,       G2, K3_BP,     24, T15_RS, 0, 1> L3_T15;
-constexpr int K3_LDS = L3_T15::OFF + K3_BP * T15_ROW;
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k3(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  const uint32_t z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
-  char* frames = smem;
-  const long jobs = prm.n * K3_BANDS;
-  constexpr int N_T8 = (K3_BP + 2) * T8_ROW / 16, N_T7 = K3_BP * G2 * 8 / 16, N_P8 = K3_BP * G2 * 20 / 16;
-  Prefetch<NT, N_T8> pre8;
-  Prefetch<NT, N_T7> pre7;
-  Prefetch<NT, N_P8> prep;
-  auto fetch = [&](long job) {
-    const long fr = job / K3_BANDS;
-    const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
-    const char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    pf_fetch(pre8, arena + A_T8 + p0 * T8_ROW, N_T8, tid);
-    pf_fetch(pre7, arena + A_T7 + p0 * (G2 * 8), N_T7, tid);
-    pf_fetch(prep, arena + A_P8 + p0 * (G2 * 20), N_P8, tid);
-  };
-  long job = blockIdx.x;
-  if (job < jobs) fetch(job);
-  for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K3_BANDS;
-    const int p0 = (int)(job - fr * K3_BANDS) * K3_BP;
-    char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    lds_barrier();
-    YF_BAND_PRIO(3);
-    pf_commit(pre8, frames + L3_T8::OFF, N_T8, tid);
-    pf_commit(pre7, frames + L3_T7::OFF, N_T7, tid);
-#pragma unroll
-    for (int k = 0; k < prep.PER; ++k) {                                   // pooled half of concat_22: 20 of every 48 bytes
-      const int i = tid + k * NT;
-      if (i < N_P8) {
-        const uint32_t w[4] = {prep.v[k][0], prep.v[k][1], prep.v[k][2], prep.v[k][3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int d = 4 * i + j, px = d / 5, c = d - 5 * px;
-          *reinterpret_cast<uint32_t*>(frames + L3_T14::OFF + px * 48 + 4 * c) = w[j];
-        }
-      }
-    }
-    lds_barrier();
-    if (job + gridDim.x < jobs) fetch(job + gridDim.x);
-    dw_mfma_stage<F, NW, 1, L3_T8, L3_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(2);
-    dense_stage<F, NW, 1, 3, 16, L3_T9, L3_T11, 0, 6, EPI_ADD, YF_A_ADD18, L3_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 2, 1, 8, L3_T11, L3_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L3_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(1);
-    dense_stage<F, NW, 2, 3, 16, L3_T14, L3_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L3_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
-    fill_column<NT, T15_ROW, 24>(frames + L3_T15::OFF, 0, K3_BP, z_t15, tid);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L3_T15::OFF, K3_BP * T15_ROW, tid);
-    if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
   }
 }
 
@@ -2475,13 +2178,11 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
                 (int)uniform_u32(a + offsetof(yf_add, rso))};
   };
   const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15)), z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
-#if YF_BAND_LEAN
   constexpr int JT_DW10 = 0, JT_DW15 = 8 * v2::DwGeo<1, 2, L23_T4_DW, L23_T6>::JPG;
   __syncthreads();
   load_resident<LayK23, NT>(smem, tab, tid);
   v2::fill_jobtab<1, 2, L23_T4_DW, L23_T6, JT_DW10, LayK23>(smem, tid);
   v2::fill_jobtab<1, 1, L23_T8, L23_T9, JT_DW15, LayK23>(smem, tid);
-#endif
   char* frames = smem;
   const long jobs = prm.n * K23_BANDS;
   Prefetch<NT, K23_NR * T4_ROW / 16> pre;
@@ -2530,19 +2231,11 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     }
     lds_barrier();                                                 // T6 (written next) aliases HB
     YF_BAND_PRIO(2);
-#if YF_BAND_LEAN
     v2::dw2_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11, 4, JT_DW10, LayK23>(frames, tab, wave, lane);               // ten rows
     lds_barrier();
     v2::dense2_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7, 5, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
     lds_barrier();
     v2::dense2_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8, 6, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-#else
-    dw_mfma_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);      // ten rows
-    lds_barrier();
-    dense_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7>(frames, nullptr, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8>(frames, nullptr, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
-#endif
     fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
     fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
     lds_barrier();
@@ -2550,7 +2243,6 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * K23_T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
     if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
     YF_BAND_PRIO(1);
-#if YF_BAND_LEAN
     v2::dw2_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16, 7, JT_DW15, LayK23>(frames, tab, wave, lane);
     lds_barrier();
     v2::dense2_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C, 8, -1, 0, -1, LayK23>(frames, nullptr, tab, addctx(YF_A_ADD18), wave, lane);
@@ -2559,16 +2251,6 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     lds_barrier();
     YF_BAND_PRIO(0);
     v2::dense2_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15, 10, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-#else
-    dw_mfma_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C>(frames, nullptr, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 2, 1, 8, L23_T11, L23_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L23_T14>(frames, nullptr, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    dense_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15>(frames, nullptr, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
-#endif
     fill_column<NT, T15_ROW, 24>(frames + L23_T15::OFF, 0, K23_BP, z_t15, tid);
     lds_barrier();
     store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L23_T15::OFF, K23_BP * T15_ROW, tid);
@@ -2622,11 +2304,7 @@ constexpr bool k4_ring_ok() {
   return true;
 }
 static_assert(k4_ring_ok(), "every tail block (without its add tables) fits its ring slot");
-#if YF_BAND_LEAN
 constexpr int K4_LDS = K4_BUFS_END + v2::ZERO_B + LayK4::JT_BYTES;
-#else
-constexpr int K4_LDS = K4_BUFS_END;
-#endif
 static_assert(K4_LDS <= 81920, "two workgroups per CU");
 
 // pool_25 for output rows [oy0, oy0 + K4_HALF) from a T15 half whose first halo'd row is h0
@@ -2646,7 +2324,6 @@ YF_STAGE_FN void pool25_half(char* frames, int oy0, int h0, int tid) {
   }
 }
 
-#if YF_BAND_LEAN
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2744,78 +2421,6 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
 #undef K4_SYNC
 #undef K4_DENSE
 }
-#else
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  char* frames = smem;
-  constexpr int N0 = K4_ROWS0 * T15_ROW / 16, N1 = K4_ROWS1 * T15_ROW / 16, H1 = 2 * K4_HALF;     // halves: vectors, first halo'd row of the second
-  Prefetch<NT, N0> pre;
-  long fr = blockIdx.x;
-  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N0, tid);
-  for (; fr < prm.n; fr += gridDim.x) {
-    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
-    const char* t15 = prm.arena + fr * (long)ARENA_BYTES + A_T15;
-    YF_BAND_PRIO(3);
-    lds_barrier();
-    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N0, tid);    // halo'd rows 0 .. ROWS0-1
-    lds_barrier();
-    pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
-    pool25_half<NT>(frames, 0, 0, tid);
-    dw_mfma_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
-    lds_barrier();
-    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N1, tid);    // halo'd rows H1 .. G2
-    lds_barrier();
-    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
-    pool25_half<NT>(frames, K4_HALF, H1, tid);
-    dw_mfma_stage<F, NW, 2, L4_T15H, L4_T17B, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(2);
-    dense_stage<F, NW, 1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
-    lds_barrier();
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
-    dense_stage<F, NW, 3, 1, 8, L4_T18, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, wave, lane, vz);
-    lds_barrier();
-    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(1);
-    dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
-    lds_barrier();
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
-    dense_stage<F, NW, 3, 1, 8, L4_T22, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, wave, lane, vz);
-    lds_barrier();
-    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    dense_stage<F, NW, 2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
-    lds_barrier();
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
-    dense_stage<F, NW, 2, 3, 16, L4_T30, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, L4_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane, vz);
-    lds_barrier();
-    dw_mfma_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 2, 3, 16, L4_T20, L4_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane, vz);
-    lds_barrier();
-    dense_stage<F, NW, 1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
-  }
-}
-#endif
 }  // namespace band
 #endif  // YF_GENERIC
 

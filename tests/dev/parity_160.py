@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""160x160 parity of the banded (default) or layer-by-layer (YF_160_LAYERWISE=1) path against the CPU oracle (debug tool; runs on the GPU box)."""
+"""160x160 parity of the banded path -- or, with the lab library (YF_LIB_PATH=.../lib_lab/libyf_network.so) and YF_160_LAYERWISE=1, of the layer-by-layer
+   form -- against the CPU oracle.  Test helper (tests/test_gpu_parity.py runs it in a fresh process); runs on the GPU box."""
 import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle.oracle import Oracle
 yf = importlib.import_module("stm32h7-yolo_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6

@@ -2,7 +2,7 @@
 """Which stage tensors of the debug (dump) build differ from the oracle's per-op outputs?  Prints every stage, does not stop at the first.  DEV TOOL."""
 import importlib, sys, os
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 yf = importlib.import_module("stm32h7-yolo_amd")
 from oracle.np_restatement import load_yfm

@@ -18,7 +18,8 @@ STAGES = [("T1", 2), ("T2", 4), ("T3", 5), ("T4", 7), ("Q21", 21), ("T6", 11), (
           ("T22", 35), ("T23", 37), ("T24", 39), ("T26", 41), ("T30", 46), ("T31", 48), ("T32", 50), ("T33", 52),
           # tensors the fused stages never materialise, dumped for the per-node observer: raw max-pools, convolutions in front of the adds
           ("P8", 8), ("C17", 17), ("P25", 25), ("C34", 34), ("C40", 40), ("L43", 43)]
-VARIANTS = [(1, 4), (1, 8), (2, 4), (2, 8), (4, 8), (202, 8)]     # (202, 8): the experimental (YF_EXP) build of the shipped shape
+VARIANTS = [(1, 8), (2, 8)]     # the product's two shapes (the lab library's other shapes: test_lab_library_shapes_agree)
+LAB_LIB = os.path.join(ROOT, "stm32h7-yolo_amd", "lib_lab", "libyf_network.so")
 
 
 @pytest.fixture(scope="module")
@@ -210,7 +211,7 @@ def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), a[perm])                # frames are independent
 
 
-@pytest.mark.parametrize("shape", [(2, 8), (1, 4), (4, 8)])
+@pytest.mark.parametrize("shape", [(2, 8), (1, 8)])
 def test_tail_pairing_patterns(network, oracle, torch_cuda, shape):
     """Tail batching runs the 7x7 stages once per PAIR of a workgroup's frame groups.  Batch sizes around the multiples of the
     resident grid give workgroups with 1, 2, 3, 4 ... groups (paired, unpaired last, half-filled last group); frames are drawn
@@ -424,15 +425,26 @@ def test_baseline_config5_160x160(network, oracle, torch_cuda):
     assert (ei.value.type, ei.value.code) == (0x12, 0x18)
 
 
+@pytest.mark.skipif(not os.path.exists(LAB_LIB), reason="the lab library is not built (make -C stm32h7-yolo_amd/csrc lab)")
 def test_160x160_layer_by_layer_form_agrees(torch_cuda):
-    """The layer-by-layer form of the 160x160 path (one kernel per stage over an HBM arena; YF_160_LAYERWISE=1, kept as the
-    plain statement the banded kernels are debugged against) gives the same heads: tools/gpu_parity_160.py compares it with
-    the oracle in a fresh process, because the form is chosen when the engine is created."""
+    """The layer-by-layer form of the 160x160 path (one kernel per stage over an HBM arena; the LAB library with YF_160_LAYERWISE=1, kept as
+    the plain statement the banded kernels are debugged against) gives the same heads: tests/dev/parity_160.py compares it with the oracle
+    in a fresh process, because library and form are chosen when the engine is created."""
     import subprocess, sys
-    env = dict(os.environ, YF_160_LAYERWISE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_parity_160.py"), "4"], env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, YF_160_LAYERWISE="1", YF_LIB_PATH=LAB_LIB)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "parity_160.py"), "4"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "160x160 head ok" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(LAB_LIB), reason="the lab library is not built (make -C stm32h7-yolo_amd/csrc lab)")
+def test_lab_library_shapes_agree(torch_cuda):
+    """The other fused shapes (<1,4>, <2,4>, <4,8>) live in the lab library only (make lab): bit-exact against the oracle on ragged batches
+    (tests/dev/lab_shapes.py, fresh process with YF_LIB_PATH)."""
+    import subprocess, sys
+    env = dict(os.environ, YF_LIB_PATH=LAB_LIB)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "lab_shapes.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lab shapes ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):

@@ -9,7 +9,7 @@ i=0
 for lib in "$@"; do
   i=$((i+1))
   export YF_LIB_PATH=$PWD/$lib
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/t$i -o t -- python3 tools/gpu_parity_160.py 6 > $OUT/run$i.log 2> $OUT/err$i.log
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/t$i -o t -- python3 tests/dev/parity_160.py 6 > $OUT/run$i.log 2> $OUT/err$i.log
   echo "== $lib: $(tail -1 $OUT/run$i.log)"
   python3 - $OUT/t$i <<'PY'
 import csv, glob, sys, collections

@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 yf = importlib.import_module("stm32h7-yolo_amd")
 n, cap = 4096, 4
 net = yf.Network().init()
-if len(sys.argv) > 1 and sys.argv[1] == "exp": net.configure(202, 8)      # the experimental namespace of a library built with YF_EXP_MASK
 rng = np.random.default_rng(5)
 ins = [torch.from_numpy(rng.integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)).cuda() for _ in range(8)]
 d_out = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
