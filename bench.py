@@ -327,6 +327,8 @@ def main():
     ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if world > 1 else None
     if world > 1 and not np.array_equal(heads[:n_chk], ref_heads):
         problems.append(f"rank {rank}: heads differ from the oracle on its first {n_chk} frames")
+    if world > 1 and os.environ.get("YF_BENCH_TEST_FAIL_RANK") == str(rank):         # read by ONE test only: rehearses "a rank's check fails -> every
+        problems.append(f"rank {rank}: parity failure forced by YF_BENCH_TEST_FAIL_RANK")   # rank exits non-zero after rank 0 has printed its line"
     for f in range(min(n_chk, 64)):             # decoded records of the first frames against the oracle's decode of the GPU heads
         want = orc.decode_py(heads[f], f, 1.0, 1.0)
         got = [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["q_conf"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in dets[f, :min(cap, counts[f])]]

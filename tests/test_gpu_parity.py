@@ -850,6 +850,25 @@ def test_bench_two_ranks_exchange_detections(tmp_path):
     assert 0 < line["config"]["exchange_bytes_per_rank_per_step"] <= 600_000
 
 
+def test_bench_two_ranks_gather_heads_and_a_failing_rank():
+    """Two more rehearsals of the N > 1 path on one GPU (gloo), before the first real 8-rank run: (1) --gather-heads (the exchange record grows by
+    the 3.6 MB of int8 heads per rank); (2) rank 1's parity check forced to fail (YF_BENCH_TEST_FAIL_RANK, read only here): rank 0 still prints
+    its line, the line says FAILED, and the command exits non-zero."""
+    import json
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd + ["--gather-heads"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["all_gather_ok"] is True and line["config"]["exchange_bytes_per_rank_per_step"] > 4096 * 882
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, YF_BENCH_TEST_FAIL_RANK="1"))
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(lines[0])["parity"].startswith("FAILED")
+
+
 def test_c_level_all_gather_through_rccl(network, torch_cuda):
     """yf_network_all_gather_device: the exchange step a C host application calls (one process per GPU, its own ncclComm_t).
     With one GPU on the box the communicator has one rank; the call still goes through librccl's ncclAllGather on the
