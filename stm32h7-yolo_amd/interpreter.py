@@ -87,15 +87,6 @@ class Interpreter:
         return self._out.copy()
 
 
-def xywh2xyxy(x):                                     # tflite_prediction.py:5-11
-    y = np.zeros(x.shape, dtype=np.float32)
-    y[..., 0] = x[..., 0] - x[..., 2] / 2
-    y[..., 1] = x[..., 1] - x[..., 3] / 2
-    y[..., 2] = x[..., 0] + x[..., 2] / 2
-    y[..., 3] = x[..., 1] + x[..., 3] / 2
-    return y
-
-
 def decode_boxes(head, conf_thres=0.7, w_scale=1.0, h_scale=1.0):
     """tflite_prediction.py:42-63 for one int8 head [7,7,18]: int32 boxes [k,4] in (a,row,col) order."""
     sig, ex = decode_tables()
@@ -112,9 +103,9 @@ def decode_boxes(head, conf_thres=0.7, w_scale=1.0, h_scale=1.0):
     x = output[output[..., 4] > np.float32(conf_thres)]
     if not x.shape[0]:
         return np.zeros((0, 4), np.int32)
-    boxes = xywh2xyxy(x[:, :4])
-    boxes[:, [0, 2]] *= np.float32(w_scale)
-    boxes[:, [1, 3]] *= np.float32(h_scale)
+    half = x[:, 2:4] / 2                                      # centre +- half the size (float32 throughout, as the reference computes it)
+    boxes = np.concatenate([x[:, 0:2] - half, x[:, 0:2] + half], axis=1)
+    boxes *= np.array([w_scale, h_scale, w_scale, h_scale], np.float32)
     return boxes.astype(np.int32)
 
 
