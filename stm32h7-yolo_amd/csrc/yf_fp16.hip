@@ -743,12 +743,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
 #elif defined(YF16_STAGEPMC)
-  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop, every frame is abandoned behind its barrier number `stop`;
-  // the differences between consecutive launches are the stages' instruction counts.  Results are wrong by construction.
+  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop = 1 .. 14, every frame is abandoned behind its barrier number `stop`
+  // and the tail phase is skipped; stop = 0 runs everything.  The differences between consecutive launches are the stages' instruction counts.  Results
+  // are wrong by construction.
   int stage_no = 0;
 #define SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (++stage_no == prm.stop) continue; }
+#define SYNC_BATCH() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #else
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#endif
+#ifndef YF16_STAGEPMC
+#define SYNC_BATCH() SYNC()
 #endif
 #define FETCH(K) fetch_w<K, NW>(tab, conv_at(K).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #ifdef YF16_BARPROF
     prof_on = false;
 #endif
-    SYNC();
+    SYNC_BATCH();
     for (int k = 0; k < nb; ++k) {
     const long fr = base + k * G;
     int tid = tid0;
@@ -878,14 +883,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #ifdef YF16_BARPROF
       bar_no = 20; prof_on = prof_out != nullptr && base == (long)blockIdx.x;
 #endif
+#ifdef YF16_STAGEPMC
+      if (prm.stop > 0) continue;                                 // counting a front stage: no tail phase
+#endif
       fetch_tailw<NW>(tab0, wave, lane);
       for (int i = tid; i < NW * XB / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
-      SYNC();
+      SYNC_BATCH();
       if (wave < nb) tail_chain<NW>(wave * XB, prm.scratch + ((long)blockIdx.x * NW + wave) * PARK_BYTES, prm.out + (base + wave * G) * (7 * 7 * 18), lane);
-      SYNC();                                                     // the next batch's clear overwrites the buffers
+      SYNC_BATCH();                                               // the next batch's clear overwrites the buffers
     }
   }
 #undef SYNC
+#undef SYNC_BATCH
 #undef SYNC_KEEP_PREFETCH
 #undef FETCH
 }

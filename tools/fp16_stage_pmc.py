@@ -9,13 +9,13 @@ import csv, glob, importlib, os, sys
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = 4096
-# barrier-delimited stages in launch order (stop = 1 ... 27, then the full kernel) and their conv outputs per frame
-STAGES = [("arena clear + top barrier", 0), ("input staging + halo fills", 0), ("conv2d_1", 6272), ("conv2d_3 (dw)", 6272), ("conv2d_5", 3136),
+# barrier-delimited front stages in launch order (stop = 1 ... 14: every frame is abandoned behind that barrier, no tail phase), then the full kernel
+# (stop = 0): its difference to stop = 14 is the tail phase (conv2d_29 .. conv2d_53, one frame per wave) + the per-batch arena clear / weight fetch
+STAGES = [("input staging + halo fills", 0), ("conv2d_1", 6272), ("conv2d_3 (dw)", 6272), ("conv2d_5", 3136),
           ("conv2d_6", 14112), ("pool_8 h", 0), ("pool_8 v + conv2d_10 (dw)", 3528), ("conv2d_12", 1176), ("conv2d_13", 7056),
-          ("conv2d_15 (dw)", 7056), ("conv2d_17+add", 1176), ("conv2d_19", 3528), ("conv2d_23 (+ parking / fetch of the parked T15)", 4704),
-          ("pool_25 + conv2d_27 (dw)", 1176), ("conv2d_29", 392), ("conv2d_30", 1960), ("conv2d_32 (dw)", 1960), ("conv2d_34+add", 392),
-          ("conv2d_36", 1960), ("conv2d_38 (dw)", 1960), ("conv2d_40+add", 392), ("conv2d_42", 1176), ("conv2d_47", 1960), ("conv2d_49 (dw)", 1960),
-          ("conv2d_51", 1568), ("conv2d_53 (head) + stores", 882)]
+          ("conv2d_15 (dw)", 7056), ("conv2d_17+add", 1176), ("conv2d_19", 3528), ("conv2d_23", 4704),
+          ("pool_25 + conv2d_27 (dw) -> park", 1176),
+          ("tail phase: conv2d_29 .. conv2d_53", 392 + 1960 * 3 + 392 * 2 + 1960 * 2 + 1176 + 1960 + 1568 + 882)]
 
 
 def run():
@@ -24,7 +24,7 @@ def run():
     x = (np.random.default_rng(3).integers(0, 256, (N, 56, 56, 3)).astype(np.float32) / 255.0).astype(np.float16)
     net = yf.Network().init(); net.fp16_init()
     d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((N, 7, 7, 18), dtype=torch.float32, device="cuda")
-    for k in list(range(1, len(STAGES))) + [0]:
+    for k in list(range(1, len(STAGES))) + [0]:      # stops 1 .. 14, then everything
         os.environ["YF16_STOP_STAGE"] = str(k)
         net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), N)
     torch.cuda.synchronize()
@@ -46,7 +46,7 @@ def report(roots):
     floor = lambda i: STAGES[i][1] / 64.0 * 2.5 if STAGES[i][1] else None      # v_mul + v_max per output, one v_cvt_pk per two   # noqa: E731
     has_valu = "SQ_INSTS_VALU" in ctrs
     print(f"{'stage':32s}" + "".join(f"{c[3:] if c.startswith('SQ_') else c:>18s}" for c in ctrs)
-          + (f"{'conv outputs':>14s}{'VALU floor':>12s}{'VALU/floor':>12s}" if has_valu else "") + "   (per frame; the tail runs once per pair of frames)")
+          + (f"{'conv outputs':>14s}{'VALU floor':>12s}{'VALU/floor':>12s}" if has_valu else "") + "   (per frame)")
     prev = {c: 0.0 for c in ctrs}; tot_floor = 0.0
     for i in range(len(STAGES)):
         cur = per[i]
