@@ -149,6 +149,12 @@ __device__ __forceinline__ uint2 lds_tap64(const char* p) {
 typedef const __attribute__((address_space(4))) v4f* cv4f_ptr;
 __device__ __forceinline__ v4f uniform_f4(const void* p) { return *(cv4f_ptr)(uintptr_t)p; }
 
+// absolute LDS addresses (the kernel has no static LDS: the dynamic segment starts at 0; `lds + offset` costs a v_add of the segment base per address)
+typedef __attribute__((address_space(3))) v4i* lds_v4i_p;
+typedef __attribute__((address_space(3))) v2u_t* lds_v2u_p;
+__device__ __forceinline__ v4i ld128(int a) { return *(const lds_v4i_p)(uintptr_t)(uint32_t)a; }
+__device__ __forceinline__ uint2 ld64(int a) { const v2u_t v = *(const lds_v2u_p)(uintptr_t)(uint32_t)a; return uint2{v.x, v.y}; }
+__device__ __forceinline__ void st64(int a, uint2 v) { *(lds_v2u_p)(uintptr_t)(uint32_t)a = v2u_t{v.x, v.y}; }
 template <int JOBS, int NW>
 __device__ __forceinline__ void job_range(int wave, int& j0, int& j1) {
   constexpr int BASE = JOBS / NW, REM = JOBS % NW;
@@ -222,12 +228,6 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
 // kernel names one per stage) -- so a chunk set-up is ONE address instruction and KS unmasked ds_read_b128 per pass instead of four zero moves, an exec
 // mask and a masked read per fragment.  The biases come with the block (LDS-DMA), are read into VGPRs once per chunk with one broadcast ds_read_b128 per
 // pass and enter the MFMA as its C operand: no scalar load, no move per pass and job.
-// absolute LDS addresses (the kernel has no static LDS: the dynamic segment starts at 0; `lds + offset` costs a v_add of the segment base per address)
-typedef __attribute__((address_space(3))) v4i* lds_v4i_p;
-typedef __attribute__((address_space(3))) v2u_t* lds_v2u_p;
-__device__ __forceinline__ v4i ld128(int a) { return *(const lds_v4i_p)(uintptr_t)(uint32_t)a; }
-__device__ __forceinline__ uint2 ld64(int a) { const v2u_t v = *(const lds_v2u_p)(uintptr_t)(uint32_t)a; return uint2{v.x, v.y}; }
-__device__ __forceinline__ void st64(int a, uint2 v) { *(lds_v2u_p)(uintptr_t)(uint32_t)a = v2u_t{v.x, v.y}; }
 constexpr int dense_rows_bytes(int cout, int ks) { return ((cout + 3) / 4) * 4 * 8 * ks * 2; }
 template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int ZB, int F = 1>
 __device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0, int wave, int lane, float* __restrict__ out_frame1 = nullptr) {
@@ -498,45 +498,56 @@ __device__ __forceinline__ uint32_t pkmaxh(uint32_t a, uint32_t b) {      // v_p
   uint32_t o; __builtin_memcpy(&o, &r, 4); return o;
 }
 // 8-wide stride-2 window [2o-3, 2o+4] = four odd pairs R[j] = max(c[2j+1], c[2j+2]); S[j] = max(R[j], R[j+1]);
-// out[o] = max(S[o-2], S[o]); coordinates clamped into [0, LIM] (max is idempotent).  NO outputs per sweep.
-template <int NO, int LIM, class LOADC, class STORE>
-__device__ __forceinline__ void pool8_sweep(int o0, LOADC loadc, STORE store) {
+// out[o] = max(S[o-2], S[o]); coordinates clamped into [0, LIM] (max is idempotent).  NO outputs from O0 on per sweep; O0 is a compile-time
+// constant, so every clamped coordinate is one and the loads' offsets are immediates (round 3 computed ~85 address instructions per item).
+// V: the packed value type (one or two dwords of fp16 pairs).
+template <int O0, int NO, int LIM, class V, class MAX, class LOADC, class STORE>
+__device__ __forceinline__ void pool8_sweep(MAX mx, LOADC loadc, STORE store) {
   constexpr int NR = NO + 3;
-  uint32_t r[NR];
+  V r[NR];
 #pragma unroll
   for (int jj = 0; jj < NR; ++jj) {
-    const int j = o0 - 2 + jj;
-    r[jj] = pkmaxh(loadc(min(max(2 * j + 1, 0), LIM)), loadc(min(max(2 * j + 2, 0), LIM)));
+    constexpr int dummy = 0; (void)dummy;
+    const int j = O0 - 2 + jj;
+    const int xa = 2 * j + 1 < 0 ? 0 : (2 * j + 1 > LIM ? LIM : 2 * j + 1), xb = 2 * j + 2 < 0 ? 0 : (2 * j + 2 > LIM ? LIM : 2 * j + 2);
+    r[jj] = xa == xb ? loadc(xa) : mx(loadc(xa), loadc(xb));
   }
-  uint32_t q[NR - 1];
+  V q[NR - 1];
 #pragma unroll
-  for (int jj = 0; jj < NR - 1; ++jj) q[jj] = pkmaxh(r[jj], r[jj + 1]);
+  for (int jj = 0; jj < NR - 1; ++jj) q[jj] = mx(r[jj], r[jj + 1]);
 #pragma unroll
-  for (int n = 0; n < NO; ++n) store(o0 + n, pkmaxh(q[n], q[n + 2]));
+  for (int n = 0; n < NO; ++n) store(O0 + n, mx(q[n], q[n + 2]));
 }
-template <int NT>
-__device__ __forceinline__ void pool8_h(char* lds, int tid) {                 // T4 [28][28] x 18 ch -> HB [28 rows][14]
-  constexpr int NO = 7, OW = 14, NCH = 2, ND = 9;                              // 9 dwords = 18 channels; 28 x 2 x 9 = 504 items: one round of the 512 threads
-  for (int i = tid; i < 28 * NCH * ND; i += NT) {
-    const int d = i % ND; int t = i / ND;
-    const int k = t % NCH; const int y = t / NCH;
-    const char* row = lds + B_T4::at(y, 0) + 4 * d;
-    char* dst = lds + B_HB::OFF + (y * OW) * B_HB::S + 4 * d;
-    pool8_sweep<NO, 27>(min(k * NO, OW - NO), [&](int x) { return lds_u32(row + x * B_T4::S); },
-                        [&](int ox, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + ox * B_HB::S) = v; });
-  }
+typedef __attribute__((address_space(3))) uint32_t* lds_u32w_p;
+__device__ __forceinline__ uint32_t ld32(int a) { return *(const lds_u32w_p)(uintptr_t)(uint32_t)a; }
+__device__ __forceinline__ void st32(int a, uint32_t v) { *(lds_u32w_p)(uintptr_t)(uint32_t)a = v; }
+// pool_8, horizontal pass: T4 [28][28] x 18 ch -> HB [28 rows][14].  An item = (row, 8-byte chunk of the 40-byte pixel: four channels) sweeps HALF a
+// row (seven outputs, twenty ds_read_b64); the half is wave-uniform (waves 0-2: outputs 0..6, waves 3-5: 7..13), so its coordinates are immediates.
+// 2 x 140 items on six waves.
+template <int O0>
+__device__ __forceinline__ void pool8_h_half(int row, int dst, bool two) {
+  auto mx = [](uint2 a, uint2 b) { return uint2{pkmaxh(a.x, b.x), pkmaxh(a.y, b.y)}; };
+  pool8_sweep<O0, 7, 27, uint2>(mx, [&](int x) { return ld64(row + x * B_T4::S); },
+                                [&](int ox, uint2 v) { st32(dst + ox * B_HB::S, v.x); if (two) st32(dst + ox * B_HB::S + 4, v.y); });
 }
-template <int NT>
-__device__ __forceinline__ void pool8_v(char* lds, int tid) {                 // HB -> pool half of concat_22 (T14 channels 0..17)
-  constexpr int NO = 5, OW = 14, OH = 14, NCH = 3, ND = 9;
-  for (int i = tid; i < OW * NCH * ND; i += NT) {
-    const int d = i % ND; int t = i / ND;
-    const int k = t % NCH; const int ox = t / NCH;
-    const char* col = lds + B_HB::OFF + ox * B_HB::S + 4 * d;
-    char* dst = lds + B_T14::OFF + ox * B_T14::S + 4 * d;
-    pool8_sweep<NO, 27>(min(k * NO, OH - NO), [&](int r) { return lds_u32(col + r * (OW * B_HB::S)); },
-                        [&](int oy, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + oy * (OW * B_T14::S)) = v; });
-  }
+__device__ __forceinline__ void pool8_h(int wave, int lane) {
+  static_assert(B_T4::S == 40 && B_T4::OFF % 8 == 0 && B_T4::ROWB % 8 == 0 && B_HB::S == 36, "8-byte chunks of T4's pixels, dword stores into HB's");
+  if (wave >= 6) return;
+  const int hw = wave >= 3 ? 1 : 0;
+  const int it = min((wave - 3 * hw) * 64 + lane, 139);          // surplus lanes redo the last item (same values, same addresses)
+  const int q = (it * 2341) >> 16, y = it - 28 * q;              // chunk = it / 28 (rows vary fastest: 34-dword row pitch mod 64 spreads the lanes over the banks)
+  const int row = B_T4::at(y, 0) + 8 * q, dst = B_HB::OFF + y * (14 * B_HB::S) + 8 * q;
+  if (hw == 0) pool8_h_half<0>(row, dst, q < 4); else pool8_h_half<7>(row, dst, q < 4);
+}
+// pool_8, vertical pass: HB -> pool half of concat_22 (T14 channels 0..17).  An item = (column, channel dword) sweeps its whole column (fourteen outputs,
+// twenty-eight loads at immediate offsets): 126 items = two waves; the other waves of the stage run conv2d_10, which does not touch HB or T14.
+constexpr int POOL8V_WAVES = 2;
+__device__ __forceinline__ void pool8_v(int item) {
+  const int it = min(item, 14 * 9 - 1);
+  const int ox = (it * 7282) >> 16, d = it - 9 * ox;             // it / 9
+  const int col = B_HB::OFF + 4 * it, dst = B_T14::OFF + ox * B_T14::S + 4 * d;
+  pool8_sweep<0, 14, 27, uint32_t>([](uint32_t a, uint32_t b) { return pkmaxh(a, b); }, [&](int r) { return ld32(col + r * (14 * B_HB::S)); },
+                                   [&](int oy, uint32_t v) { st32(dst + oy * (14 * B_T14::S), v); });
 }
 // pool_25 by COLUMNS (as in the int8 kernel): one item = (frame, output column, channel dword) walks the 14 rows of T15 once -- per row
 // the horizontal 4-tap maximum (clamped columns), pairs of rows R[j] = max(h[2j-1], h[2j]), out[oy] = max(R[oy], R[oy+1]) -- and writes
@@ -837,11 +848,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     fill_halo<B_T4, false, NT>(lds, tid);
     dense_tile_stage<3, NW, (NW > 8 ? 3 : 5), 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4, ZSLACK>(nullptr, wave, lane);     // conv2d_6
     SYNC();
-    pool8_h<NT>(lds, tid);
+    pool8_h(wave, lane);
     SYNC();
     FETCH(5);
-    pool8_v<NT>(lds, tid);                                                                            // pool_8 -> concat_22[0,18)
-    conv3x3_stage<4, NW, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave, lane);                     // conv2d_10 (dw, stride 2)
+    if (wave < POOL8V_WAVES) pool8_v(wave * 64 + lane);                                               // pool_8 -> concat_22[0,18) ...
+    else conv3x3_stage<4, NW - POOL8V_WAVES, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave - POOL8V_WAVES, lane);   // ... beside conv2d_10 (dw, stride 2)
     SYNC();
     FETCH(6);
     dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(nullptr, wave, lane);   // conv2d_12
