@@ -58,8 +58,7 @@ struct Buf {
 //              OFF    W   H   S  RS PT PL
 typedef Buf<     0, 56, 56,  8, 57, 1, 1> B_IN;    // RGBX fp16, top/left halo (3x3 stride 2, pad 1)
 typedef Buf< 26000, 28, 28, 16, 30, 1, 1, 0, YF16_ROW_SKEW> B_T1;    // conv1 out, 8 ch, halo ring; 30 rows of 488 bytes
-typedef Buf< 40640, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch
-typedef Buf<     0, 28, 28, 16, 28, 0, 0> B_T3;    // c5 out, 4 ch in an 8-channel pixel (upper half zero)
+typedef Buf<     0, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch (on the dead input frame: conv2d_5 -> conv2d_6 reads it while it writes T4)
 typedef Buf< 12544, 28, 28, 40, 29, 1, 1> B_T4;    // c6 out, 18 ch (stride 20), top/left halo for dw10
 typedef Buf< 46184, 14, 28, 36, 14, 0, 0> B_HB;    // pool_8 horizontal pass, 18 ch
 typedef Buf< 60304, 14, 14, 80, 14, 0, 0> B_T14;   // concat: pool [0,18) | conv [20,38) (8-byte aligned start), stride 40; 16-byte aligned pixels (conv2d_23 reads them with ds_read_b128)
@@ -74,7 +73,7 @@ constexpr int ZSLACK = 75984;                       // the 48 bytes between the 
 static_assert(ZSLACK == B_T14::OFF + 14 * 14 * 80 && ZSLACK + 48 <= LDS_BYTES && ZSLACK % 16 == 0, "zero spot of the dense stages with at most three k-steps");
 static_assert(B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF && B_T15::OFF + 15 * B_T15::ROWB <= B_T8::OFF, "skewed buffers do not run into their neighbours");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
-static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROWB <= B_T2::OFF && B_T2::OFF + 28 * 28 * 16 <= B_HB::OFF + 14112, "plan");
+static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROWB <= B_HB::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T4::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T1::OFF, "plan: conv2d_3 reads T1 and writes T2; conv2d_5 -> conv2d_6 reads T2 and writes T4");
 
 // ---- weight ring.  A conv's A-operand rows come from LDS, not from global memory: stage k's first act is ONE LDS-DMA of stage
 // k+1's rows (global_load_lds_dwordx4: 64 x 16 bytes per wave-instruction, no registers), so that the next stage's waves read
@@ -85,28 +84,38 @@ static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROW
 // (a dense 1x1 block carries its fp32 biases behind its rows: 16 bytes per pass of four output channels; the 3x3 stages read theirs with scalar loads)
 constexpr int WBYTES[24] = {640, 640, 80, 400, 1600, 416, 720, 2880, 672, 400, 2016, 1920, 416, 800, 3200, 672, 800, 3200, 672, 480, 4000, 3200, 2688, 1360};
 constexpr int RING0 = LDS_BYTES, LDS_TOTAL = 81920, RING_BYTES = LDS_TOTAL - LDS_BYTES;
-// The ring serves the FRONT stages (convs 0..11); the tail's blocks are resident during the tail phase.
-constexpr int woff(int k) { return k % 2 == 0 ? RING0 : RING0 + RING_BYTES - WBYTES[k]; }
+constexpr int COUT_[24] = {8, 8, 4, 18, 18, 6, 36, 36, 6, 18, 24, 24, 8, 40, 40, 8, 40, 40, 8, 24, 40, 40, 32, 18};
+constexpr bool IS_3X3_[24] = {1, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0};
+// The ring serves the FRONT stages (convs 0..11; the tail's blocks are resident during the tail phase).  A UNIT is what one stage needs: one block, or
+// the two blocks of the fused 1x1 pair conv2d_5 -> conv2d_6 (adjacent in the blob: ONE DMA).  Units k and k+1 are the only ones alive together, so even units grow up from the
+// bottom of the region and odd units down from its top.
+constexpr int UNIT_OF[12] = {0, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+constexpr int NUNITS = 11;
+constexpr int unit_first(int u) { for (int k = 0; k < 12; ++k) if (UNIT_OF[k] == u) return k; return -1; }
+constexpr int unit_bytes(int u) { int b = 0; for (int k = 0; k < 12; ++k) if (UNIT_OF[k] == u) b += WBYTES[k] + (IS_3X3_[k] ? ((COUT_[k] + 3) / 4) * 16 : 0); return b; }
+constexpr int unit_base(int u) { return u % 2 == 0 ? RING0 : RING0 + RING_BYTES - unit_bytes(u); }
+constexpr int woff(int k) { int o = unit_base(UNIT_OF[k]); for (int i = unit_first(UNIT_OF[k]); i < k; ++i) o += WBYTES[i] + (IS_3X3_[i] ? ((COUT_[i] + 3) / 4) * 16 : 0); return o; }
 constexpr bool ring_ok() {
-  for (int k = 0; k < 12; ++k) {
-    if (WBYTES[k] % 16 != 0) return false;
-    if (k + 1 < 12 && WBYTES[k] + WBYTES[k + 1] > RING_BYTES) return false;
+  for (int u = 0; u < NUNITS; ++u) {
+    if (unit_bytes(u) % 16 != 0) return false;
+    if (u + 1 < NUNITS && unit_bytes(u) + unit_bytes(u + 1) > RING_BYTES) return false;
   }
   return RING0 % 16 == 0 && RING_BYTES % 16 == 0;
 }
-static_assert(ring_ok(), "adjacent weight blocks fit the ring side by side");
-// LDS-DMA of conv K's rows into its place in the ring: wave w moves bytes [1024 w, 1024 w + 1024).  The compiler does not see
-// the transfer (inline assembly): the barrier behind every stage is preceded by an explicit s_waitcnt vmcnt(0) (SYNC in the kernel).
-// The LAST waves of the workgroup issue it: the job split gives a stage's surplus jobs to the first ones.
-template <int K, int NW>
-__device__ __forceinline__ void fetch_w(const uint8_t* __restrict__ tab, uint32_t w_off, int wave, int lane) {
-  constexpr int BYTES = WBYTES[K], NCHUNK = (BYTES + 1023) / 1024;
+static_assert(ring_ok(), "adjacent units fit the ring side by side");
+// LDS-DMA of ring unit U (rows and biases of its convs, contiguous in the blob at byte w_off) into its place in the ring: a wave moves 1 KB per
+// instruction (64 x 16 bytes, no registers).  The compiler does not see the transfer (inline assembly): the barrier behind every stage is preceded by
+// an explicit s_waitcnt vmcnt(0) (SYNC in the kernel).  The LAST waves of the workgroup issue it: the job split gives a stage's surplus jobs to the first ones.
+template <int U, int NW>
+__device__ __forceinline__ void fetch_unit(const uint8_t* __restrict__ tab, uint32_t w_off, int wave, int lane) {
+  constexpr int BYTES = unit_bytes(U), NCHUNK = (BYTES + 1023) / 1024;
+  static_assert(NCHUNK <= NW, "one DMA instruction per wave");
   const int ch = NW - 1 - wave;
   if (ch < NCHUNK) {
     const int off = ch * 1024 + lane * 16;
     if (off < BYTES) {
       const uint8_t* src = tab + w_off + off;
-      const uint32_t dst = (uint32_t)(woff(K) + ch * 1024);
+      const uint32_t dst = (uint32_t)(unit_base(U) + ch * 1024);
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -126,8 +135,8 @@ struct Tables { ConvT conv[24]; };
 // The blob's layout is fixed by the graph, so the kernel compiles it in (no descriptor load in front of a stage's weight DMA or bias loads):
 // [Tables][conv 0 rows | biases][conv 1 rows | biases] ...; every piece is a multiple of 16 bytes.  yf_fp16_create builds the blob and checks
 // that it arrives at the same offsets.
-constexpr int COUT[24] = {8, 8, 4, 18, 18, 6, 36, 36, 6, 18, 24, 24, 8, 40, 40, 8, 40, 40, 8, 24, 40, 40, 32, 18};
-constexpr bool IS_3X3[24] = {1, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0};
+#define COUT COUT_
+#define IS_3X3 IS_3X3_
 constexpr int bias_bytes(int k) { return ((COUT[k] + 3) / 4) * 16; }
 constexpr int rows_bytes(int k) { return IS_3X3[k] ? WBYTES[k] : WBYTES[k] - bias_bytes(k); }
 constexpr ConvT conv_at(int k) {
@@ -315,6 +324,94 @@ __device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0,
             else { v.x = pack2(acc[0], acc[1]); v.y = pack2(acc[2], acc[3]); }
             st64(dst + 8 * tt, v);
           }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ two 1x1 layers in one stage
+// Layer A's four (or eight) output channels of a lane's pixel land in the lane's own accumulators: packed to fp16 they ARE layer B's B operand (KS = 1:
+// at most 8 input channels).  conv2d_5 -> conv2d_6 run as ONE stage that way: conv2d_5's output makes no LDS round trip and one barrier-separated
+// latency chain of ~1.3 k cycles per frame is gone (the two other candidates, conv2d_12 -> 13 and conv2d_17 -> 19, have two chunks of layer B's passes per
+// tile -- layer A would run twice -- and measured slower).  A job = (chunk of layer B's passes, tile); STA optionally stores A's output from the jobs of
+// chunk 0.  Arithmetic and its order are those of the separate stages.
+struct NoBuf { static constexpr int OFF = 0, S = 0, W = 0, RS = 0, PT = 0, PL = 0, SK = 0, FS = 0; };
+template <int KA, int KSA, int COUTA, int EPIA, class ADDA, class STA, int ZBA, int KB, int NW, int TPJ, int COUTB, class IN, class OUT, int OUT_CH0, int ZBB>
+__device__ __forceinline__ void dense_pair_stage(int wave, int lane) {
+  constexpr int NPA = (COUTA + 3) / 4, KROWA = 8 * KSA, ROWSA = NPA * 4 * KROWA * 2;
+  constexpr int NPB = (COUTB + 3) / 4, NCH = (NPB + TPJ - 1) / TPJ, ROWSB = NPB * 4 * 8 * 2;
+  constexpr int W = IN::W, P = W * W, NT = (P + 63) / 64, JOBS = NCH * NT;
+  constexpr bool OUT_LINEAR = (OUT::RS == W && OUT::PT == 0 && OUT::PL == 0 && OUT::SK == 0), STORE_A = STA::S != 0;
+  static_assert(NPA <= 2 && COUTA <= 8 && (EPIA == EPI_LINEAR || EPIA == EPI_ADD), "layer A: at most eight linear output channels");
+  static_assert(WBYTES[KA] == ROWSA + NPA * 16 && WBYTES[KB] == ROWSB + NPB * 16 && UNIT_OF[KA] == UNIT_OF[KB] && KB == KA + 1, "the two blocks of one ring unit");
+  static_assert(IN::S >= 16 * KSA && IN::OFF % 16 == 0 && IN::S % 16 == 0 && IN::RS == W && IN::PT == 0 && IN::PL == 0 && IN::SK == 0, "halo-free input, aligned B fragments");
+  static_assert((W == 28 || W == 14) && IN::H == W && OUT::W == W && ZBA % 16 == 0 && ZBB % 16 == 0, "tile geometries");
+  const int g = lane >> 4, c = lane & 15;
+  const int ly = (W == 14) ? (lane * 74) >> 10 : (lane * 37) >> 10, lx = lane - W * ly;         // the lane's pixel inside the first tile
+  const int in_lane = IN::OFF + lane * IN::S, out_lane = OUT::at(ly, lx) + 2 * OUT_CH0;
+  const bool a_on = (c >> 2) == g;
+  const int fa_base = a_on ? woff(KA) + (c & 3) * (KROWA * 2) : ZBA, fb_base = a_on ? woff(KB) + (c & 3) * 16 : ZBB;
+  int fr_scale = a_on ? 1 : 0;
+  asm("" : "+v"(fr_scale));
+  int j, j1;
+  job_range<JOBS, NW>(wave, j, j1);
+  while (j < j1) {
+    const int chunk = j / NT;
+    const int jend = min(j1, (chunk + 1) * NT);
+    v4i aA[NPA][KSA], aB[TPJ];
+    v4f bA[NPA], bB[TPJ];
+#pragma unroll
+    for (int pa = 0; pa < NPA; ++pa) {
+      const int fa = fa_base + __mul24(fr_scale, pa * (4 * KROWA * 2));
+#pragma unroll
+      for (int ks = 0; ks < KSA; ++ks) aA[pa][ks] = ld128(fa + 16 * ks);
+      bA[pa] = __builtin_bit_cast(v4f, ld128(woff(KA) + ROWSA + 16 * pa));
+    }
+#pragma unroll
+    for (int tt = 0; tt < TPJ; ++tt) {
+      const int ps = min(chunk * TPJ + tt, NPB - 1);
+      aB[tt] = ld128(fb_base + __mul24(fr_scale, ps * 64));
+      bB[tt] = __builtin_bit_cast(v4f, ld128(woff(KB) + ROWSB + 16 * ps));
+    }
+    for (; j < jend; ++j) {
+      const int p0 = min(64 * (j - chunk * NT), P - 64);
+      const int src = in_lane + p0 * IN::S;
+      v4i b[KSA];
+#pragma unroll
+      for (int ks = 0; ks < KSA; ++ks) b[ks] = ld128(src + 16 * ks);
+      v4i mid = {0, 0, 0, 0};                                   // layer A's packed outputs = layer B's k-slots (channels past COUTA: zero, as the arena's padding was)
+#pragma unroll
+      for (int pa = 0; pa < NPA; ++pa) {
+        v4f acc = bA[pa];
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, aA[pa][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
+        if constexpr (EPIA == EPI_ADD) {
+          const uint2 r = ld64(ADDA::OFF + (p0 + lane) * ADDA::S + 8 * pa);
+          v2h r0, r1; __builtin_memcpy(&r0, &r.x, 4); __builtin_memcpy(&r1, &r.y, 4);
+          acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
+        }
+        mid[2 * pa] = (int)pack2(acc[0], acc[1]); mid[2 * pa + 1] = (int)pack2(acc[2], acc[3]);
+      }
+      if constexpr (STORE_A) {
+        if (chunk == 0) {
+#pragma unroll
+          for (int pa = 0; pa < NPA; ++pa) st64(STA::OFF + (p0 + lane) * STA::S + 8 * pa, uint2{(uint32_t)mid[2 * pa], (uint32_t)mid[2 * pa + 1]});
+        }
+      }
+      int dst;
+      if constexpr (OUT_LINEAR) dst = out_lane + (p0 * OUT::S + 8 * TPJ * chunk);
+      else {
+        const int Y = (W == 14) ? (p0 * 4682) >> 16 : (p0 * 2341) >> 16;          // p0 / W (scalar)
+        const int X = p0 - W * Y;
+        dst = out_lane + (Y * OUT::ROWB + X * OUT::S + 8 * TPJ * chunk) + (lx >= W - X ? OUT::ROWB - W * OUT::S : 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TPJ; ++tt) {
+        if (chunk * TPJ + tt < NPB) {
+          v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, aB[tt]), __builtin_bit_cast(v8h, mid), bB[tt], 0, 0, 0);
+          uint2 v; v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]);
+          st64(dst + 8 * tt, v);
         }
       }
     }
@@ -766,7 +863,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #ifndef YF16_STAGEPMC
 #define SYNC_BATCH() SYNC()
 #endif
-#define FETCH(K) fetch_w<K, NW>(tab, conv_at(K).w_off, wave, lane)
+#define FETCH(U) fetch_unit<U, NW>(tab, conv_at(unit_first(U)).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
   // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
 #if defined(YF16_BARPROF) || defined(YF16_STAGEPMC)
@@ -842,35 +939,32 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     conv3x3_stage<1, NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv_at(1), wave, lane);                     // conv2d_3 (dw)
     SYNC();
     FETCH(3);
-    dense_tile_stage<2, NW, 1, 1, B_T2, B_T3, 0, 4, EPI_LINEAR, B_T3, ZSLACK>(nullptr, wave, lane);   // conv2d_5 (4 ch)
-    SYNC();
-    FETCH(4);
     fill_halo<B_T4, false, NT>(lds, tid);
-    dense_tile_stage<3, NW, (NW > 8 ? 3 : 5), 1, B_T3, B_T4, 0, 18, EPI_ACT, B_T4, ZSLACK>(nullptr, wave, lane);     // conv2d_6
+    dense_pair_stage<2, 1, 4, EPI_LINEAR, NoBuf, NoBuf, ZSLACK, 3, NW, 5, 18, B_T2, B_T4, 0, ZSLACK>(wave, lane);            // conv2d_5 -> conv2d_6
     SYNC();
     pool8_h(wave, lane);
     SYNC();
-    FETCH(5);
+    FETCH(4);
     if (wave < POOL8V_WAVES) pool8_v(wave * 64 + lane);                                               // pool_8 -> concat_22[0,18) ...
     else conv3x3_stage<4, NW - POOL8V_WAVES, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave - POOL8V_WAVES, lane);   // ... beside conv2d_10 (dw, stride 2)
     SYNC();
-    FETCH(6);
+    FETCH(5);
     dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(nullptr, wave, lane);   // conv2d_12
     SYNC();
-    FETCH(7);
+    FETCH(6);
     fill_halo<B_T8, true, NT>(lds, tid);
     dense_tile_stage<6, NW, (NW > 8 ? 3 : 5), 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8, ZSLACK>(nullptr, wave, lane);     // conv2d_13
     SYNC();
-    FETCH(8);
+    FETCH(7);
     conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv_at(7), wave, lane);                     // conv2d_15 (dw)
     SYNC();
-    FETCH(9);
+    FETCH(8);
     dense_tile_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7, B_T8::OFF>(nullptr, wave, lane);     // conv2d_17 + eltwise_18
     SYNC();
-    FETCH(10);
+    FETCH(9);
     dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(nullptr, wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
-    FETCH(11);
+    FETCH(10);
     const bool more = k + 1 < nb;
     if (more) prefetch_in(fr + G);                                                                    // the next frame's input, behind this stage's weight DMA
     fill_halo<B_T15, false, NT>(lds, tid);
