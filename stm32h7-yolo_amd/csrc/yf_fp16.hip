@@ -176,19 +176,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {          // v_cvt_
   const v2h h = __builtin_convertvector(v2f{a, b}, v2h);               // plain cast; the round-toward-zero form (v_cvt_pkrtz) biases
   uint32_t u; __builtin_memcpy(&u, &h, 4); return u;                   // every layer the same way and misses the tolerance
 }
-__device__ __forceinline__ float leaky(float v) {                       // max(v, 0.1 v) as ONE v_mul and ONE v_max: fmaxf() first
-  float r;                                                              // canonicalises both operands (a v_max v, v each) under IEEE mode
-  const float t = 0.1f * v;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
-  return r;
-}
-
 // LeakyReLU of two channels, then one v_cvt_pk_f16_f32.  (On the packed halfs AFTER the conversion -- v_pk_mul_f16 by 0.1, v_pk_max_f16:
 // three instructions per pair instead of five -- the extra fp16 rounding of 0.1 h misses the tolerance and the kernel is 0.5 % faster.)
-#ifndef YF16_PKMUL
-#define YF16_PKMUL 1
-#endif
-#if YF16_PKMUL
 // 0.1 x for both channels as ONE v_pk_mul_f32 (same rate as a single v_mul_f32), then the two v_max_f32 and the conversion: four VALU instructions
 // per channel pair instead of five, results bit for bit the same
 __device__ __forceinline__ uint32_t leaky_pack2(float a, float b) {
@@ -199,30 +188,6 @@ __device__ __forceinline__ uint32_t leaky_pack2(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x[1]), "v"(t[1]));
   return pack2(r0, r1);
 }
-#else
-__device__ __forceinline__ uint32_t leaky_pack2(float a, float b) { return pack2(leaky(a), leaky(b)); }
-#endif
-// four fp32 results of a pass (channels chq..chq+3 of pixel p) -> activation -> fp16 -> LDS (or fp32 logits -> HBM)
-template <int EPI, class OUT, int OUT_CH0, class ADDB, int COUT>
-__device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_frame, int p, int chq, v4f acc, bool live) {
-  if constexpr (EPI == EPI_HEAD) {
-    if (live && out_frame != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (chq + j < COUT) out_frame[p * COUT + chq + j] = acc[j];
-    }
-  } else {
-    if constexpr (EPI == EPI_ADD) {
-      const uint2 r = lds_u64(lds + ADDB::at_p(p) + 2 * chq);
-      v2h r0, r1; __builtin_memcpy(&r0, &r.x, 4); __builtin_memcpy(&r1, &r.y, 4);
-      acc[0] += (float)r0[0]; acc[1] += (float)r0[1]; acc[2] += (float)r1[0]; acc[3] += (float)r1[1];
-    }
-    uint2 v;
-    if constexpr (EPI == EPI_ACT) { v.x = leaky_pack2(acc[0], acc[1]); v.y = leaky_pack2(acc[2], acc[3]); }
-    else { v.x = pack2(acc[0], acc[1]); v.y = pack2(acc[2], acc[3]); }
-    *reinterpret_cast<uint2*>(lds + OUT::at_p(p) + 2 * (OUT_CH0 + chq)) = v;        // surplus lanes redo the last pixel (same value)
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ dense 1x1, lane-private
 // KS k-steps of 8 input channels (16 bytes of the pixel's fp16 vector each); TPJ passes of 4 output channels share a job's B fragments; the bias is
 // the accumulator's initial value.  A job's 64 lanes are a TILE:
@@ -232,28 +197,26 @@ __device__ __forceinline__ void epilogue(char* lds, float* __restrict__ out_fram
 //     so is its output offset when the output has no halo, and with a halo it is one compare-and-select more (the lane's row / column inside the first
 //     tile are per-stage constants, a tile adds a scalar row / column and at most one carry into the next row): one to three VALU instructions per job
 //     (round 3: ~14 of pixel arithmetic -- a min, two divisions by multiplication, two multiply-adds)
-//   7x7 (two frames, tail batching): one frame per tile, 49 lanes (the others redo pixel 48)
 // A fragments: the lanes whose fragment is all zero (48 of 64) read it too -- from ZB, a spot of the arena that holds zeros while the stage runs (the
 // kernel names one per stage) -- so a chunk set-up is ONE address instruction and KS unmasked ds_read_b128 per pass instead of four zero moves, an exec
 // mask and a masked read per fragment.  The biases come with the block (LDS-DMA), are read into VGPRs once per chunk with one broadcast ds_read_b128 per
 // pass and enter the MFMA as its C operand: no scalar load, no move per pass and job.
 constexpr int dense_rows_bytes(int cout, int ks) { return ((cout + 3) / 4) * 4 * 8 * ks * 2; }
-template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int ZB, int F = 1>
-__device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0, int wave, int lane, float* __restrict__ out_frame1 = nullptr) {
+template <int K, int NW, int TPJ, int KS, class IN, class OUT, int OUT_CH0, int COUT, int EPI, class ADDB, int ZB>
+__device__ __forceinline__ void dense_tile_stage(int wave, int lane) {
   constexpr int NP = (COUT + 3) / 4, NCH = (NP + TPJ - 1) / TPJ, KROW = 8 * KS;
-  constexpr int W = IN::W, P = W * W, NT = (W == 7) ? F : (P + 63) / 64, JOBS = NCH * NT;
+  constexpr int W = IN::W, P = W * W, NT = (P + 63) / 64, JOBS = NCH * NT;
   constexpr bool OUT_LINEAR = (OUT::RS == W && OUT::PT == 0 && OUT::PL == 0 && OUT::SK == 0);
   constexpr int ROWS = NP * 4 * KROW * 2;                     // the block: A-operand rows, then the fp32 biases (16 bytes per pass)
   static_assert(WBYTES[K] == ROWS + NP * 16, "stage and weight block agree");
   static_assert(IN::S >= 16 * KS, "the pixel vector must cover every k-step");
   static_assert(IN::OFF % 16 == 0 && IN::S % 16 == 0 && IN::FS % 16 == 0, "B fragments are aligned ds_read_b128 (a misaligned one is several times slower)");
   static_assert(IN::RS == W && IN::PT == 0 && IN::PL == 0 && IN::SK == 0 && (EPI != EPI_ADD || (ADDB::RS == W && ADDB::PT == 0 && ADDB::PL == 0 && ADDB::SK == 0)), "inputs are halo-free");
-  static_assert((W == 28 || W == 14 || W == 7) && IN::H == W && OUT::W == W && (EPI != EPI_ADD || ADDB::W == W), "tile geometries");
-  static_assert((W == 7) == (F == 2) && (F == 1 || (IN::FS == OUT::FS && IN::FS == ADDB::FS && IN::FS > 0)), "the 7x7 stages run on two frames with one stride");
+  static_assert((W == 28 || W == 14) && IN::H == W && OUT::W == W && (EPI != EPI_ADD || ADDB::W == W) && EPI != EPI_HEAD, "the front stages' grids (the 7x7 layers and the head run in tail_chain)");
   static_assert(ZB % 16 == 0 && ZB >= 0, "zero fragments are aligned reads too");
   const int g = lane >> 4, c = lane & 15;
-  const int pl = (W == 7) ? min(lane, 48) : lane;            // the lane's pixel inside the first tile
-  const int ly = (W == 7) ? (pl * 37) >> 8 : (W == 14) ? (pl * 74) >> 10 : (pl * 37) >> 10;     // pl / W for pl < 64 (7: 37/256, 14: 74/1024, 28: 37/1024; checked exhaustively)
+  const int pl = lane;                                       // the lane's pixel inside the first tile
+  const int ly = (W == 14) ? (pl * 74) >> 10 : (pl * 37) >> 10;     // pl / W for pl < 64 (14: 74/1024, 28: 37/1024; checked exhaustively)
   const int lx = pl - W * ly;
   const int in_lane = IN::OFF + pl * IN::S, add_lane = ADDB::OFF + pl * ADDB::S;
   const int out_lane = OUT::at(ly, lx) + 2 * OUT_CH0;
@@ -281,9 +244,7 @@ __device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0,
     for (; j < jend; ++j) {
       const int tile = j - chunk * NT;
       int src, dst, addp;
-      if constexpr (W == 7) {
-        src = in_lane + tile * IN::FS; dst = out_lane + tile * OUT::FS + 8 * TPJ * chunk; addp = add_lane + tile * ADDB::FS + 8 * TPJ * chunk;
-      } else {
+      {
         const int p0 = tile_p0(tile);
         src = in_lane + p0 * IN::S;
         addp = add_lane + (p0 * ADDB::S + 8 * TPJ * chunk);
@@ -297,17 +258,7 @@ __device__ __forceinline__ void dense_tile_stage(float* __restrict__ out_frame0,
       v4i b[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) b[ks] = ld128(src + 16 * ks);
-      if constexpr (EPI == EPI_HEAD) {
-        static_assert(TPJ == 1, "the head stores one pass per job");
-        float* of = (F == 2 && tile) ? out_frame1 : out_frame0;
-        if (of == nullptr) continue;
-        v4f acc = bias[0];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[0][ks]), __builtin_bit_cast(v8h, b[ks]), acc, 0, 0, 0);
-        float* o = of + (ly * 7 + lx) * COUT + 4 * chunk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (4 * chunk + q < COUT) o[q] = acc[q];
-      } else {
+      {
 #pragma unroll
         for (int tt = 0; tt < TPJ; ++tt) {
           if (chunk * TPJ + tt < NP) {
@@ -425,25 +376,22 @@ __device__ __forceinline__ void dense_pair_stage(int wave, int lane) {
 // GOUT: the results go to global memory (gout + OUT's offsets + OUT_B0) instead of LDS -- conv2d_27 writes the frame's park slot.
 typedef __attribute__((address_space(1))) v2u_t* glb_v2u_p;
 typedef __attribute__((address_space(1))) uint32_t* glb_u32_p;
-template <int K, int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, int F = 1, bool GOUT = false, int OUT_B0 = 0>
+template <int K, int NW, int STRIDE, class IN, class OUT, int C, bool DEPTHWISE, bool GOUT = false, int OUT_B0 = 0>
 __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restrict__ tab, ConvT t, int wave, int lane, char* gout = nullptr) {
   constexpr int W = OUT::W, H = OUT::H;
   static_assert(WBYTES[K] == ((C + 3) / 4) * 320, "stage and weight block agree");
-  constexpr int FL = (F == 2) ? 2 : 1;                             // two 7-wide frames side by side in the 16 lanes of a row tile
-  static_assert(F == 1 || (W <= 8 && IN::FS == OUT::FS && IN::FS > 0), "frame pairs need grids of at most 8 columns");
   constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4;
   constexpr int NG = (C + 3) / 4;                                  // output-channel groups of 4
   constexpr int JPG = NRB * NSEG, JOBS = NG * JPG;
   constexpr int DROW = STRIDE * IN::ROWB, TS = IN::S, TR = IN::ROWB;
   const int g = lane >> 4, c = lane & 15;
-  const int fl = (FL == 2) ? (c >> 3) : 0;
-  const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);
-  const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;
+  const int xl = min(c, W - 1);                                    // surplus lanes redo the last column (same value, same address)
+  const int lane_in = g * DROW + xl * STRIDE * IN::S;
   const bool a_on = (c >> 2) == g;
   if constexpr (!DEPTHWISE) {
     // a dense 3x3 (conv2d_1): every output-channel group reads the SAME taps, so a job is a tile with ALL its groups -- the nine tap reads and
     // the pixel arithmetic once instead of once per group, NG independent MFMA chains in flight
-    static_assert(F == 1 && NG == 2, "conv2d_1: eight output channels");
+    static_assert(NG == 2, "conv2d_1: eight output channels");
     v4i a[NG][5];
     v4f bias[NG];
     {
@@ -516,7 +464,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
 #pragma unroll
       for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
-      dst = (GOUT ? gout : lds) + fl * OUT::FS + OUT::at(oy0 + g, x0 + xl) + 8 * cg + OUT_B0;
+      dst = (GOUT ? gout : lds) + OUT::at(oy0 + g, x0 + xl) + 8 * cg + OUT_B0;
     };
     auto kstep = [&](const uint2 (&tp)[9], int ks, v4f acc) {
       const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
@@ -561,20 +509,19 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
 // pixel of row HR-2 and the bottom row are one run.  Otherwise (top row + left column): the top row is one run, then one pixel per
 // row.  An item is one granule: a compare or two and a multiply-shift instead of the five divisions of a per-dword formulation
 // (the halo fills were 25 % of the kernel's VALU instructions).
-template <class B, bool RING, int NT, int F = 1>
+template <class B, bool RING, int NT>
 __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
   constexpr int S = B::S, WR = B::RS, HR = B::H + B::PT + (RING ? 1 : 0), SK = B::SK, ROWB = B::ROWB;
   constexpr int G = (S % 16 == 0 && B::OFF % 16 == 0 && SK % 16 == 0) ? 16 : 8, PG = S / G, SG = SK / G;       // granule bytes, granules per pixel / per row skew
-  static_assert(S % G == 0 && B::OFF % G == 0 && SK % G == 0 && (F == 1 || B::FS % G == 0), "granules");
+  static_assert(S % G == 0 && B::OFF % G == 0 && SK % G == 0, "granules");
   // the skew bytes between a row's last pixel and the next row's first one are unused: a run that crosses a row boundary clears them too
   constexpr int NA = RING ? (WR + 1) * PG + SG : WR * PG;             // first run
   constexpr int RUN = RING ? 2 * PG + SG : PG;                        // middle runs (two pixels / one pixel each)
   constexpr int NB = RING ? (HR - 3) * RUN : (HR - 1) * RUN;
   constexpr int NC = RING ? (WR + 1) * PG + SG : 0;                   // last run
   constexpr int N1 = NA + NB + NC;
-  for (int i = NT - 1 - tid; i < F * N1; i += NT) {          // the last waves first (see fetch_w)
-    const int f = (F == 1) ? 0 : (i >= N1 ? 1 : 0);
-    const int k = i - f * N1;
+  for (int i = NT - 1 - tid; i < N1; i += NT) {              // the last waves first (see fetch_unit)
+    const int k = i;
     int off;
     if (k < NA) off = k * G;
     else if (k < NA + NB) {
@@ -582,7 +529,7 @@ __device__ __forceinline__ void fill_halo(char* lds0, int tid) {
       const int r = j / RUN, g = j - r * RUN;                         // compile-time divisor
       off = RING ? (r + 1) * ROWB + (WR - 1) * S + g * G : (r + 1) * ROWB + g * G;
     } else off = (HR - 2) * ROWB + (WR - 1) * S + (k - NA - NB) * G;
-    char* dst = lds0 + f * B::FS + B::OFF + off;
+    char* dst = lds0 + B::OFF + off;
     if constexpr (G == 16) *reinterpret_cast<uint4*>(dst) = uint4{0u, 0u, 0u, 0u};
     else *reinterpret_cast<uint2*>(dst) = uint2{0u, 0u};
   }
@@ -646,18 +593,16 @@ __device__ __forceinline__ void pool8_v(int item) {
   pool8_sweep<0, 14, 27, uint32_t>([](uint32_t a, uint32_t b) { return pkmaxh(a, b); }, [&](int r) { return ld32(col + r * (14 * B_HB::S)); },
                                    [&](int oy, uint32_t v) { st32(dst + oy * (14 * B_T14::S), v); });
 }
-// pool_25 by COLUMNS (as in the int8 kernel): one item = (frame, output column, channel dword) walks the 14 rows of T15 once -- per row
+// pool_25 by COLUMNS (as in the int8 kernel): one item = (output column, channel dword) walks the 14 rows of T15 once -- per row
 // the horizontal 4-tap maximum (clamped columns), pairs of rows R[j] = max(h[2j-1], h[2j]), out[oy] = max(R[oy], R[oy+1]) -- and writes
-// its 7 outputs: 56 loads per item instead of 7 x 16, no per-tap clamping.  F x 84 items: the first waves of the stage take them, the
+// its 7 outputs: 56 loads per item instead of 7 x 16, no per-tap clamping.  84 items: the first two waves of the stage take them, the
 // others run conv2d_27, which reads the same T15.
-template <int F> constexpr int pool25_waves() { return (F * 84 + 63) / 64; }
-template <int F, class T15, class T30, bool GOUT = false>
-__device__ __forceinline__ void pool25_cols(char* lds0, int item, char* gout = nullptr) {
-  static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7 && T15::FS == T30::FS, "pool_25 geometry");
-  if (item >= F * 84) return;
-  const int t = item / 12, d = item - 12 * t;
-  const int f = t / 7, ox = t - 7 * f;
-  char* lds = lds0 + f * T15::FS;
+constexpr int POOL25_WAVES = (84 + 63) / 64;
+template <class T15, class T30>
+__device__ __forceinline__ void pool25_cols(char* lds, int item, char* gout) {
+  static_assert(T15::W == 14 && T15::H == 14 && T30::W == 7, "pool_25 geometry");
+  if (item >= 84) return;
+  const int ox = item / 12, d = item - 12 * ox;
   const char* base = lds + T15::at(0, 0) + 4 * d;
   constexpr int S = T15::S, ROW = T15::ROWB;
   const int c0 = max(2 * ox - 1, 0) * S, c1 = 2 * ox * S, c2 = c1 + S, c3 = min(2 * ox + 2, 13) * S;
@@ -665,14 +610,13 @@ __device__ __forceinline__ void pool25_cols(char* lds0, int item, char* gout = n
     const char* p = base + r * ROW;
     return pkmaxh(pkmaxh(lds_u32(p + c0), lds_u32(p + c1)), pkmaxh(lds_u32(p + c2), lds_u32(p + c3)));
   };
-  char* dst = (GOUT ? gout : lds) + T30::OFF + ox * T30::S + 4 * d;
+  char* dst = gout + T30::OFF + ox * T30::S + 4 * d;          // the pooled half goes straight to the frame's park slot (global memory)
   uint32_t prev = hrow(0);                                     // R[0] = max(h[-1 -> 0], h[0])
 #pragma unroll
   for (int oy = 0; oy < 7; ++oy) {
     uint32_t next = hrow(2 * oy + 1);                          // R[oy+1] = max(h[2oy+1], h[2oy+2 -> 13])
     if (2 * oy + 2 <= 13) next = pkmaxh(next, hrow(2 * oy + 2));
-    if constexpr (GOUT) *(glb_u32_p)(uintptr_t)(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
-    else *reinterpret_cast<uint32_t*>(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
+    *(glb_u32_p)(uintptr_t)(dst + oy * (7 * T30::S)) = pkmaxh(prev, next);
     prev = next;
   }
 }
@@ -949,34 +893,34 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     else conv3x3_stage<4, NW - POOL8V_WAVES, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave - POOL8V_WAVES, lane);   // ... beside conv2d_10 (dw, stride 2)
     SYNC();
     FETCH(5);
-    dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(nullptr, wave, lane);   // conv2d_12
+    dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(wave, lane);   // conv2d_12
     SYNC();
     FETCH(6);
     fill_halo<B_T8, true, NT>(lds, tid);
-    dense_tile_stage<6, NW, (NW > 8 ? 3 : 5), 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8, ZSLACK>(nullptr, wave, lane);     // conv2d_13
+    dense_tile_stage<6, NW, (NW > 8 ? 3 : 5), 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8, ZSLACK>(wave, lane);     // conv2d_13
     SYNC();
     FETCH(7);
     conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv_at(7), wave, lane);                     // conv2d_15 (dw)
     SYNC();
     FETCH(8);
-    dense_tile_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7, B_T8::OFF>(nullptr, wave, lane);     // conv2d_17 + eltwise_18
+    dense_tile_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7, B_T8::OFF>(wave, lane);     // conv2d_17 + eltwise_18
     SYNC();
     FETCH(9);
-    dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(nullptr, wave, lane); // conv2d_19 -> concat_22 conv half
+    dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(wave, lane); // conv2d_19 -> concat_22 conv half
     SYNC();
     FETCH(10);
     const bool more = k + 1 < nb;
     if (more) prefetch_in(fr + G);                                                                    // the next frame's input, behind this stage's weight DMA
     fill_halo<B_T15, false, NT>(lds, tid);
-    dense_tile_stage<10, NW, (NW > 8 ? 1 : 2), 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15, B_T8::OFF>(nullptr, wave, lane);  // conv2d_23
+    dense_tile_stage<10, NW, (NW > 8 ? 1 : 2), 5, B_T14, B_T15, 0, 24, EPI_ACT, B_T15, B_T8::OFF>(wave, lane);  // conv2d_23
     if (more) { SYNC_KEEP_PREFETCH(); } else { SYNC(); }
     {   // pool_25 (by columns, on the first waves) and conv2d_27 (dw, stride 2, on the others) both only read T15; their outputs -- the two
         // inputs of the tail -- go straight to the frame's park slot in HBM (49 pixels x {24 | 24} channels)
-      constexpr int PW = pool25_waves<1>();
+      constexpr int PW = POOL25_WAVES;
       static_assert(PW < NW, "waves left for conv2d_27");
       char* slot = prm.scratch + ((long)blockIdx.x * NW + k) * PARK_BYTES;
-      if (wave < PW) pool25_cols<1, B_T15, PARK, true>(lds, wave * 64 + lane, slot);
-      else conv3x3_stage<11, NW - PW, 2, B_T15, PARK, 24, true, 1, true, 48>(lds, tab, conv_at(11), wave - PW, lane, slot);
+      if (wave < PW) pool25_cols<B_T15, PARK>(lds, wave * 64 + lane, slot);
+      else conv3x3_stage<11, NW - PW, 2, B_T15, PARK, 24, true, true, 48>(lds, tab, conv_at(11), wave - PW, lane, slot);
     }
     SYNC();                                                       // this frame's buffers are dead, its park slot is written
     }
