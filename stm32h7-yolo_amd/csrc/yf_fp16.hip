@@ -633,7 +633,12 @@ __device__ __forceinline__ void pool25_cols(char* lds, int item, char* gout) {
 // runs the tail of the batch's frame w.  Arithmetic and its order are those of the staged form: results bit for bit equal.
 constexpr int PARK_PX = 96, PARK_BYTES = 49 * PARK_PX;        // a frame's park slot: 49 pixels x (24 pool_25 + 24 conv2d_27) fp16 channels
 typedef Buf<0, 7, 7, PARK_PX, 7, 0, 0> PARK;
-typedef Buf<0, 7, 7, 80, 9, 1, 1, 0, YF16_ROW_SKEW> XT;       // exchange buffer: T19's layout (40 channels, halo ring, skewed rows)
+// Exchange buffer: T19's geometry (40 channels, halo ring) with a row pitch of 198 dwords.  A tap is a ds_read_b64 (two banks per lane, 32 lanes per
+// group): pixel x of a row starts at bank 20 x mod 64 -- slots 5 x mod 16 of the sixteen 4-bank slots of one parity class -- and with 198 dwords per row
+// rows y and y + 2 are three slots apart and rows y, y + 1 in different classes, so the lane -> pixel map of tail_chain (lanes 0-31: rows 0-3 and the first
+// two pixels of rows 4 and 5) puts the 32 lanes of each group on 64 different banks for every tap: 2.2 cycles per read instead of ~5.5 with the 182-dword
+// pitch of the staged T19 (the chain is bound by the LDS pipe: 33.9 k -> 30.9 k cycles per tail phase).
+typedef Buf<0, 7, 7, 80, 9, 1, 1, 0, 72> XT;
 constexpr int XB = (9 * XT::ROWB + 15) & ~15;                  // bytes per wave
 constexpr int TAILW0 = (int)conv_at(12).w_off, TAILW_BYTES = (int)conv_at(23).b_off + bias_bytes(23) - TAILW0;
 template <int NW> constexpr int tw(int k) { return NW * XB + (int)conv_at(k).w_off - TAILW0; }     // LDS address of tail conv k's rows / biases
@@ -641,7 +646,7 @@ template <int NW> constexpr int tb(int k) { return NW * XB + (int)conv_at(k).b_o
 static_assert(XB % 16 == 0 && TAILW0 % 16 == 0 && TAILW_BYTES % 16 == 0 && 5 * 64 + 16 <= XT::ROWB && 16 * 6 <= XT::ROWB, "tail plan: aligned blocks, a zero halo row that covers every zero fragment");
 template <int NW>
 __device__ __forceinline__ void fetch_tailw(const uint8_t* __restrict__ tab, int wave, int lane) {
-  static_assert(NW * XB + TAILW_BYTES <= ZSLACK, "exchange buffers and resident tail weights fit the arena below its zero spot");
+  static_assert(NW * XB + TAILW_BYTES <= LDS_TOTAL, "exchange buffers and resident tail weights fit the workgroup's LDS (arena and ring are dead in the tail phase; the arena is cleared before the next batch)");
   constexpr int NCHUNK = (TAILW_BYTES + 1023) / 1024;
   for (int j = wave; j < NCHUNK; j += NW) {
     const int off = j * 1024 + lane * 16;
@@ -737,7 +742,10 @@ __device__ __forceinline__ void dw_reg(const TailLane& L, const uint32_t (&in)[2
 template <int NW>
 __device__ __forceinline__ void tail_chain(int xb, const char* __restrict__ park, float* __restrict__ head, int lane) {
   const int g = lane >> 4, c = lane & 15;
-  const int p = min(lane, 48), y = (p * 37) >> 8, x = p - 7 * y;                     // lanes 49..63 redo pixel 48
+  // lane -> pixel: rows 0-3 on lanes 0-27, then (4,0) (4,1) (5,0) (5,1) on lanes 28-31, the rest of rows 4 and 5 and row 6 on lanes 32-48 (see XT: every
+  // tap read is then free of bank conflicts); lanes 49..63 redo pixel 48
+  const int p = lane < 30 ? lane : lane < 32 ? lane + 5 : lane < 37 ? lane - 2 : min(lane, 48);
+  const int y = (p * 37) >> 8, x = p - 7 * y;
   TailLane L;
   L.a_on = (c >> 2) == g; L.c3 = c & 3; L.zb = xb; L.tapb = xb + y * XT::ROWB + x * XT::S;
   L.scale = L.a_on ? 1 : 0;
