@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
 #elif defined(YF16_STAGEPMC)
-  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop = 1 .. 14, every frame is abandoned behind its barrier number `stop`
+  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop = 1 .. 13, every frame is abandoned behind its barrier number `stop`
   // and the tail phase is skipped; stop = 0 runs everything.  The differences between consecutive launches are the stages' instruction counts.  Results
   // are wrong by construction.
   int stage_no = 0;
