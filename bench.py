@@ -136,10 +136,10 @@ def secondary_configs(net, dev, stream, settle_ms=60.0):
                            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
                            "kernel": "band_k1, band_k23, band_k4: three launches, each a group of fused stages over row bands staged through LDS (DESIGN.md, 160x160)",
                            "kernel_source_hash": kernel_source_hash()}
-    prof, why = stamped_profile("profiles/r03_160/summary.json", lambda d: d.get("total", {}).get("source_hash"))
+    prof, why = stamped_profile("profiles/r04_160/summary.json", lambda d: d.get("total", {}).get("source_hash"))
     out["int8_160x160"]["roofline"]["traffic"] = round(prof["total"]["hbm_bytes_per_batch"]) if prof else None
     out["int8_160x160"]["roofline"]["traffic_source" if prof else "traffic_missing"] = \
-        "profiles/r03_160/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 1024-frame batch)" if prof else why
+        "profiles/r04_160/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 1024-frame batch)" if prof else why
     del d_in, d_out
     # camera-format pipeline: 112x112 RGB565 frames -> heads + firmware-mode boxes, the frame preparation
     # fused into the kernel's input staging (ONE launch) against the two-launch form (separate preparation kernel)
@@ -176,10 +176,10 @@ def secondary_configs(net, dev, stream, settle_ms=60.0):
                          "ms_per_step": round(ms, 4), "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * FP16_BYTES_PER_FRAME,
                          "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
                          "dtype": "f16 (f32 accumulate)", "kernel": "yoloface56_f16_fused<8>", "kernel_source_hash": kernel_source_hash()}
-    prof, why = stamped_profile("profiles/r03_fp16/summary.json", lambda d: d.get("source_hash"))
+    prof, why = stamped_profile("profiles/r04_fp16/summary.json", lambda d: d.get("source_hash"))
     out["fp16_56x56"]["roofline"]["traffic"] = round(prof["hbm_bytes_per_launch"]) if prof else None
     out["fp16_56x56"]["roofline"]["traffic_source" if prof else "traffic_missing"] = \
-        "profiles/r03_fp16/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 4096-frame launch)" if prof else why
+        "profiles/r04_fp16/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 4096-frame launch)" if prof else why
     return out
 
 
