@@ -282,7 +282,9 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
     for (const Variant& v : k_variants) park = v.park > park ? v.park : park;
-    e->park_region = (size_t)e->cus * 4 * park;      // allocated per stream on its first launch (launch())
+    size_t slots = 4;
+    for (const Variant& v : k_variants) { const size_t need = (163840 / v.lds) * (size_t)v.f; slots = need > slots ? need : slots; }   // (a lab what-if with overlapping arenas holds three workgroups per CU)
+    e->park_region = (size_t)e->cus * slots * park;      // allocated per stream on its first launch (launch())
   }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
   if ((rc = hipEventCreate(&e->ev0)) != hipSuccess || (rc = hipEventCreate(&e->ev1)) != hipSuccess) return bail(rc, "hipEventCreate");

@@ -54,7 +54,14 @@ constexpr int LUT_BYTES = YF_N_LUT * 256 + YF_ADDLUT_BYTES;    // byte LUTs, the
 // PT/PL halo rows/cols in front of logical pixel (0,0); FS = bytes between the arenas of consecutive frames of a
 // workgroup (the 7x7 tail of the 56x56 kernel packs its frames at half the stride of the front stages).
 #if !defined(YF_H0) || YF_H0 == 56
-constexpr int BUF_FS = FRAME_BYTES;
+// Timing-only what-if (lab builds, WRONG results; profiles/r04_whatif.txt): the frames of a workgroup YF_WHATIF_FS bytes apart instead of FRAME_BYTES -- their
+// arenas overlap, every LDS access stays in range and a third workgroup fits the CU's LDS.
+#if defined(YF_LAB) && defined(YF_WHATIF_FS)
+constexpr int FRAME_STRIDE = YF_WHATIF_FS;
+#else
+constexpr int FRAME_STRIDE = FRAME_BYTES;
+#endif
+constexpr int BUF_FS = FRAME_STRIDE;
 #else
 constexpr int BUF_FS = 0;                      // one frame per workgroup
 #endif
@@ -120,7 +127,9 @@ struct TailBufs {
   typedef Buf<16160,  7,  7, 18,  7, 0, 0, FS_> HEAD;
   static constexpr int END = 16160 + 882, T15_BYTES = 5408;
   static_assert(T19::OFF + 9 * T19::ROWB <= T20::OFF && T20::OFF + 49 * 48 <= T22::OFF && T26::OFF + 49 * 8 <= HEAD::OFF, "tail buffers do not overlap");
+#if !(defined(YF_LAB) && defined(YF_WHATIF_FS))
   static_assert(END <= FS_, "a set fits its stride");
+#endif
 };
 #else
 // Any other size: the same buffers laid out one after another in a per-frame HBM arena (nothing aliases; 64 bytes
@@ -1150,7 +1159,7 @@ struct DwGeo {
 // job tables of the five depthwise geometries (8 bytes per job of one channel group), laid out one after another
 template <int F, bool BATCH>
 struct JobTabs {
-  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  typedef TailBufs<BATCH ? FRAME_STRIDE / 2 : FRAME_STRIDE> U;
   static constexpr int FT = BATCH ? 2 * F : F;
   static constexpr int JT_DW3 = 0;
   static constexpr int JT_DW10 = JT_DW3 + 8 * DwGeo<F, 1, B_T1, B_T2>::JPG;
@@ -1186,7 +1195,7 @@ struct HaloGeo {
 #if YF_H0 == 56
 template <int F, bool BATCH>
 struct HaloTabs {
-  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  typedef TailBufs<BATCH ? FRAME_STRIDE / 2 : FRAME_STRIDE> U;
   static constexpr int FT = BATCH ? 2 * F : F;
   typedef HaloGeo<B_T1, true, F> G1; typedef HaloGeo<B_T4, false, F> G4; typedef HaloGeo<B_T8, true, F> G8;
   typedef HaloGeo<B_T15, false, F> G15; typedef HaloGeo<typename U::T19, true, FT> G19;
@@ -1402,12 +1411,26 @@ template <bool DUMP> constexpr bool tail_batch() { return !DUMP; }
 // CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
 // preparation runs inside the input staging (stage_input_cam).
 template <int F, int NW, bool DUMP, bool CAM = false>
-__global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6 ? 3 : 2)) yoloface56_fused(const NetParams prm) {
+// passes per job of conv2d_13 / conv2d_23 (lab builds may override: the register-hungry settings that spill at the 128-VGPR cap)
+#if !defined(YF_LAB) || !defined(YF_TPJ13)
+#undef YF_TPJ13
+#define YF_TPJ13 3
+#endif
+#if !defined(YF_LAB) || !defined(YF_TPJ23)
+#undef YF_TPJ23
+#define YF_TPJ23 2
+#endif
+#if defined(YF_LAB) && defined(YF_WHATIF_WPE)      // what-if: another register budget (waves per SIMD the kernel must fit)
+#define YF_WPE(NW) YF_WHATIF_WPE
+#else
+#define YF_WPE(NW) ((NW) == 12 ? 6 : (NW) >= 8 ? 4 : ((NW) == 6 ? 3 : 2))
+#endif
+__global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const NetParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
   constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
-  typedef TailBufs<BATCH ? FRAME_BYTES / 2 : FRAME_BYTES> U;
+  typedef TailBufs<BATCH ? FRAME_STRIDE / 2 : FRAME_STRIDE> U;
   constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
   uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
   constexpr int PRE = v2::pre_bytes<F, tail_batch<DUMP>()>();   // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
@@ -1427,7 +1450,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
   for (int i = tid0; i < v2::LUT_B / 16; i += NT)
     reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
   for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
-  constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + F * FRAME_BYTES;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
+  constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + FRAME_BYTES + (F - 1) * FRAME_STRIDE;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
   if constexpr (DUMP) { if (tid0 < YF_DBG_LUT_BYTES / 16) reinterpret_cast<uint4*>(smem + DBG_LUT)[tid0] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off + YF_N_LUT * 256 + YF_ADDLUT_BYTES)[tid0]; }
   {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
     typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
@@ -1550,8 +1573,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     YF_PRIO(5);
+#if !(defined(YF_LAB) && defined(YF_WHATIF_NO_POOL8H))   // what-if (WRONG results): the horizontal pass and its barrier gone -- the bound for folding it into conv2d_6's epilogue
     pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
     YF_SYNC();
+#endif
     YF_STAGE_END()
     YF_PRIO(6);
     pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
@@ -1569,7 +1594,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     YF_PRIO(9);
     YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
     YF_FETCH(7, W_m, L_m);
-    YF_DENSE(F, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
+    YF_DENSE(F, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
     YF_SYNC(); YF_DUMP(B_T8, 36, T8)
     YF_STAGE_END()
     YF_PRIO(10);
@@ -1611,7 +1636,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
     }
     YF_HALO(B_T15, false, F, G15, H_T15, YF_W_DW27, tid_m);
     YF_FETCH(11, W_m, L_m);
-    YF_DENSE(F, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
+    YF_DENSE(F, YF_TPJ23, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
     if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
     YF_SYNC(); YF_DUMP(B_T15, 24, T15)
     YF_STAGE_END()
@@ -1627,7 +1652,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
       if (parked_first < 0 && grp + gridDim.x < n_groups) {
         for (int i = tid_t; i < F * V; i += NT) {
           const int f = i / V, k = i - f * V;
-          park[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_BYTES + 16 * k);
+          park[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_STRIDE + 16 * k);
         }
         parked_first = first;
         continue;
@@ -1788,7 +1813,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 6 : NW >= 8 ? 4 : (NW == 6
 }
 
 template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)v2::pre_bytes<F, tail_batch<DUMP>()>() + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)F * FRAME_BYTES + (DUMP ? YF_DBG_LUT_BYTES : 0); }
+constexpr size_t lds_bytes() { return (size_t)v2::pre_bytes<F, tail_batch<DUMP>()>() + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)FRAME_BYTES + (size_t)(F - 1) * FRAME_STRIDE + (DUMP ? YF_DBG_LUT_BYTES : 0); }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
 
