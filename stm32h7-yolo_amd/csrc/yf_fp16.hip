@@ -226,11 +226,15 @@ __device__ __forceinline__ void dense_tile_stage(int wave, int lane) {
   const int fr_base = a_on ? woff(K) + (c & 3) * (KROW * 2) : ZB;
   int fr_scale = a_on ? 1 : 0;
   asm("" : "+v"(fr_scale));                 // opaque: the fragment address stays ONE multiply-add (otherwise the compiler selects between two sums)
-  int j, j1;
-  job_range<JOBS, NW>(wave, j, j1);
-  while (j < j1) {
-    const int chunk = j / NT;
+  // The chunk loop is unrolled at compile time: a chunk's pass numbers, fragment and bias offsets and the `pass exists` tests are constants of its copy
+  // (as a run-time loop every chunk set-up spent ~35 scalar instructions on them, and every pass of a job a scalar branch)
+  int j0, j1;
+  job_range<JOBS, NW>(wave, j0, j1);
+#pragma unroll
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    int j = max(j0, chunk * NT);
     const int jend = min(j1, (chunk + 1) * NT);
+    if (j >= jend) continue;
     v4i a[TPJ][KS];
     v4f bias[TPJ];
 #pragma unroll
@@ -305,11 +309,13 @@ __device__ __forceinline__ void dense_pair_stage(int wave, int lane) {
   const int fa_base = a_on ? woff(KA) + (c & 3) * (KROWA * 2) : ZBA, fb_base = a_on ? woff(KB) + (c & 3) * 16 : ZBB;
   int fr_scale = a_on ? 1 : 0;
   asm("" : "+v"(fr_scale));
-  int j, j1;
-  job_range<JOBS, NW>(wave, j, j1);
-  while (j < j1) {
-    const int chunk = j / NT;
+  int j0, j1;
+  job_range<JOBS, NW>(wave, j0, j1);
+#pragma unroll
+  for (int chunk = 0; chunk < NCH; ++chunk) {                  // unrolled at compile time (see dense_tile_stage)
+    int j = max(j0, chunk * NT);
     const int jend = min(j1, (chunk + 1) * NT);
+    if (j >= jend) continue;
     v4i aA[NPA][KSA], aB[TPJ];
     v4f bA[NPA], bB[TPJ];
 #pragma unroll
@@ -435,11 +441,16 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     }
     return;
   }
+  // Jobs of the depthwise stages.  A two-segment grid (conv2d_3: 28 columns = segments at x0 = 0 and 12) hands out ROW BLOCKS: the two tiles of a block are the
+  // two jobs in flight of an iteration, so a job's coordinates are its block's row and a compile-time column (the per-tile formulation spent 34 scalar
+  // instructions per iteration on two divisions by NSEG, their remainders and clamps).
+  constexpr bool BLOCKS = (NSEG == 2 && NW <= 8);
+  constexpr int JU = BLOCKS ? NRB : JPG;                          // job units per channel group
   int j, j1;
-  job_range<JOBS, NW>(wave, j, j1);
+  job_range<NG * JU, NW>(wave, j, j1);
   while (j < j1) {
-    const int cg = j / JPG;
-    const int jend = min(j1, (cg + 1) * JPG);
+    const int cg = j / JU;
+    const int jend = min(j1, (cg + 1) * JU);
     v4i a[5];                        // A fragments as dword vectors (bit-cast at the MFMA): as half vectors the compiler re-packs
                                      // every already loaded fragment behind each conditional load (~120 VALU instructions per group)
     // the lanes whose fragment is all zero read it too -- from the input buffer's top halo row, which holds zeros while the stage runs --
@@ -455,16 +466,17 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
     // one job: nine tap reads -> five MFMAs -> LeakyReLU -> fp16 -> one 8-byte store.  TWO jobs run in flight per iteration: all
     // eighteen tap reads are issued before the first MFMA and the two accumulator chains interleave (the default schedule paired
     // every MFMA with its own reads: five LDS round trips in a row per job, 1250 cycles per job in the stage timeline).
-    auto taps = [&](int jj, uint2 (&tp)[9], char*& dst) {
-      const int rem = jj - cg * JPG;
-      const int rb = rem / NSEG, seg = rem - rb * NSEG;
-      const int oy0 = min(rb * 4, H - 4);
-      const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
+    auto taps_at = [&](int oy0, int x0, uint2 (&tp)[9], char*& dst) {
       // tap (ky,kx) of output (oy,ox) sits at halo'd row oy*STRIDE+ky, column ox*STRIDE+kx; depthwise: channel group cg
       const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + (DEPTHWISE ? 8 * cg : 0) + lane_in;
 #pragma unroll
       for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
       dst = (GOUT ? gout : lds) + OUT::at(oy0 + g, x0 + xl) + 8 * cg + OUT_B0;
+    };
+    auto taps = [&](int jj, uint2 (&tp)[9], char*& dst) {
+      const int rem = jj - cg * JPG;
+      const int rb = rem / NSEG, seg = rem - rb * NSEG;
+      taps_at(min(rb * 4, H - 4), (W >= 16) ? min(seg * 16, W - 16) : 0, tp, dst);
     };
     auto kstep = [&](const uint2 (&tp)[9], int ks, v4f acc) {
       const uint2 lo = tp[2 * ks], hi = tp[ks < 4 ? 2 * ks + 1 : 8];
@@ -476,11 +488,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       if constexpr (GOUT) *(glb_v2u_p)(uintptr_t)dst = v2u_t{v.x, v.y};
       else *reinterpret_cast<uint2*>(dst) = v;
     };
-    for (; NW <= 8 && j + 1 < jend; j += 2) {
-      uint2 tp0[9], tp1[9];
-      char *d0, *d1;
-      taps(j, tp0, d0);
-      taps(j + 1, tp1, d1);
+    auto pair = [&](const uint2 (&tp0)[9], const uint2 (&tp1)[9], char* d0, char* d1) {
       __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);         // the eighteen tap reads ...
       __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);         // ... then the ten MFMAs
       v4f acc0 = bias, acc1 = bias;
@@ -488,17 +496,35 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
       for (int ks = 0; ks < 5; ++ks) { acc0 = kstep(tp0, ks, acc0); acc1 = kstep(tp1, ks, acc1); }
       finish(acc0, d0);
       finish(acc1, d1);
-    }
-    for (; j < jend; ++j) {
-      uint2 tp[9];
-      char* dst;
-      taps(j, tp, dst);
-      __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-      v4f acc = bias;
+    };
+    if constexpr (BLOCKS) {
+      for (; j < jend; ++j) {
+        const int oy0 = min((j - cg * NRB) * 4, H - 4);
+        uint2 tp0[9], tp1[9];
+        char *d0, *d1;
+        taps_at(oy0, 0, tp0, d0);
+        taps_at(oy0, W - 16, tp1, d1);
+        pair(tp0, tp1, d0, d1);
+      }
+    } else {
+      for (; NW <= 8 && j + 1 < jend; j += 2) {
+        uint2 tp0[9], tp1[9];
+        char *d0, *d1;
+        taps(j, tp0, d0);
+        taps(j + 1, tp1, d1);
+        pair(tp0, tp1, d0, d1);
+      }
+      for (; j < jend; ++j) {
+        uint2 tp[9];
+        char* dst;
+        taps(j, tp, dst);
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        v4f acc = bias;
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) acc = kstep(tp, ks, acc);
-      finish(acc, dst);
+        for (int ks = 0; ks < 5; ++ks) acc = kstep(tp, ks, acc);
+        finish(acc, dst);
+      }
     }
   }
 }
@@ -843,7 +869,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
   const long G = gridDim.x;
   // a BATCH: up to NW of the workgroup's frames (base + k G): their front stages one after the other, then one tail phase with a wave per frame
   for (long base = blockIdx.x; base < prm.n; base += NW * G) {
-    const int nb = (int)min((long)NW, (prm.n - base + G - 1) / G);
+    int nb = 1;                                                 // frames of this batch: base + k G < n (counted: a 64-bit division costs ~120 scalar instructions per wave)
+#pragma unroll
+    for (int k = 1; k < NW; ++k) nb += (base + k * G < prm.n) ? 1 : 0;
     // Padding channels and k-slots whose weights are zero may hold stale data: fine as long as it is FINITE (0 * NaN = NaN).  Everything the
     // stages store is finite fp16, but the tail phase leaves fp32 biases in the arena: it is cleared once per batch.
     for (int i = tid0; i < LDS_BYTES / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
