@@ -56,8 +56,15 @@ struct Buf {
   }
 };
 //              OFF    W   H   S  RS PT PL
-typedef Buf<     0, 56, 56,  8, 57, 1, 1> B_IN;    // RGBX fp16, top/left halo (3x3 stride 2, pad 1)
-typedef Buf< 26000, 28, 28, 16, 30, 1, 1, 0, YF16_ROW_SKEW> B_T1;    // conv1 out, 8 ch, halo ring; 30 rows of 488 bytes
+// The input frame in COLUMN-PARITY PLANES: halo'd column hx = x + 1 of a row sits in plane hx & 1 at index hx >> 1 (plane 0: 29 pixels from byte 0, plane 1:
+// 28 pixels from byte IN_PLANE1), so the stride-2 taps of conv2d_1 -- tap kx of output column ox is halo'd column 2 ox + kx = {plane 0 [ox], plane 1 [ox],
+// plane 0 [ox + 1]} -- are reads of CONSECUTIVE 8-byte pixels across a tile row (16 lanes on 32 banks) instead of every other pixel (16 lanes on the 16 bank
+// pairs 4k, 4k+1, the next tile row on the same ones: 5.1 pipe cycles per tap read in the per-stage counters, 444 of the stage's 1128 LDS cycles conflicts).
+// Rows are 480 bytes apart and conv2d_1's tile rows go to the lane groups in the order 0, 2, 1, 3: the two rows of a 32-lane half are then 2 x 960 bytes =
+// 32 banks (mod 64) apart, and every tap read touches each bank once.  at() does not apply to this buffer.
+typedef Buf<     0, 56, 56,  8, 58, 1, 1, 0, 16> B_IN;    // RGBX fp16, top halo row, halo column = plane 0 [0]; 57 rows of 480 bytes
+constexpr int IN_PLANE1 = 29 * 8;
+typedef Buf< 27360, 28, 28, 16, 30, 1, 1, 0, YF16_ROW_SKEW> B_T1;    // conv1 out, 8 ch, halo ring; 30 rows of 488 bytes
 typedef Buf<     0, 28, 28, 16, 28, 0, 0> B_T2;    // dw3 out, 8 ch (on the dead input frame: conv2d_5 -> conv2d_6 reads it while it writes T4)
 typedef Buf< 12544, 28, 28, 40, 29, 1, 1> B_T4;    // c6 out, 18 ch (stride 20), top/left halo for dw10
 typedef Buf< 46184, 14, 28, 36, 14, 0, 0> B_HB;    // pool_8 horizontal pass, 18 ch
@@ -73,7 +80,7 @@ constexpr int ZSLACK = 75984;                       // the 48 bytes between the 
 static_assert(ZSLACK == B_T14::OFF + 14 * 14 * 80 && ZSLACK + 48 <= LDS_BYTES && ZSLACK % 16 == 0, "zero spot of the dense stages with at most three k-steps");
 static_assert(B_T8::OFF + 16 * B_T8::ROWB <= B_T9::OFF && B_T9::OFF + 196 * 80 <= B_T11::OFF && B_T11::OFF + 196 * 16 <= B_T14::OFF && B_T15::OFF + 15 * B_T15::ROWB <= B_T8::OFF, "skewed buffers do not run into their neighbours");
 static_assert(B_T14::OFF + 14 * 14 * 80 <= LDS_BYTES && B_HB::OFF + 28 * 14 * 36 <= B_T14::OFF && B_T4::OFF + 29 * 29 * 40 <= B_HB::OFF, "plan");
-static_assert(B_IN::OFF + 57 * 57 * 8 <= B_T1::OFF && B_T1::OFF + 30 * B_T1::ROWB <= B_HB::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T4::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T1::OFF, "plan: conv2d_3 reads T1 and writes T2; conv2d_5 -> conv2d_6 reads T2 and writes T4");
+static_assert(B_IN::OFF + 57 * B_IN::ROWB <= B_T1::OFF && B_IN::ROWB == 480 && B_T1::OFF % 16 == 0 && B_T1::OFF + 30 * B_T1::ROWB <= B_HB::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T4::OFF && B_T2::OFF + 28 * 28 * 16 <= B_T1::OFF, "plan: conv2d_3 reads T1 and writes T2; conv2d_5 -> conv2d_6 reads T2 and writes T4");
 
 // ---- weight ring.  A conv's A-operand rows come from LDS, not from global memory: stage k's first act is ONE LDS-DMA of stage
 // k+1's rows (global_load_lds_dwordx4: 64 x 16 bytes per wave-instruction, no registers), so that the next stage's waves read
@@ -388,7 +395,7 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
   static_assert(WBYTES[K] == ((C + 3) / 4) * 320, "stage and weight block agree");
   constexpr int NSEG = (W + 15) / 16, NRB = (H + 3) / 4;
   constexpr int NG = (C + 3) / 4;                                  // output-channel groups of 4
-  constexpr int JPG = NRB * NSEG, JOBS = NG * JPG;
+  constexpr int JPG = NRB * NSEG;
   constexpr int DROW = STRIDE * IN::ROWB, TS = IN::S, TR = IN::ROWB;
   const int g = lane >> 4, c = lane & 15;
   const int xl = min(c, W - 1);                                    // surplus lanes redo the last column (same value, same address)
@@ -411,17 +418,21 @@ __device__ __forceinline__ void conv3x3_stage(char* lds, const uint8_t* __restri
         asm volatile("" : "+v"(bias[q]));
       }
     }
+    // the input is in column-parity planes (B_IN): the three taps of a row are plane 0 [ox], plane 1 [ox], plane 0 [ox + 1]; tile row gp of lane group g
+    static_assert(STRIDE == 2 && IN::S == 8 && IN::RS == 58, "conv2d_1 reads the plane layout of B_IN");
+    const int gp = ((g & 1) << 1) | (g >> 1);
+    const int lane_pl = gp * DROW + xl * IN::S;
     int jt, jt1;
     job_range<JPG, NW>(wave, jt, jt1);
     for (; jt < jt1; ++jt) {
       const int rb = jt / NSEG, seg = jt - rb * NSEG;
       const int oy0 = min(rb * 4, H - 4);
       const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
-      const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + lane_in;
+      const char* src = lds + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * IN::S + lane_pl;
       uint2 tp[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3) * TS);
-      char* dst = lds + OUT::at(oy0 + g, x0 + xl);
+      for (int k = 0; k < 9; ++k) tp[k] = lds_tap64(src + (k / 3) * TR + (k % 3 == 0 ? 0 : k % 3 == 1 ? IN_PLANE1 : IN::S));
+      char* dst = lds + OUT::at(oy0 + gp, x0 + xl);
       v4f acc[NG];
 #pragma unroll
       for (int q = 0; q < NG; ++q) acc[q] = bias[q];
@@ -902,11 +913,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
         const int i = tid0 + kk * NT;
         if (IN_ITERS * NT != 56 * 28 && i >= 56 * 28) break;
         const uint32_t d0 = pin[kk][0], d1 = pin[kk][1], d2 = pin[kk][2];
-        const int y = i / 28, x2 = (i - y * 28) * 2;
+        const int y = i / 28, xh = i - y * 28;
         uint4 px = {d0, d1 & 0xFFFFu, (d1 >> 16) | (d2 << 16), d2 >> 16};
-        // pixels x2 and x2+1 of row y: halo'd pixel index (y + 1) * 57 + x2 + 1 (8 bytes each; the pair is 8-byte aligned only)
-        uint2* dst = reinterpret_cast<uint2*>(lds + B_IN::at(y, x2));
-        dst[0] = uint2{px.x, px.y}; dst[1] = uint2{px.z, px.w};
+        // pixels 2 xh and 2 xh + 1 of row y = halo'd columns 2 xh + 1 (plane 1 [xh]) and 2 xh + 2 (plane 0 [xh + 1]) of halo'd row y + 1
+        char* row = lds + B_IN::OFF + (y + 1) * B_IN::ROWB + xh * 8;
+        *reinterpret_cast<uint2*>(row + IN_PLANE1) = uint2{px.x, px.y};
+        *reinterpret_cast<uint2*>(row + 8) = uint2{px.z, px.w};
       }
       fill_halo<B_IN, false, NT>(lds, tid);
       fill_halo<B_T1, true, NT>(lds, tid);

@@ -966,6 +966,9 @@ __device__ __forceinline__ void epilogue2_half(char* dstpix, const char* addpix,
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(r[0], r[1]) ^ 0x8080u;
   }
 }
+#ifndef YF_CHUNK_UNROLL
+#define YF_CHUNK_UNROLL 0       /* dense stages with at most this many channel chunks unroll their chunk loop at compile time (0: never) */
+#endif
 #define YF_HALF_PASS 1          /* the last pass of a layer with 4k + 2 output channels requantises its two real channels only */
 
 // ---- dense 1x1 (lane-private MFMA, see dense_stage), constants from ring slot CS
@@ -1005,8 +1008,8 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
   }
   int j0, j1;
   job_range<JOBS, NW>(wave, j0, j1);
-  int chunk = (int)((uint32_t)j0 / (uint32_t)MT), mt = j0 - chunk * MT, left = j1 - j0;
-  while (left > 0) {
+  // one chunk of the wave's job range: jobs mt .. mt + n - 1 of channel chunk `chunk`
+  auto run_chunk = [&](const int chunk, int mt, const int n) __attribute__((always_inline)) {
     // ---- the chunk's constants: TPJ passes of {A fragments, 2M, ZR} from the ring slot, {C64, shift} by scalar loads
     v4i a[TPJ][KS];
     PassV pv[TPJ];
@@ -1022,7 +1025,6 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
       const uint8_t* s = sc + min(ps, NP - 1) * (int)sizeof(yf_pass_s);
       ksr[t] = PassS{*(cv4ul_ptr)(uintptr_t)s, *(cv4i_ptr)(uintptr_t)(s + 32)};
     }
-    const int n = min(left, MT - mt);
     const int cq = chunk * TPJ * 4;                              // first channel of the chunk: rides in the pixel bases, the pass in the immediates
     const int out_cc = out_c + cq, add_cc = add_c + cq;
     for (int k = 0; k < n; ++k, ++mt) {
@@ -1080,7 +1082,22 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
         }
       }
     }
-    left -= n; ++chunk; mt = 0;
+  };
+  // Stages with at most YF_CHUNK_UNROLL chunks walk them in a loop unrolled at compile time: a chunk's pass numbers, the addresses of its scalar constants,
+  // its `pass exists` / `half pass` tests and its channel offset are constants of its copy instead of scalar arithmetic and branches on the wave's path.
+  if constexpr (NCH <= YF_CHUNK_UNROLL) {
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      const int lo = max(j0, chunk * MT), hi = min(j1, (chunk + 1) * MT);
+      if (lo < hi) run_chunk(chunk, lo - chunk * MT, hi - lo);
+    }
+  } else {
+    int chunk = (int)((uint32_t)j0 / (uint32_t)MT), mt = j0 - chunk * MT, left = j1 - j0;
+    while (left > 0) {
+      const int n = min(left, MT - mt);
+      run_chunk(chunk, mt, n);
+      left -= n; ++chunk; mt = 0;
+    }
   }
 }
 
