@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage timeline of the fused kernel.  Needs a library built with -DYF_BARPROF
-(make -C stm32h7-yolo_amd/csrc OUT=../lib_prof HIPFLAGS+=' -DYF_BARPROF'; YF_LIB_PATH=.../lib_prof/libyf_network.so):
+(make -C stm32h7-yolo_amd/csrc OUT=../lib_prof EXTRA_HIPFLAGS=-DYF_BARPROF; YF_LIB_PATH=.../lib_prof/libyf_network.so):
 every wave then stores the cycle counter on arrival at and on release from each __syncthreads() of its workgroup's
 second group (steady state).  Prints, per barrier interval, how long the waves worked (mean / slowest wave = the
 interval's critical path) and how long they waited.  DEV TOOL."""
