@@ -9,4 +9,4 @@ HIPFLAGS_BASE = --offload-arch=gfx950 -Os -std=c++17 -fPIC -fvisibility=hidden -
 # the fused fp16 kernel: -O3 (measured faster than the -Os / iterative-ilp flags of the int8 engine) without loop strength reduction (+2.3 %; with
 # iterative-ilp or max-ilp on top -1 %)
 FP16FLAGS_BASE = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wall -mllvm -disable-lsr
-DEVICE_SRCS = yf_engine.hip yf_kernels.hip.h yf_decode.hip.h yf_tables.h yf_stream_scratch.h gen/yf_decode_tables_gen.h yf_fp16.hip yf_fp16.h
+DEVICE_SRCS = yf_engine.hip yf_kernels.hip.h yf_fused56.hip.h yf_band160.hip.h yf_lab_stages.hip.h yf_lab_layerwise.hip.h yf_decode.hip.h yf_tables.h yf_stream_scratch.h gen/yf_decode_tables_gen.h yf_fp16.hip yf_fp16.h

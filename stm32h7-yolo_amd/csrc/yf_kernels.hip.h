@@ -16,8 +16,11 @@
 //   residual add          : TFLite int8 ADD arithmetic in the producing conv's epilogue
 //   concat                : producers write straight into the concat buffer (no copy)
 // Included twice by yf_engine.hip: namespace yf (56x56: the fused kernel) and namespace yf160 (YF_H0 160: the banded kernels).
-// -DYF_LAB (make lab -> lib_lab/) adds what only tools and two debugging tests use: the other fused shapes and the layer-by-layer 160x160 form with
-// the round-2 stage forms it is written in.
+// This file holds what both share -- the LDS plan, the arithmetic, input staging, pools and the stage forms (namespace v2) -- and includes, from inside
+// the namespace:   yf_fused56.hip.h   the fused 56x56 kernel            (namespace yf)
+//                  yf_band160.hip.h   the three banded 160x160 kernels  (namespace yf160)
+// -DYF_LAB (make lab -> lib_lab/) adds what only tools and two debugging tests use: the other fused shapes, and yf_lab_stages.hip.h /
+// yf_lab_layerwise.hip.h = the layer-by-layer 160x160 form with the round-2 stage forms it is written in.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -514,258 +517,8 @@ YF_STAGE_FN void stage_input_cam(char* frames, const uint8_t* __restrict__ cam, 
 struct AddK { uint32_t mo2, zro; unsigned long c64o; int rso; };
 
 #ifdef YF_LAB
-// ==== round-2 stage forms (constants from global memory, per-job index arithmetic): what the layer-by-layer 160x160 kernels are written in
-// ------------------------------------------------------------------------------------------------ epilogue store
-
-// idx[4]: the pass's four requantised channels as unsigned bytes q + 128 (= LUT indices) of pixel p of frame f
-template <int EPI, int LUT_ID, class OUT, int OUT_CH0, class ADDB>
-__device__ __forceinline__ void epilogue_store(char* fbase /*frame arena*/, char* out_all, int f, int p, int chq,
-                                               const int (&idx)[4], const AddK& ad) {
-  if constexpr (EPI == EPI_LUT) {
-    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) =
-        join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
-  } else if constexpr (EPI == EPI_RAW) {
-    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-  } else if constexpr (EPI == EPI_ADD) {
-    // tflite ADD (LUT_ID = add index): in1 = stored tensor (ADDB) -> table A, in2 = this conv's output -> table B (which
-    // carries the accumulator offset), then one fused requantisation of the sum.
-    typedef const __attribute__((address_space(3))) int* lds_i32_ptr;
-    constexpr uint32_t LA = YF_N_LUT * 256 + LUT_ID * 2048, LB = LA + 1024;
-    const uint32_t o = lds_u32(fbase + ADDB::at_p(p) + chq) ^ 0x80808080u;
-    v4i sum;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      sum[j] = *(lds_i32_ptr)(uint32_t)(LA + 4 * ((o >> (8 * j)) & 255)) + *(lds_i32_ptr)(uint32_t)(LB + 4 * idx[j]);
-    int r[4];
-    requant4<false>(sum, v4u{ad.mo2, ad.mo2, ad.mo2, ad.mo2}, v4u{ad.zro, ad.zro, ad.zro, ad.zro},
-                    v4ul{ad.c64o, ad.c64o, ad.c64o, ad.c64o}, v4i{ad.rso, ad.rso, ad.rso, ad.rso}, r);
-    *reinterpret_cast<uint32_t*>(fbase + OUT::at_p(p) + OUT_CH0 + chq) = join4(r[0], r[1], r[2], r[3]) ^ 0x80808080u;
-  } else {  // head: 18 channels per pixel, 2-byte aligned, staged for one coalesced copy to HBM
-    static_assert(EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "epilogue kind");
-    const uint32_t v = join4(idx[0], idx[1], idx[2], idx[3]) ^ 0x80808080u;
-    uint16_t* dst = reinterpret_cast<uint16_t*>((EPI == EPI_HEAD ? out_all + f * OUT_FRAME_BYTES : fbase + OUT::OFF) + p * 18 + chq);
-    dst[0] = (uint16_t)v;
-    if (chq + 2 < 18) dst[1] = (uint16_t)(v >> 16);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ dense 1x1
-// Lane-private MFMA: the lane's own pixel supplies KS fragments of 16 bytes (k-steps; the last one BW = 4, 8 or 16 bytes
-// wide), the A operand of k-step ks carries W[4*pass + (r&3)][16*ks ..] in row r's own slot group only, and KS MFMAs
-// accumulate the 4 channels of one pass for 64 pixels.  Every lane owns ONE pixel: no lane is wasted when Cout is not a
-// multiple of 16 (6, 8, 18, 24, 40), the constants of a pass are wave-uniform, and the pixel math is shared by the TPJ
-// passes of a job.  MFMA count grows (KS per 4 channels) but the matrix pipe is idle anyway.
-template <int F, int NW, int TPJ, int KS, int BW, class IN, class OUT, int OUT_CH0, int COUT, int EPI, int LUT_ID, class ADDB>
-YF_STAGE_FN void dense_stage(char* frames, char* out_all, const uint8_t* __restrict__ tab, const yf_dense d, const AddK ad,
-                             int wave, int lane, int vz) {
-  constexpr int NP = (COUT + 3) / 4;                        // passes of 4 output channels
-  constexpr int NCH = (NP + TPJ - 1) / TPJ;
-  constexpr int P = IN::P, TOT = F * P;
-  constexpr int MT = (TOT + 63) / 64;
-  constexpr int JOBS = NCH * MT;
-  constexpr int KROW = 16 * KS;
-  static_assert(OUT::P == P || EPI == EPI_HEAD || EPI == EPI_HEAD_LDS, "1x1 conv keeps the grid");
-  static_assert(IN::FS == OUT::FS && IN::FS == ADDB::FS, "one frame stride per stage");
-  static_assert(IN::S >= 16 * (KS - 1) + BW && (BW == 4 || BW == 8 || BW == 16), "the pixel vector must cover all k-steps");
-  const int g = lane >> 4, c = lane & 15;
-  int j0, j1;
-  job_range<JOBS, NW>(wave, j0, j1);
-  const uint8_t* pp = tab + d.c_off;
-  const bool a_on = (c >> 2) == g;
-  int cur_chunk = -1;
-  v4i a[TPJ][KS];
-  PassV pv[TPJ];
-  PassS ksr[TPJ];                           // scalar constants stay resident per chunk (one load per tile costs a wait per tile)
-  for (int j = j0; j < j1; ++j) {
-    const int chunk = j / MT, mt = j - chunk * MT;
-    if (chunk != cur_chunk) {
-      cur_chunk = chunk;
-#pragma unroll
-      for (int t = 0; t < TPJ; ++t) {
-        const int ps = min(chunk * TPJ + t, NP - 1);
-        pv[t] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
-        ksr[t] = load_pass_s(pp + ps * (int)sizeof(yf_pass));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          a[t][ks] = v4i{0, 0, 0, 0};
-          if (a_on) a[t][ks] = load_wfrag(tab + d.w_off + (ps * 4 + (c & 3)) * KROW + 16 * ks, vz);
-        }
-      }
-    }
-    const int q = mt * 64 + lane;
-    const int qc = min(q, TOT - 1);
-    const int f = qc / P, p = qc - f * P;
-    char* fbase = frames + f * IN::FS;
-    v4i b[KS];
-    {
-      const char* src = fbase + IN::at_p(p);
-      {
-#pragma unroll
-      for (int ks = 0; ks < KS - 1; ++ks) b[ks] = *reinterpret_cast<const v4i*>(src + 16 * ks);
-      const char* last = src + 16 * (KS - 1);
-      if constexpr (BW == 16) b[KS - 1] = *reinterpret_cast<const v4i*>(last);
-      else if constexpr (BW == 8) { const int2 t2 = *reinterpret_cast<const int2*>(last); b[KS - 1] = v4i{t2.x, t2.y, any_value(), any_value()}; }
-      else b[KS - 1] = v4i{*reinterpret_cast<const int*>(last), any_value(), any_value(), any_value()};
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < TPJ; ++t) {
-      const int ps = chunk * TPJ + t;
-      if (ps < NP) {                                          // uniform
-        const PassS k = ksr[t];
-        v4i acc = {ACC0, ACC0, ACC0, ACC0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][ks], b[ks], acc, 0, 0, 0);
-        int idx[4];                         // no exec mask: surplus lanes redo pixel TOT-1 (same value, same address)
-        requant4<true>(acc, pv[t].m2, pv[t].zr, k.c64, k.rs, idx);
-        epilogue_store<EPI, LUT_ID, OUT, OUT_CH0, ADDB>(fbase, out_all, f, p, ps * 4, idx, ad);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ conv2d_1
-// 3x3 stride 2, Cin 3 -> 8 on RGBX dwords, lane-private like the 1x1 stages: the lane's pixel gathers its nine taps
-// (nine aligned dwords of the staged frame) into three k-steps, both 4-channel passes share them.
-template <int F, int NW, class IN = B_IN, class OUT = B_T1>
-YF_STAGE_FN void conv1_stage(char* frames, const uint8_t* __restrict__ tab, const yf_dense d, int wave, int lane, int vz) {
-  constexpr int P = OUT::P, W1 = OUT::W, RSW = IN::RS, TOT = F * P;
-  constexpr int MT = (TOT + 63) / 64;
-  const int g = lane >> 4, c = lane & 15;
-  const bool a_on = (c >> 2) == g;
-  const uint8_t* pp = tab + d.c_off;
-  v4i a[2][3];
-  PassV pv[2];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    pv[ps] = load_pass_v(pp + ps * (int)sizeof(yf_pass), vz);
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      a[ps][ks] = v4i{0, 0, 0, 0};
-      if (a_on) a[ps][ks] = load_wfrag(tab + d.w_off + (ps * 4 + (c & 3)) * YF_CONV1_KROW + 16 * ks, vz);
-    }
-  }
-  int j0, j1;
-  job_range<MT, NW>(wave, j0, j1);
-  const AddK ad = {};
-  for (int mt = j0; mt < j1; ++mt) {
-    const int q = mt * 64 + lane;
-    const int qc = min(q, TOT - 1);
-    const int f = qc / P, p = qc - f * P;
-    const int oy = p / W1, ox = p - oy * W1;
-    char* fbase = frames + f * IN::FS;
-    // tap (ky,kx) of output (oy,ox) = IN[2oy-1+ky][2ox-1+kx] = halo'd dword (2oy+ky)*RSW + 2ox+kx+3
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(fbase + IN::OFF) + (2 * oy * RSW + 2 * ox + 3);
-    const v4i b0 = {(int)src[0], (int)src[1], (int)src[2], (int)src[RSW]};
-    const v4i b1 = {(int)src[RSW + 1], (int)src[RSW + 2], (int)src[2 * RSW], (int)src[2 * RSW + 1]};
-    const v4i b2 = {(int)src[2 * RSW + 2], any_value(), any_value(), any_value()};
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const PassS k = load_pass_s(pp + ps * (int)sizeof(yf_pass));
-      v4i acc = {ACC0, ACC0, ACC0, ACC0};
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][0], b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][1], b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
-      int idx[4];                           // no exec mask (surplus lanes redo pixel TOT-1)
-      requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
-      epilogue_store<EPI_LUT, YF_L_LEAKY2, OUT, 0, OUT>(fbase, nullptr, f, p, 4 * ps, idx, ad);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ depthwise on MFMA
-// Lane-private one-hot packing.  The 64 k-slots of v_mfma_i32_16x16x64_i8 are supplied by four lane groups of 16
-// slots each; rows 4g..4g+3 of the A operand are non-zero only in group g's slots.  D[4g+j][c] is then a 16-long dot
-// product over data that lane (g,c) itself supplied -- 64 independent pixels per MFMA, each lane working on ITS OWN
-// pixel.  One k-step carries 4 taps x 4 channels (4 aligned dwords of the pixel's halo'd neighbourhood), so the
-// 9 taps of a 3x3 depthwise filter take 3 k-steps; A holds w[tap][channel j] at byte j of tap's dword in row 4g+j.
-// Per 64 pixels x 4 channels: 9 ds_read_b32 off one address register, 3 MFMAs, no VALU multiply at all.
-// IN has a halo holding its zero point; the zero point itself is folded into the requantisation constant.
-// A job = 4 output rows x 16 columns (2 frames side by side for the 7x7 grids); border blocks are shifted inwards so
-// every lane's neighbourhood address is in range.
-template <int F, int NW, int STRIDE, class IN, class OUT, int C, int LUT_ID>
-YF_STAGE_FN void dw_mfma_stage(char* frames, const uint8_t* __restrict__ tab, const yf_dw d, int wave, int lane, int vz) {
-  constexpr int W = OUT::W, H = OUT::H;
-  constexpr int FL = (W <= 8 && F % 2 == 0) ? 2 : 1;       // frames side by side in the 16 lanes of a row tile
-  constexpr int NSEG = (W + 15) / 16;                       // 16-column segments, the last one shifted left (28 -> x0 in {0, 12})
-  constexpr int NRB = (H + 3) / 4;                          // 4-row blocks (last one shifted up)
-  constexpr int NG = (C + 3) / 4;
-  constexpr int NFP = F / FL;
-  constexpr int JPG = NFP * NRB * NSEG;                     // jobs per channel group
-  constexpr int JOBS = NG * JPG;
-  constexpr int DROW = STRIDE * IN::ROWB;                   // input bytes between consecutive output rows
-  constexpr int TS = IN::S, TR = IN::ROWB;                  // tap strides: +1 column, +1 row
-  static_assert(OUT::RS == W && OUT::PT == 0 && OUT::PL == 0, "depthwise outputs are plain buffers");
-  static_assert(IN::FS == OUT::FS, "one frame stride per stage");
-  static_assert(H >= 4 && (W >= 16 || W * FL <= 16), "tile shape");
-  const int g = lane >> 4, c = lane & 15;
-  const int fl = (FL == 2) ? (c >> 3) : 0;
-  const int xl = (FL == 2) ? min(c & 7, W - 1) : min(c, W - 1);      // surplus lanes duplicate the last column (idempotent)
-  const int lane_in = fl * IN::FS + g * DROW + xl * STRIDE * IN::S;      // this lane's pixel: row oy0+g, col x0+xl
-  const int lane_out = fl * IN::FS + (g * W + xl) * OUT::S;
-  const bool a_on = (c >> 2) == g;                          // A row r = c belongs to row block r>>2
-  int j, j1;
-  job_range<JOBS, NW>(wave, j, j1);
-  while (j < j1) {
-    const int cg = j / JPG;
-    const int jend = min(j1, (cg + 1) * JPG);
-    const uint8_t* grp = tab + d.g_off + cg * YF_DW_GROUP_BYTES;
-    const uint32_t* wg = reinterpret_cast<const uint32_t*>(grp);
-    v4i a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;                // k-steps: taps 0-3, 4-7, 8
-    if (a_on) {
-      const uint32_t* wl = wg + (c & 3);                    // masked weight dwords of channel c&3: wl[4*tap]
-      a0 = v4i{(int)wl[0], (int)wl[4], (int)wl[8], (int)wl[12]};
-      a1 = v4i{(int)wl[16], (int)wl[20], (int)wl[24], (int)wl[28]};
-      a2[0] = (int)wl[32];
-    }
-    const PassV pv = load_pass_v(grp + 144, vz);
-    const PassS k = load_pass_s(grp + 144);
-    // one job: 9 tap dwords -> 3 MFMAs -> requantise -> LUT -> packed store
-    auto taps = [&](int jj, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
-      int rem = jj - cg * JPG;
-      const int fp = rem / (NRB * NSEG); rem -= fp * (NRB * NSEG);
-      const int rb = rem / NSEG, seg = rem - rb * NSEG;
-      const int oy0 = min(rb * 4, H - 4);
-      const int x0 = (W >= 16) ? min(seg * 16, W - 16) : 0;
-      char* fb = frames + fp * FL * IN::FS;
-      const char* src = fb + IN::OFF + (oy0 * STRIDE) * IN::ROWB + x0 * STRIDE * IN::S + 4 * cg + lane_in;
-      b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
-      b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
-      b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);
-      dst = fb + OUT::OFF + (oy0 * W + x0) * OUT::S + lane_out + 4 * cg;
-    };
-    auto conv = [&](const v4i& b0, const v4i& b1, const v4i& b2) {
-      v4i acc = {ACC0, ACC0, ACC0, ACC0};
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-      return __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc, 0, 0, 0);
-    };
-    auto finish = [&](const v4i& acc, char* dst) {
-      int idx[4];
-      requant4<true>(acc, pv.m2, pv.zr, k.c64, k.rs, idx);
-      *reinterpret_cast<uint32_t*>(dst) = join4(lutb<LUT_ID>(idx[0]), lutb<LUT_ID>(idx[1]), lutb<LUT_ID>(idx[2]), lutb<LUT_ID>(idx[3]));
-    };
-    // two jobs in flight per iteration: the second job's tap reads and MFMAs overlap the first one's epilogue chain
-    for (; j + 1 < jend; j += 2) {
-      v4i p0, p1, p2 = {0, any_value(), any_value(), any_value()}, q0, q1, q2 = {0, any_value(), any_value(), any_value()};
-      char *dp, *dq;
-      taps(j, p0, p1, p2, dp);
-      taps(j + 1, q0, q1, q2, dq);
-      const v4i ap = conv(p0, p1, p2);
-      const v4i aq = conv(q0, q1, q2);
-      finish(ap, dp);
-      finish(aq, dq);
-    }
-    for (; j < jend; ++j) {
-      v4i b0, b1, b2 = {0, any_value(), any_value(), any_value()};
-      char* dst;
-      taps(j, b0, b1, b2, dst);
-      finish(conv(b0, b1, b2), dst);
-    }
-  }
-}
-
-#endif   // YF_LAB
+#include "yf_lab_stages.hip.h"      // the round-2 stage forms (laboratory build only)
+#endif
 
 // ------------------------------------------------------------------------------------------------ max-pools
 // pool_8: 8x8 stride 2 pad 3 on T4 (28x28x18) -> separable; the vertical pass applies QUANTIZE#21 and writes the
@@ -825,28 +578,6 @@ YF_STAGE_FN void pool8_v(char* frames, int tid) {
                                  });
   }
 }
-#ifdef YF_LAB   // (the direct 4x4 form: the layer-by-layer 160x160 kernels)
-// pool_25: 4x4 stride 2 pad 1 on T15 (14x14x24) -> QUANTIZE#45 -> pool half of concat_46
-template <int F, int NT, class T15 = B_T15, class T30 = B_T30>
-YF_STAGE_FN void pool25(char* frames, int tid) {
-  constexpr int PP = T30::P, OW = T30::W, LIM = T15::W - 1;
-  static_assert(T15::FS == T30::FS, "one frame stride per stage");
-  for (int i = tid; i < F * PP * 6; i += NT) {
-    const int cg = i % 6; int t = i / 6;
-    const int p = t % PP; const int f = t / PP;
-    const int oy = p / OW, ox = p - oy * OW;
-    char* fbase = frames + f * T15::FS;
-    SplitB m;
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx)
-        m = m.mx(SplitB(lds_u32(fbase + T15::at(clampi(2 * oy - 1 + ky, 0, LIM), clampi(2 * ox - 1 + kx, 0, LIM)) + 4 * cg)));
-    *reinterpret_cast<uint32_t*>(fbase + T30::at_p(p) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
-  }
-}
-
-#endif   // YF_LAB
 
 // ================================================================================================ lean stages (round 3)
 // The 56x56 fused kernel's own forms of the dense and depthwise stages.  What changes against dense_stage / dw_mfma_stage
@@ -1366,1104 +1097,12 @@ YF_STAGE_FN void pool25_cols(char* frames, int item) {
 }
 }  // namespace v2
 #ifndef YF_GENERIC
-
-// ------------------------------------------------------------------------------------------------ debug dump
-// Observer-style per-stage dump (reference observer API, ai_platform_interface.h:684-731): logical NHWC bytes.
-template <class B, int C, int F, int NT>
-__device__ __forceinline__ void dump_buf(const char* frames, int8_t* dump, long stride, long off, long first_frame,
-                                         long n_frames, int tid, int ch0 = 0, int split = 1 << 30, int gap = 0) {
-  if (!dump) return;
-  for (int i = tid; i < F * B::P * C; i += NT) {
-    const int ch = i % C; const int t = i / C;
-    const int p = t % B::P; const int f = t / B::P;
-    if (first_frame + f >= n_frames) continue;
-    const int phys = ch0 + ch + (ch >= split ? gap : 0);
-    dump[(first_frame + f) * stride + off + (long)p * C + ch] = (int8_t)frames[f * B::FS + B::at_p(p) + phys];
-  }
-}
-
-struct DumpOffsets {   // byte offsets of each fused stage's tensor inside one frame's dump record
-  enum { T1 = 0, T2 = T1 + 6272, T3 = T2 + 6272, T4 = T3 + 3136, Q21 = T4 + 14112, T6 = Q21 + 3528, T7 = T6 + 3528,
-         T8 = T7 + 1176, T9 = T8 + 7056, T11 = T9 + 7056, T14 = T11 + 1176, T15 = T14 + 7056, Q45 = T15 + 4704,
-         T17 = Q45 + 1176, T18 = T17 + 1176, T19 = T18 + 392, T20 = T19 + 1960, T22 = T20 + 1960, T23 = T22 + 392,
-         T24 = T23 + 1960, T26 = T24 + 1960, T30 = T26 + 392, T31 = T30 + 2352, T32 = T31 + 1960, T33 = T32 + 1960,
-         // tensors that the fused stages never materialise, dumped for the per-node observer (platform_abi.c): the raw max-pools (ST's
-         // pool nodes carry their input's quantisation; the kernel applies QUANTIZE in the same pass) and the convolutions in front of
-         // the residual adds (the add is part of their epilogue).  Debug builds park them in bytes of the concat buffers that are still
-         // unwritten at that point (the conv halves) and dump them from there.
-         // ... and LEAKY_RELU #43's output (production composes it with QUANTIZE #44 into one LUT)
-         P8 = T33 + 1568, C17 = P8 + 3528, P25 = C17 + 1176, C34 = P25 + 1176, C40 = C34 + 392, L43 = C40 + 392,
-         TOTAL = L43 + 1176 };
-};
-
-// ------------------------------------------------------------------------------------------------ the kernel
-struct NetParams {
-  const int8_t* in;       // [n][56][56][3] int8
-  int8_t* out;            // [n][7][7][18] int8
-  long n;
-  const uint8_t* tab;     // device table blob (yf_host_prep.c)
-  int8_t* dump;           // optional per-stage dump, [n][DumpOffsets::TOTAL]
-  int stop_stage;         // debug kernel only: leave the group after this many stages (stage timing); <0 = run all
-  // optional fused box decode (heads are decoded while still in LDS): dets == nullptr -> heads only
-  yf_det* dets;           // [n][cap] detection records
-  int* counts;            // [n] candidates per frame (may exceed cap)
-  int cap, mode;          // YF_DECODE_PY / YF_DECODE_FW
-  int q_thr;              // smallest quantised confidence that passes the mode's threshold (the sigmoid table is monotonic): set by the engine
-  float w_scale, h_scale;
-  char* scratch;          // tail batching: gridDim.x * F * TailBufs::T15_BYTES bytes (a workgroup parks one group's T15 there)
-};
-static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit its reserved slot");
-
-// Issue priority per stage (s_setprio, 0..3), stage order: staging, conv2d_1, 3, 5, 6, pool_8 h, pool_8 v, conv2d_10, 12, 13, 15,
-// 17, 19, 23, then the thirteen tail stages.  See the kernel: a workgroup's priority FALLS as its group advances.
-#ifndef YF_PRIO_LIST
-#define YF_PRIO_LIST 3,3,3,3,3,3,3,3,3,3, 2,2,2,2, 1,1,1,1,1,1, 0,0,0,0,0,0,0
-#endif
-constexpr int STAGE_PRIO[27] = {YF_PRIO_LIST};
-template <int K> __device__ __forceinline__ void stage_prio() {
-  if constexpr (K == 0 || STAGE_PRIO[K] != STAGE_PRIO[K - 1]) __builtin_amdgcn_s_setprio(STAGE_PRIO[K]);
-}
-template <bool DUMP> constexpr bool tail_batch() { return !DUMP; }
-
-// CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
-// preparation runs inside the input staging (stage_input_cam).
-template <int F, int NW, bool DUMP, bool CAM = false>
-// passes per job of conv2d_13 / conv2d_23 (lab builds may override: the register-hungry settings that spill at the 128-VGPR cap)
-#if !defined(YF_LAB) || !defined(YF_TPJ13)
-#undef YF_TPJ13
-#define YF_TPJ13 3
-#endif
-#if !defined(YF_LAB) || !defined(YF_TPJ23)
-#undef YF_TPJ23
-#define YF_TPJ23 2
-#endif
-#if defined(YF_LAB) && defined(YF_WHATIF_WPE)      // what-if: another register budget (waves per SIMD the kernel must fit)
-#define YF_WPE(NW) YF_WHATIF_WPE
-#else
-#define YF_WPE(NW) ((NW) == 12 ? 6 : (NW) >= 8 ? 4 : ((NW) == 6 ? 3 : 2))
-#endif
-__global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const NetParams prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64;
-  constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
-  constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
-  typedef TailBufs<BATCH ? FRAME_STRIDE / 2 : FRAME_STRIDE> U;
-  constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
-  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // LUTs are addressed absolutely: the host checks that the kernel has no static LDS
-  constexpr int PRE = v2::pre_bytes<F, tail_batch<DUMP>()>();   // LUTs | depthwise job tables | zeros | two constant ring slots | halo tables
-  char* out_all = smem + PRE;
-  char* frames = smem + PRE + OUT_ALL_BYTES;
-  long parked_first = -1;                                // first frame of the group whose T15 waits in the scratch
-  const int tid0 = threadIdx.x;
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
-  // Issue priorities.  A static priority for the first-dispatched half of a workgroup was worth -1.9 % in round 1 and costs
-  // 1.7 % with the tail on four frames.  What pays is a priority
-  // LADDER over a group's stages (YF_PRIO_LIST, s_setprio before a stage whenever the level changes): 3 up to conv2d_13, 2 up
-  // to conv2d_23, 1 for the first six tail stages, 0 for the rest.  The two workgroups of a CU are in different phases; the one
-  // in the VALU-bound front stages then issues ahead of the one in the latency-bound tail, which only needs the slots left
-  // over.  -6.8 % kernel time in-run (A/B 1.073 against no ladder); every placement of the three steps tried gave 6.0-7.3 %.
-  for (int i = tid0; i < v2::LUT_B / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
-  for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
-  constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + FRAME_BYTES + (F - 1) * FRAME_STRIDE;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
-  if constexpr (DUMP) { if (tid0 < YF_DBG_LUT_BYTES / 16) reinterpret_cast<uint4*>(smem + DBG_LUT)[tid0] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off + YF_N_LUT * 256 + YF_ADDLUT_BYTES)[tid0]; }
-  {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
-    typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
-    typedef typename JTS::U UT;
-    v2::fill_jobtab<F, 1, B_T1, B_T2, JTS::JT_DW3>(smem, tid0);
-    v2::fill_jobtab<F, 2, B_T4, B_T6, JTS::JT_DW10>(smem, tid0);
-    v2::fill_jobtab<F, 1, B_T8, B_T9, JTS::JT_DW15>(smem, tid0);
-    v2::fill_jobtab<JTS::FT, 2, typename UT::T15, typename UT::T17, JTS::JT_DW27>(smem, tid0);
-    v2::fill_jobtab<JTS::FT, 1, typename UT::T19, typename UT::T20, JTS::JT_DW32>(smem, tid0);
-    typedef v2::HaloTabs<F, tail_batch<DUMP>()> HTS;       // halo pixel lists of the five depthwise inputs
-    v2::build_halotab<typename HTS::G1, HTS::H_T1, NT>(smem, tid0);
-    v2::build_halotab<typename HTS::G4, HTS::H_T4, NT>(smem, tid0);
-    v2::build_halotab<typename HTS::G8, HTS::H_T8, NT>(smem, tid0);
-    v2::build_halotab<typename HTS::G15, HTS::H_T15, NT>(smem, tid0);
-    v2::build_halotab<typename HTS::G19, HTS::H_T19, NT>(smem, tid0);
-  }
-
-  const long n_groups = (prm.n + F - 1) / F;
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  constexpr long DS = DumpOffsets::TOTAL;
-#ifdef YF_BARPROF
-  // Stage timeline (tools/barrier_profile.py): for ONE group of every workgroup (its second: steady state) each wave stores
-  // the cycle counter on arrival at and on release from every __syncthreads(): [wg][wave][40][2] in prm.dump.
-  bool prof_on = false;
-  int bar_no = 0;
-  long long* prof_out = reinterpret_cast<long long*>(prm.dump) + ((long)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(tid0 >> 6)) * 80;
-#define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the LDS-DMA of the next stage's constants, as in the shipped form of YF_SYNC: the stamp follows it */ \
-                       if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
-                       if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
-#else
-  // the barrier behind a stage also publishes the LDS-DMA of the NEXT stage's constants, which the compiler does not see
-#define YF_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
-#endif
-  // Stage calls: constants from an LDS ring slot, fetched one stage ahead by YF_FETCH
-#define YF_HALO(B, RING, FR, G, HOFF, WI, TID) \
-  v2::fill_halo_t<B, typename v2::HaloTabs<F, BATCH>::G, v2::HaloTabs<F, BATCH>::HOFF>(frames, load_halo_zp(tab, WI), TID)
-#define YF_FETCH(CS, WV, LN) v2::fetch_consts<CS>(tab, WV, LN)
-#define YF_CONV1(WV, LN, CS) v2::conv1_2_stage<F, NW, CS>(frames, tab, WV, LN)
-#define YF_DENSE(FR, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, DI, AD, WV, LN, CS) \
-  v2::dense2_stage<FR, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS>(frames, out_all, tab, AD, WV, LN)
-#define YF_DW(FR, STRIDE, IN, OUT, C, LUT, WI, WV, LN, CS, JTOFF) v2::dw2_stage<FR, NW, STRIDE, IN, OUT, C, LUT, CS, v2::JobTabs<F, BATCH>::JTOFF>(frames, tab, WV, LN)
-#define YF_DUMP(BUF, C, OFF, ...) \
-  if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, F, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
-  int stage_no = 0;
-#define YF_STAGE_END() if constexpr (DUMP) { if (++stage_no == prm.stop_stage) continue; }
-#define YF_PRIO(K) stage_prio<K>()
-
-  // Fused box decode: the staged heads of group g stay in out_all until conv2d_53 of group g+1, so they are decoded by
-  // the last F waves DURING conv2d_29 of the next group (a 4-job stage: those waves are idle there), off the critical
-  // path; the workgroup's last group is decoded after the loop.
-  long prev_first = -1;
-  auto decode_prev = [&](int w, int ln) {
-    if (prm.dets != nullptr && prev_first >= 0 && w >= NW - F && prev_first + (w - (NW - F)) < prm.n) {
-      int dl = ln;
-      asm volatile("" : "+v"(dl));              // keep the decode's per-lane index arithmetic out of the kernel-wide hoisted set
-      yfdec::decode_frame(reinterpret_cast<const int8_t*>(out_all) + (w - (NW - F)) * OUT_FRAME_BYTES, prev_first + (w - (NW - F)), dl,
-                          prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap);
-    }
-  };
-  for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const long first = grp * F;
-#ifdef YF_BARPROF
-    bar_no = 0;
-    prof_on = !DUMP && prm.dump != nullptr && grp == (long)blockIdx.x + gridDim.x;
-#endif
-    // Loop-invariant code motion hoists the per-lane index arithmetic of every stage out of this loop and parks the
-    // results in VGPRs for the whole kernel.  YF_LAUNDER selects stage groups (1 front 28x28, 2 middle 14x14, 4 tail
-    // 7x7) whose thread index is laundered once per group, i.e. recomputed instead of parked.
-    int tid = tid0, tid_f = tid0, tid_m = tid0, tid_t = tid0;
-    if constexpr ((YF_LAUNDER & 1) != 0) asm volatile("" : "+v"(tid_f));
-    if constexpr ((YF_LAUNDER & 2) != 0) asm volatile("" : "+v"(tid_m));
-    if constexpr ((YF_LAUNDER & 4) != 0) asm volatile("" : "+v"(tid_t));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L_f = tid_f & 63, L_m = tid_m & 63, L_t = tid_t & 63;
-    const int W_f = __builtin_amdgcn_readfirstlane(tid_f >> 6), W_m = __builtin_amdgcn_readfirstlane(tid_m >> 6), W_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
-    (void)lane; (void)wave;
-#if !defined(YF_BARPROF)
-    // previous group's arena is dead.  LDS-only barrier: __syncthreads() would also wait for the acknowledgements of the
-    // previous group's head / detection / parking stores (vmcnt), which nothing in this group depends on
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    YF_SYNC();
-#endif
-    stage_no = 0;
-    YF_PRIO(0);
-    int tid_s = tid0;
-    asm volatile("" : "+v"(tid_s));         // the staging offsets are cheap: recomputed per group instead of parked in VGPRs for the whole kernel
-    if constexpr (CAM) stage_input_cam<F, NT>(frames, reinterpret_cast<const uint8_t*>(prm.in), first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
-    else stage_input<F, NT>(frames, prm.in, first, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid_s);
-    YF_FETCH(0, W_f, L_f);                                                                            // conv2d_1's constants -> ring slot 0
-    YF_HALO(B_T1, true, F, G1, H_T1, YF_W_DW3, tid_f);
-    YF_SYNC();
-    YF_STAGE_END()
-    YF_PRIO(1);
-    YF_FETCH(1, W_f, L_f);
-    YF_CONV1(W_f, L_f, 0);                                                                            // conv2d_1
-    YF_SYNC(); YF_DUMP(B_T1, 8, T1)
-    YF_STAGE_END()
-    YF_PRIO(2);
-    YF_FETCH(2, W_f, L_f);
-    YF_DW(F, 1, B_T1, B_T2, 8, YF_L_LEAKY4, YF_W_DW3, W_f, L_f, 1, JT_DW3);                              // conv2d_3
-    YF_SYNC(); YF_DUMP(B_T2, 8, T2)
-    YF_STAGE_END()
-    YF_PRIO(3);
-    YF_FETCH(3, W_f, L_f);
-    YF_DENSE(F, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3, YF_D_C5, no_add, W_f, L_f, 2);              // conv2d_5
-    YF_SYNC(); YF_DUMP(B_T3, 4, T3)
-    YF_STAGE_END()
-    YF_PRIO(4);
-    YF_HALO(B_T4, false, F, G4, H_T4, YF_W_DW10, tid_f);
-    YF_FETCH(4, W_f, L_f);
-    YF_DENSE(F, 5, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50; experimental bit 1024: three)
-    YF_SYNC(); YF_DUMP(B_T4, 18, T4)
-    YF_STAGE_END()
-    YF_PRIO(5);
-#if !(defined(YF_LAB) && defined(YF_WHATIF_NO_POOL8H))   // what-if (WRONG results): the horizontal pass and its barrier gone -- the bound for folding it into conv2d_6's epilogue
-    pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
-    YF_SYNC();
-#endif
-    YF_STAGE_END()
-    YF_PRIO(6);
-    pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
-    YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
-    YF_PRIO(7);
-    YF_FETCH(5, W_m, L_m);
-    YF_DW(F, 2, B_T4, B_T6, 18, YF_L_LEAKY11, YF_W_DW10, W_m, L_m, 4, JT_DW10);                          // conv2d_10
-    YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T14, 18, P8, YF_T14_CONV_BASE) YF_DUMP(B_T6, 18, T6)
-    YF_STAGE_END()
-    YF_PRIO(8);
-    YF_FETCH(6, W_m, L_m);
-    YF_DENSE(F, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);            // conv2d_12
-    YF_SYNC(); YF_DUMP(B_T7, 6, T7)
-    YF_STAGE_END()
-    YF_PRIO(9);
-    YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
-    YF_FETCH(7, W_m, L_m);
-    YF_DENSE(F, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
-    YF_SYNC(); YF_DUMP(B_T8, 36, T8)
-    YF_STAGE_END()
-    YF_PRIO(10);
-    YF_FETCH(8, W_m, L_m);
-    YF_DW(F, 1, B_T8, B_T9, 36, YF_L_LEAKY16, YF_W_DW15, W_m, L_m, 7, JT_DW15);                          // conv2d_15
-    YF_SYNC(); YF_DUMP(B_T9, 36, T9)
-    YF_STAGE_END()
-    YF_PRIO(11);
-    YF_FETCH(9, W_m, L_m);
-    if constexpr (DUMP)   // debug builds: conv2d_17's own output is parked in the (still unwritten) conv half of concat_22 for the dump
-      v2::dense2_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, 8, B_T14::OFF + YF_T14_CONV_BASE, B_T14::S>(frames, out_all, tab, addctx(YF_A_ADD18), W_m, L_m);
-    else
-    YF_DENSE(F, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, YF_D_C17, addctx(YF_A_ADD18), W_m, L_m, 8);   // conv2d_17 + eltwise_18
-    YF_SYNC(); YF_DUMP(B_T11, 6, T11) YF_DUMP(B_T14, 6, C17, YF_T14_CONV_BASE)
-    YF_STAGE_END()
-    YF_PRIO(12);
-    YF_FETCH(10, W_m, L_m);
-    YF_DENSE(F, 3, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14, YF_D_C19, no_add, W_m, L_m, 9);  // conv2d_19 -> concat_22
-    YF_SYNC(); YF_DUMP(B_T14, 36, T14, 0, 18, 2)
-    YF_STAGE_END()
-    YF_PRIO(13);
-    // BATCH: the parked group's T15 goes from the scratch straight into the odd tail sets by LDS-DMA (no registers), issued
-    // here -- their bytes (T9/T11's old slots) are dead once conv2d_19 is through.  The wait that guards it is the explicit
-    // s_waitcnt vmcnt(0) in front of the barrier behind conv2d_23 (this toolchain also waits at conv2d_23's first LDS access: its
-    // alias analysis cannot tell the DMA's destination from the stage's buffers, so the transfer overlaps less than it could).
-    // One wave-instruction moves 64 x 16 contiguous bytes.
-    if constexpr (BATCH) {
-      if (parked_first >= 0) {
-        constexpr int PV = TailBufs<FRAME_BYTES>::T15_BYTES / 16, WI = (PV + 63) / 64;      // vectors / wave-instructions per frame
-        const char* park = prm.scratch + (long)blockIdx.x * (F * PV * 16);
-        for (int j = W_m; j < F * WI; j += NW) {
-          const int f = j / WI, k0 = (j - f * WI) * 64;
-          if (k0 + L_m < PV)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(park + (f * PV + k0 + L_m) * 16),
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(PRE + (2 * f + 1) * U::T15::FS + 16 * k0),
-                                             16, 0, 0);
-        }
-      }
-    }
-    YF_HALO(B_T15, false, F, G15, H_T15, YF_W_DW27, tid_m);
-    YF_FETCH(11, W_m, L_m);
-    YF_DENSE(F, YF_TPJ23, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15, YF_D_C23, no_add, W_m, L_m, 10);   // conv2d_23
-    if constexpr (BATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the parked T15's LDS-DMA must have landed before the barrier that publishes the odd sets
-    YF_SYNC(); YF_DUMP(B_T15, 24, T15)
-    YF_STAGE_END()
-    // ---- the 7x7 tail.  BATCH: it runs once per PAIR of groups on FT = 2F frames.  Its thirteen stages are latency chains
-    // (98 pixels per group: one or two jobs per wave), so twice the jobs per stage cost far less than twice the time.  The
-    // first group of a pair parks its T15 (5.4 KB per frame) in a per-workgroup HBM scratch and skips the tail; the second
-    // group fetches it back into the odd tail sets -- set f of the tail sits at f * FRAME_BYTES / 2, so the even sets ARE the
-    // arenas' own T15 -- and runs the tail for both.  A workgroup's last group runs the tail alone when it has no partner.
-    long odd_first = -1;                          // first frame of the odd sets (the parked group), -1: none
-    if constexpr (BATCH) {
-      constexpr int V = U::T15_BYTES / 16;
-      uint4* park = reinterpret_cast<uint4*>(prm.scratch) + (long)blockIdx.x * (F * V);
-      if (parked_first < 0 && grp + gridDim.x < n_groups) {
-        for (int i = tid_t; i < F * V; i += NT) {
-          const int f = i / V, k = i - f * V;
-          park[i] = *reinterpret_cast<const uint4*>(frames + f * FRAME_STRIDE + 16 * k);
-        }
-        parked_first = first;
-        continue;
-      }
-      if (parked_first >= 0) {                  // its T15 is already in the odd sets (LDS-DMA issued before conv2d_23)
-        odd_first = parked_first;
-        parked_first = -1;
-      }
-    }
-    // frame number of tail set f (BATCH: even sets = this group, odd sets = the parked one), -1 = nothing to write
-    auto frame_of = [&](int f) -> long {
-      long id = first + f;
-      if constexpr (BATCH) id = (f & 1) ? (odd_first >= 0 ? odd_first + (f >> 1) : -1) : first + (f >> 1);
-      return id < prm.n ? id : -1;
-    };
-#define YF_DUMP_T(BUF, C, OFF, ...) \
-  if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
-    YF_PRIO(14);
-    YF_FETCH(12, W_t, L_t);
-    {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
-      constexpr int PW = v2::pool25_waves<FT>();
-      static_assert(PW < NW, "waves left for conv2d_27");
-      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30, DUMP>(frames, W_t * 64 + L_t);
-      else v2::dw2_stage<FT, NW - PW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, 11, v2::JobTabs<F, BATCH>::JT_DW27>(frames, tab, W_t - PW, L_t);
-    }
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T30, 24, P25, 24) YF_DUMP_T(typename U::T17, 24, T17)
-    YF_STAGE_END()
-    YF_PRIO(15);
-    YF_FETCH(13, W_t, L_t);
-    YF_DENSE(FT, 1, 2, 16, typename U::T17, typename U::T18, 0, 8, EPI_RAW, 0, typename U::T18, YF_D_C29, no_add, W_t, L_t, 12);   // conv2d_29
-    if constexpr (!BATCH) decode_prev(W_t, L_t);                                                    // previous group's boxes
-    YF_SYNC(); YF_DUMP_T(typename U::T18, 8, T18)
-    YF_STAGE_END()
-    YF_PRIO(16);
-    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW32, tid_t);
-    YF_FETCH(14, W_t, L_t);
-    YF_DENSE(FT, 5, 1, 8, typename U::T18, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY31, typename U::T19, YF_D_C30, no_add, W_t, L_t, 13);  // conv2d_30
-    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T19)
-    YF_STAGE_END()
-    YF_PRIO(17);
-    YF_FETCH(15, W_t, L_t);
-    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY33, YF_W_DW32, W_t, L_t, 14, JT_DW32);    // conv2d_32
-    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T20)
-    YF_STAGE_END()
-    YF_PRIO(18);
-    YF_FETCH(16, W_t, L_t);
-    if constexpr (DUMP)   // debug builds: conv2d_34's own output -> the conv half of concat_46 (written by conv2d_42 only)
-      v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, 15, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD35), W_t, L_t);
-    else
-    YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, YF_D_C34, addctx(YF_A_ADD35), W_t, L_t, 15);   // conv2d_34 + eltwise_35
-    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22) YF_DUMP_T(typename U::T30, 8, C34, 24)
-    YF_STAGE_END()
-    YF_PRIO(19);
-    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
-    YF_FETCH(17, W_t, L_t);
-    YF_DENSE(FT, 5, 1, 8, typename U::T22, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY37, typename U::T19, YF_D_C36, no_add, W_t, L_t, 16);  // conv2d_36
-    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T23)
-    YF_STAGE_END()
-    YF_PRIO(20);
-    YF_FETCH(18, W_t, L_t);
-    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY39, YF_W_DW38, W_t, L_t, 17, JT_DW32);    // conv2d_38
-    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T24)
-    YF_STAGE_END()
-    YF_PRIO(21);
-    YF_FETCH(19, W_t, L_t);
-    if constexpr (DUMP)
-      v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, 18, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD41), W_t, L_t);
-    else
-    YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, YF_D_C40, addctx(YF_A_ADD41), W_t, L_t, 18);   // conv2d_40 + eltwise_41
-    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26) YF_DUMP_T(typename U::T30, 8, C40, 24)
-    YF_STAGE_END()
-    YF_PRIO(22);
-    YF_FETCH(20, W_t, L_t);
-    if constexpr (DUMP)   // debug builds: LEAKY_RELU #43's output (through the debug LUT) -> T20's slot, dead since conv2d_40
-      v2::dense2_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, 19, U::T20::OFF, U::T20::S, DBG_LUT>(frames, out_all, tab, no_add, W_t, L_t);
-    else
-    YF_DENSE(FT, 3, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) YF_DUMP_T(typename U::T20, 24, L43)
-    YF_STAGE_END()
-    YF_PRIO(23);
-    YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW49, tid_t);
-    YF_FETCH(21, W_t, L_t);
-    YF_DENSE(FT, 2, 3, 16, typename U::T30, typename U::T19, 0, 40, EPI_LUT, YF_L_LEAKY48, typename U::T19, YF_D_C47, no_add, W_t, L_t, 20);   // conv2d_47
-    YF_SYNC(); YF_DUMP_T(typename U::T19, 40, T31)
-    YF_STAGE_END()
-    YF_PRIO(24);
-    YF_FETCH(22, W_t, L_t);
-    YF_DW(FT, 1, typename U::T19, typename U::T20, 40, YF_L_LEAKY50, YF_W_DW49, W_t, L_t, 21, JT_DW32);    // conv2d_49
-    YF_SYNC(); YF_DUMP_T(typename U::T20, 40, T32)
-    YF_STAGE_END()
-    YF_PRIO(25);
-    YF_FETCH(23, W_t, L_t);
-    // the decode's two look-up tables (2 KB) -> the first bytes of the frame arenas, dead since conv2d_47 (T15 / T30 of set 0), two stages ahead of
-    // the decode: the barrier behind this stage waits for the transfer, the one behind conv2d_53 would do so on the critical path
-    if (BATCH && prm.dets != nullptr && W_t < 2) {
-      int dl = L_t;
-      asm volatile("" : "+v"(dl));
-      const uint8_t* src = reinterpret_cast<const uint8_t*>(W_t == 0 ? yfdec::d_sig_bits : yfdec::d_exp_bits) + 16 * dl;
-      const uint32_t dst = (uint32_t)(PRE + OUT_ALL_BYTES + 1024 * W_t);
-      uint32_t keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    }
-    YF_DENSE(FT, 2, 3, 16, typename U::T20, typename U::T33, 0, 32, EPI_LUT, YF_L_LEAKY52, typename U::T33, YF_D_C51, no_add, W_t, L_t, 22);   // conv2d_51
-    YF_SYNC(); YF_DUMP_T(typename U::T33, 32, T33)
-    YF_STAGE_END()
-    YF_PRIO(26);
-    if constexpr (!BATCH) {
-      YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::T33, 0, 18, EPI_HEAD, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
-      YF_SYNC();
-      // head: F*882 contiguous bytes -> HBM, 2-byte granules (882 is not a multiple of 4)
-      const long valid = min((long)F, prm.n - first);
-      const int n16 = (int)(valid * (OUT_FRAME_BYTES / 2));
-      uint16_t* dst = reinterpret_cast<uint16_t*>(prm.out + first * OUT_FRAME_BYTES);
-      const uint16_t* srcp = reinterpret_cast<const uint16_t*>(out_all);
-      for (int i = tid; i < n16; i += NT) dst[i] = srcp[i];
-      prev_first = first;
-    } else {
-      YF_DENSE(FT, 1, 2, 16, typename U::T33, typename U::HEAD, 0, 18, EPI_HEAD_LDS, 0, typename U::T33, YF_D_C53, no_add, W_t, L_t, 23);   // conv2d_53
-      YF_SYNC();
-      // heads: 882 bytes per frame from its set -> HBM, 2-byte granules; the boxes of set w are decoded by wave w meanwhile
-      constexpr int H16 = OUT_FRAME_BYTES / 2;
-      // with a decode the first FT waves decode (one frame each) while the other waves copy the heads; without one every wave copies
-      const bool split = prm.dets != nullptr && FT < NW;
-      const int c0 = split ? tid_t - FT * 64 : tid_t, cstep = split ? NT - FT * 64 : NT;
-      if (!split || W_t >= FT) {
-        for (int i = c0; i < FT * H16; i += cstep) {
-          const int f = i / H16, k = i - f * H16;
-          const long id = frame_of(f);
-          if (id >= 0) reinterpret_cast<uint16_t*>(prm.out + id * OUT_FRAME_BYTES)[k] = *reinterpret_cast<const uint16_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF + 2 * k);
-        }
-      }
-      for (int f = W_t; f < FT; f += NW) {
-        const long id = frame_of(f);
-        if (prm.dets != nullptr && id >= 0) {
-          int dl = L_t;
-          asm volatile("" : "+v"(dl));
-          yfdec::decode_frame_lds(reinterpret_cast<const int8_t*>(frames + f * U::HEAD::FS + U::HEAD::OFF), id, dl, prm.mode, prm.w_scale, prm.h_scale, prm.dets, prm.counts, prm.cap,
-                                  (uint32_t)(PRE + OUT_ALL_BYTES), prm.q_thr);
-        }
-      }
-    }
-#undef YF_DUMP_T
-  }
-  if constexpr (!BATCH) {   // boxes of this workgroup's last group
-    const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    decode_prev(wave, lane);
-  }
-#undef YF_HALO
-#undef YF_FETCH
-#undef YF_CONV1
-#undef YF_DENSE
-#undef YF_DW
-#undef YF_DUMP
-#undef YF_STAGE_END
-#undef YF_PRIO
-#undef YF_SYNC
-}
-
-template <int F, int NW, bool DUMP>
-constexpr size_t lds_bytes() { return (size_t)v2::pre_bytes<F, tail_batch<DUMP>()>() + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)FRAME_BYTES + (size_t)(F - 1) * FRAME_STRIDE + (DUMP ? YF_DBG_LUT_BYTES : 0); }
-template <bool DUMP>
-constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
-
+#include "yf_fused56.hip.h"         // the fused 56x56 kernel
 #else   // YF_GENERIC
 #ifdef YF_LAB
-// ------------------------------------------------------------------------------------------------ layer-by-layer form
-// For input sizes whose activations do not fit in LDS (160x160: conv2d_6's output alone is 131 KB) the SAME stage
-// functions run one kernel per fused stage over a per-frame arena in HBM (one workgroup per frame and stage, frames
-// grid-strided).  Results are bit-identical to the oracle at that size; HBM traffic is no longer the algorithmic
-// minimum -- fusing this variant with spatial tiles is later work.
-struct GenParams {
-  const int8_t* in;       // [n][G0][G0][3]
-  int8_t* out;            // [n][G3][G3][18]
-  long n;                 // frames in this launch (<= arena capacity)
-  const uint8_t* tab;
-  char* arena;            // n * FRAME_BYTES bytes of HBM scratch
-};
-constexpr int GEN_STAGES = 27;
-
-template <int ST, int NW>
-__global__ void __launch_bounds__(NW * 64, 2) generic_stage_kernel(const GenParams prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  uint8_t* luts = reinterpret_cast<uint8_t*>(smem);      // addressed absolutely (host-checked: no static LDS)
-  char* out_all = nullptr;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));              // a zero the compiler cannot see through: keeps the pass constants' loads vector loads
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  for (int i = tid; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
-  __syncthreads();
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  for (long fr = blockIdx.x; fr < prm.n; fr += gridDim.x) {
-    char* frames = prm.arena + fr * (long)FRAME_BYTES;
-    out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
-    if constexpr (ST == 0) {
-      stage_input<F, NT>(frames, prm.in, fr, prm.n, (int)uniform_u32(tab + offsetof(yf_table_index, in_zp)), tid);
-      fill_halo<B_T1, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW3), tid);
-    } else if constexpr (ST == 1) {
-      conv1_stage<F, NW>(frames, tab, load_dense(tab, YF_D_CONV1), wave, lane, vz);
-    } else if constexpr (ST == 2) {
-      dw_mfma_stage<F, NW, 1, B_T1, B_T2, 8, YF_L_LEAKY4>(frames, tab, load_dw(tab, YF_W_DW3), wave, lane, vz);
-    } else if constexpr (ST == 3) {
-      dense_stage<F, NW, 1, 1, 8, B_T2, B_T3, 0, 4, EPI_RAW, 0, B_T3>(frames, out_all, tab, load_dense(tab, YF_D_C5), no_add, wave, lane, vz);
-    } else if constexpr (ST == 4) {
-      fill_halo<B_T4, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW10), tid);
-      dense_stage<F, NW, 3, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4>(frames, out_all, tab, load_dense(tab, YF_D_C6), no_add, wave, lane, vz);
-    } else if constexpr (ST == 5) {
-      pool8_h<F, NT>(frames, tid);
-    } else if constexpr (ST == 6) {
-      pool8_v<F, NT>(frames, tid);
-    } else if constexpr (ST == 7) {
-      dw_mfma_stage<F, NW, 2, B_T4, B_T6, 18, YF_L_LEAKY11>(frames, tab, load_dw(tab, YF_W_DW10), wave, lane, vz);
-    } else if constexpr (ST == 8) {
-      dense_stage<F, NW, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C12), no_add, wave, lane, vz);
-    } else if constexpr (ST == 9) {
-      fill_halo<B_T8, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW15), tid);
-      dense_stage<F, NW, 3, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8>(frames, out_all, tab, load_dense(tab, YF_D_C13), no_add, wave, lane, vz);
-    } else if constexpr (ST == 10) {
-      dw_mfma_stage<F, NW, 1, B_T8, B_T9, 36, YF_L_LEAKY16>(frames, tab, load_dw(tab, YF_W_DW15), wave, lane, vz);
-    } else if constexpr (ST == 11) {
-      dense_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7>(frames, out_all, tab, load_dense(tab, YF_D_C17), addctx(YF_A_ADD18), wave, lane, vz);
-    } else if constexpr (ST == 12) {
-      dense_stage<F, NW, 2, 1, 8, B_T11, B_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, B_T14>(frames, out_all, tab, load_dense(tab, YF_D_C19), no_add, wave, lane, vz);
-    } else if constexpr (ST == 13) {
-      fill_halo<B_T15, false, F, NT>(frames, load_halo_zp(tab, YF_W_DW27), tid);
-      dense_stage<F, NW, 2, 3, 16, B_T14, B_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, B_T15>(frames, out_all, tab, load_dense(tab, YF_D_C23), no_add, wave, lane, vz);
-    } else if constexpr (ST == 14) {
-      pool25<F, NT>(frames, tid);
-      dw_mfma_stage<F, NW, 2, B_T15, B_T17, 24, YF_L_LEAKY28>(frames, tab, load_dw(tab, YF_W_DW27), wave, lane, vz);
-    } else if constexpr (ST == 15) {
-      dense_stage<F, NW, 1, 2, 16, B_T17, B_T18, 0, 8, EPI_RAW, 0, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C29), no_add, wave, lane, vz);
-    } else if constexpr (ST == 16) {
-      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
-      dense_stage<F, NW, 3, 1, 8, B_T18, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C30), no_add, wave, lane, vz);
-    } else if constexpr (ST == 17) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY33>(frames, tab, load_dw(tab, YF_W_DW32), wave, lane, vz);
-    } else if constexpr (ST == 18) {
-      dense_stage<F, NW, 1, 3, 16, B_T20, B_T22, 0, 8, EPI_ADD, YF_A_ADD35, B_T18>(frames, out_all, tab, load_dense(tab, YF_D_C34), addctx(YF_A_ADD35), wave, lane, vz);
-    } else if constexpr (ST == 19) {
-      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
-      dense_stage<F, NW, 3, 1, 8, B_T22, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C36), no_add, wave, lane, vz);
-    } else if constexpr (ST == 20) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY39>(frames, tab, load_dw(tab, YF_W_DW38), wave, lane, vz);
-    } else if constexpr (ST == 21) {
-      dense_stage<F, NW, 1, 3, 16, B_T20, B_T26, 0, 8, EPI_ADD, YF_A_ADD41, B_T22>(frames, out_all, tab, load_dense(tab, YF_D_C40), addctx(YF_A_ADD41), wave, lane, vz);
-    } else if constexpr (ST == 22) {
-      dense_stage<F, NW, 2, 1, 8, B_T26, B_T30, 24, 24, EPI_LUT, YF_L_L43Q44, B_T30>(frames, out_all, tab, load_dense(tab, YF_D_C42), no_add, wave, lane, vz);
-    } else if constexpr (ST == 23) {
-      fill_halo<B_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
-      dense_stage<F, NW, 2, 3, 16, B_T30, B_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, B_T19>(frames, out_all, tab, load_dense(tab, YF_D_C47), no_add, wave, lane, vz);
-    } else if constexpr (ST == 24) {
-      dw_mfma_stage<F, NW, 1, B_T19, B_T20, 40, YF_L_LEAKY50>(frames, tab, load_dw(tab, YF_W_DW49), wave, lane, vz);
-    } else if constexpr (ST == 25) {
-      dense_stage<F, NW, 2, 3, 16, B_T20, B_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C51), no_add, wave, lane, vz);
-    } else {
-      static_assert(ST == 26, "stage index");
-      dense_stage<F, NW, 1, 2, 16, B_T33, B_T33, 0, 18, EPI_HEAD, 0, B_T33>(frames, out_all, tab, load_dense(tab, YF_D_C53), no_add, wave, lane, vz);
-    }
-  }
-}
-
-#endif   // YF_LAB
-
-// ------------------------------------------------------------------------------------------------ banded form
-// Second form for sizes that do not fit in LDS (160x160): FOUR kernels, each fusing a group of stages over a BAND of rows of
-// one frame.  A workgroup copies the band of its input tensor (with the halo rows the group needs) from the per-frame HBM
-// arena into LDS with coalesced loads, runs the SAME stage functions as the 56x56 kernel on band-local buffers, and writes
-// the band of its output tensor back.  Only five tensors cross HBM (T4, the pooled half of concat_22, T7, T8, T15):
-// ~0.78 MB per frame instead of 1.7 MB, all of it in full-row transfers.
-//   K1  input rows -> conv2d_1 -> conv2d_3 (dw) -> conv2d_5 -> conv2d_6 -> T4            band = 8 rows of the 80x80 grid
-//   K2  T4 -> pool_8 (+QUANTIZE) -> P8 ; conv2d_10 (dw) -> conv2d_12 -> T7 -> conv2d_13 -> T8     band = 4 rows of 40x40
-//   K3  T8 -> conv2d_15 (dw) -> conv2d_17 + add(T7) -> conv2d_19 | P8 -> conv2d_23 -> T15         band = 8 rows of 40x40
-//   K4  T15 -> pool_25, conv2d_27 (dw) ... conv2d_53 -> head                                       whole 20x20 grid
-// Halo rules: a band's input copy spans whole halo'd rows of the global tensor, so image borders bring their zero-point
-// halo with them and interior band edges bring real neighbour rows; the producer fills halo columns (and the first / last
-// band the top / bottom halo row) before the copy-out.
-namespace band {
-#define YF_BAND_PRIO(P) __builtin_amdgcn_s_setprio(P)      // priority ladder over a band job's stages (see the 56x56 kernel)
-constexpr int LB = LUT_BYTES;                                   // LUTs at LDS offset 0 (absolute addressing)
-// per-frame HBM arena of the banded form (bytes); rows are padded to multiples of 16 bytes so bands move as 16-byte vectors
-constexpr int T4_RS = G1 + 4, T8_RS = G2 + 4, T15_RS = G2 + 2;   // pixels per halo'd row
-constexpr int T4_ROW = T4_RS * 20, T8_ROW = T8_RS * 36, T15_ROW = T15_RS * 24;
-static_assert(T4_ROW % 16 == 0 && T8_ROW % 16 == 0 && T15_ROW % 16 == 0 && (G2 * 20) % 16 == 0 && (G2 * 8) % 16 == 0, "16-byte rows");
-constexpr int A_T4 = 0;                                          // [G1 + 1 halo'd rows][T4_RS][20]    top/left halo
-constexpr int A_P8 = (A_T4 + (G1 + 1) * T4_ROW + 63) & ~63;      // [G2][G2][20]                       pool_8 + QUANTIZE#21
-constexpr int A_T7 = (A_P8 + G2 * G2 * 20 + 63) & ~63;           // [G2][G2][8]
-constexpr int A_T8 = (A_T7 + G2 * G2 * 8 + 63) & ~63;            // [G2 + 2][T8_RS][36]                halo ring
-constexpr int A_T15 = (A_T8 + (G2 + 2) * T8_ROW + 63) & ~63;     // [G2 + 1][T15_RS][24]               top/left halo
-constexpr int ARENA_BYTES = (A_T15 + (G2 + 1) * T15_ROW + 63) & ~63;
-
-struct Params { const int8_t* in; int8_t* out; long n; const uint8_t* tab; char* arena; };
-
-// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding global access (vmcnt(0)):
-// that would drain the next band's prefetch loads and this band's copy-out stores at every stage boundary.  Nothing a
-// band kernel writes to HBM is read back by the same kernel, so LDS ordering is all the stages need.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// N bytes LDS -> HBM as 16-byte vectors (both 16-byte aligned, N a multiple of 16)
-template <int NT>
-__device__ __forceinline__ void store_rows(char* dst, const char* src, int bytes, int tid) {
-  for (int i = tid; i < bytes / 16; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
-}
-template <int NT>
-__device__ __forceinline__ void fill_dwords(char* dst, uint32_t v, int bytes, int tid) {
-  for (int i = tid; i < bytes / 4; i += NT) reinterpret_cast<uint32_t*>(dst)[i] = v;
-}
-// column `col` (pixel units) of `rows` rows of a buffer with ROW bytes per row and S bytes per pixel <- v
-template <int NT, int ROW, int S>
-__device__ __forceinline__ void fill_column(char* base, int col, int rows, uint32_t v, int tid) {
-  constexpr int DW = S / 4;
-  for (int i = tid; i < rows * DW; i += NT) {
-    const int r = i / DW, d = i - r * DW;
-    *reinterpret_cast<uint32_t*>(base + r * ROW + col * S + 4 * d) = v;
-  }
-}
-__device__ __forceinline__ uint32_t splat(int zp) { return (uint32_t)(zp & 255) * 0x01010101u; }
-
-template <int NT>
-__device__ __forceinline__ void load_luts(uint8_t* luts, const uint8_t* __restrict__ tab, int tid) {
-  for (int i = tid; i < LUT_BYTES / 16; i += NT)
-    reinterpret_cast<uint4*>(luts)[i] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off)[i];
-}
-
-// A band's input, prefetched: CNT 16-byte vectors of a contiguous HBM range, vector i owned by thread i % NT.  fetch() issues
-// the loads for the NEXT job right after the current job's data has been committed to LDS; nothing waits for them until
-// the commit at the top of the next iteration, so the HBM latency hides behind the whole band's compute.
-template <int NT, int CNT>
-struct Prefetch {
-  static constexpr int PER = (CNT + NT - 1) / NT;
-  v4u v[PER];                                   // native vectors: HIP's uint4 class keeps the array in scratch
-};
-template <int NT, int CNT>
-__device__ __forceinline__ void pf_fetch(Prefetch<NT, CNT>& p, const char* src, int n16, int tid) {      // n16 <= CNT vectors
-#pragma unroll
-  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) p.v[k] = reinterpret_cast<const v4u*>(src)[min(tid + k * NT, n16 - 1)];
-}
-template <int NT, int CNT>
-__device__ __forceinline__ void pf_commit(const Prefetch<NT, CNT>& p, char* dst, int n16, int tid) {
-#pragma unroll
-  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) { const int i = tid + k * NT; if (i < n16) reinterpret_cast<v4u*>(dst)[i] = p.v[k]; }
-}
-// the same into rows of PITCH bytes in LDS (ROWVEC 16-byte vectors per row in HBM): a pitch that is not a multiple of 16 bytes (a row skew
-// against bank conflicts) takes dword stores
-template <int ROWVEC, int PITCH, int NT, int CNT>
-__device__ __forceinline__ void pf_commit_rows(const Prefetch<NT, CNT>& p, char* dst, int n16, int tid) {
-#pragma unroll
-  for (int k = 0; k < Prefetch<NT, CNT>::PER; ++k) {
-    const int i = tid + k * NT;
-    if (i < n16) {
-      const int r = (int)((uint32_t)i / (uint32_t)ROWVEC), c = i - r * ROWVEC;
-      uint32_t* d = reinterpret_cast<uint32_t*>(dst + r * PITCH + 16 * c);
-      if constexpr (PITCH % 16 == 0) *reinterpret_cast<v4u*>(d) = p.v[k];
-      else { d[0] = p.v[k][0]; d[1] = p.v[k][1]; d[2] = p.v[k][2]; d[3] = p.v[k][3]; }
-    }
-  }
-}
-
-// ---- lean stage forms in the band kernels (round 3) -----------------------------------------------------------------------
-// band_k1 and band_k23 use the 56x56 kernel's lean stage forms (namespace v2) with their constants RESIDENT: a workgroup runs many band
-// jobs with the same few stages, so the vector-side blocks of those stages (1.4 KB for band_k1, 8 KB for band_k23) are loaded once per
-// workgroup -- into bytes of the LUT / residual-add-table area [0, LB) that the kernel's own stages never index -- instead of fetched from
-// global memory behind every stage boundary of every job (1.5-2.5 k cycles each; the band jobs ran at half the 56x56 kernel's per-pixel rate).
-template <int CS0, int CS1, int BASE_, int ZERO_, int JT_, int JT_BYTES_>
-struct BandLay {
-  static constexpr int ZERO = ZERO_, JT = JT_, JT_BYTES = JT_BYTES_, FIRST = CS0, LAST = CS1, BASE = BASE_;
-  static constexpr int slot(int cs) { int off = BASE_; for (int i = CS0; i < cs; ++i) off += PLAN.vb_bytes[i]; return off; }
-  static constexpr int END = slot(CS1 + 1);
-};
-// after load_luts: zeros, then the blocks of const-stages FIRST .. LAST at their slots (16-byte vectors, every thread)
-template <class LAY, int NT>
-__device__ __forceinline__ void load_resident(char* smem, const uint8_t* __restrict__ tab, int tid) {
-  for (int i = tid; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + LAY::ZERO)[i] = uint4{0, 0, 0, 0};
-#pragma unroll
-  for (int cs = LAY::FIRST; cs <= LAY::LAST; ++cs)
-    for (int i = tid; i < PLAN.vb_bytes[cs] / 16; i += NT)
-      reinterpret_cast<uint4*>(smem + LAY::slot(cs))[i] = reinterpret_cast<const uint4*>(tab + PLAN.vb_off[cs])[i];
-}
-// band_k1 indexes LUTs 0-2 only ([0, 768)): blocks of conv2d_1 / 3 / 5 / 6 behind them, job table and zeros at the end of the area
-typedef BandLay<0, 3, 768, LB - v2::ZERO_B, LB - v2::ZERO_B - 768, 768> LayK1;
-// band_k23 indexes LUTs 3-8 ([768, 2304)) and no add table of the area (conv2d_17's block brings its own): zeros and job tables on
-// LUTs 0-2, the seven blocks of conv2d_10 .. conv2d_23 from 2304 on
-typedef BandLay<4, 10, 2304, 0, v2::ZERO_B, 768 - v2::ZERO_B> LayK23;
-static_assert(LayK1::END <= LayK1::JT && LayK1::ZERO + v2::ZERO_B <= LB && LayK23::END <= LB && v2::ZERO_B + LayK23::JT_BYTES <= 768, "resident constants fit the unused LUT / add-table bytes");
-
-#ifndef YF_BAND_TPJ
-#define YF_BAND_TPJ 1          /* 1: five passes per job for conv2d_6 in band_k1 (10 jobs per band instead of 20: -2.5 % of that kernel; the same in band_k23 spills or loses) */
+#include "yf_lab_layerwise.hip.h"   // layer-by-layer 160x160 form (laboratory build only)
 #endif
-// ---- K1 ----------------------------------------------------------------------------------------------------------------
-#ifndef YF_K1_BH
-#define YF_K1_BH 16
-#endif
-#ifndef YF_K1_OCC
-#define YF_K1_OCC 4
-#endif
-constexpr int K1_BH = YF_K1_BH, K1_BANDS = G1 / K1_BH, K1_NIN = 2 * K1_BH + 5, K1_NT1 = K1_BH + 2;
-static_assert(G1 % K1_BH == 0, "band height must divide the grid");
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-#ifndef YF_BAND_SKEW
-#define YF_BAND_SKEW 4              /* bytes of row skew in the band kernels' depthwise inputs with 8- / 40-byte pixels (see Buf::SK) */
-#endif
-constexpr int K1_T1_ROW = (G1 + 2) * 8 + YF_BAND_SKEW;
-constexpr int K1_IN_BYTES = K1_NIN * (G0 + 4) * 4, K1_T1_BYTES = (K1_NT1 * K1_T1_ROW + 15) & ~15;
-constexpr int K1_R0 = cmax(K1_IN_BYTES + K1_T1_BYTES, K1_BH * T4_ROW);                       // IN + T1, later T4
-typedef Buf<LB,                                  G0, K1_NIN - 1, 4, G0 + 4, 1, 4> L1_IN;    // RGBX rows: local row l = global halo'd row 2(a-1)+l
-typedef Buf<L1_IN::OFF + K1_IN_BYTES,            G1, K1_NT1,     8, G1 + 2, 0, 1, BUF_FS, YF_BAND_SKEW> L1_T1;    // local row t = T1 row a-1+t, halo columns 0 and G1+1
-typedef Buf<LB + K1_R0,                          G1, K1_BH,      8, G1,     0, 0> L1_T2;
-typedef Buf<L1_T2::OFF + K1_BH * G1 * 8,         G1, K1_BH,      4, G1,     0, 0> L1_T3;
-typedef Buf<LB,                                  G1, K1_BH,     20, T4_RS,  0, 1> L1_T4;    // left halo column; aliases IN and T1 (dead after conv2d_3)
-constexpr int K1_LDS = L1_T3::OFF + K1_BH * G1 * 4;
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  constexpr int RSW = G0 + 4, WQ = G0 / 4, ITEMS = K1_NIN * WQ, PER = (ITEMS + NT - 1) / NT;     // item = 4 pixels = 12 input bytes
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  __syncthreads();                                                // the LUT area is written; its unused bytes now take the resident pieces
-  load_resident<LayK1, NT>(smem, tab, tid);
-  v2::fill_jobtab<1, 1, L1_T1, L1_T2, 0, LayK1>(smem, tid);
-  const AddK no_add = {};
-  const uint32_t z_in = splat((int)uniform_u32(tab + offsetof(yf_table_index, in_zp)));
-  const uint32_t z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
-  char* frames = smem;                                            // band-local buffers live at their LDS offsets
-  const long jobs = prm.n * K1_BANDS;
-  uint32_t pre[PER][3];
-  // input rows of a band: local row l <-> input row 2(a-1)+l-1, out of range = zero point
-  auto fetch = [&](long job) {
-    const long fr = job / K1_BANDS;
-    const int a = (int)(job - fr * K1_BANDS) * K1_BH;
-    const int8_t* in = prm.in + fr * (long)IN_FRAME_BYTES;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + k * NT;
-      const int l = i / WQ, xq = i - l * WQ;
-      const int r = 2 * (a - 1) + l - 1;
-      pre[k][0] = pre[k][1] = pre[k][2] = z_in;
-      if (i < ITEMS && r >= 0 && r < G0) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(in + r * (G0 * 3) + xq * 12);
-        pre[k][0] = src[0]; pre[k][1] = src[1]; pre[k][2] = src[2];
-      }
-    }
-  };
-  long job = blockIdx.x;
-  if (job < jobs) fetch(job);
-  for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K1_BANDS;
-    const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
-    char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    YF_BAND_PRIO(3);
-    lds_barrier();                                                // previous band's buffers are dead
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {                               // RGB -> RGBX dwords behind the halo column
-      const int i = tid + k * NT;
-      if (i < ITEMS) {
-        const int l = i / WQ, xq = i - l * WQ;
-        uint4 px;
-        px.x = pre[k][0]; px.y = funnel(pre[k][1], pre[k][0], 24); px.z = funnel(pre[k][2], pre[k][1], 16); px.w = pre[k][2] >> 8;
-        *reinterpret_cast<uint4*>(frames + L1_IN::OFF + l * RSW * 4 + 16 + 16 * xq) = px;
-      }
-    }
-    if (tid < K1_NIN) *reinterpret_cast<uint32_t*>(frames + L1_IN::OFF + tid * RSW * 4 + 12) = z_in;        // halo column (dword 3)
-    lds_barrier();
-    if (job + gridDim.x < jobs) fetch(job + gridDim.x);
-    v2::conv1_2_stage<F, NW, 0, L1_IN, L1_T1, LayK1>(frames, tab, wave, lane);
-    fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, 0, K1_NT1, z_t1, tid);
-    fill_column<NT, K1_T1_ROW, 8>(frames + L1_T1::OFF, G1 + 1, K1_NT1, z_t1, tid);
-    lds_barrier();
-    if (a == 0) fill_dwords<NT>(frames + L1_T1::OFF, z_t1, (G1 + 2) * 8, tid);                               // T1 row -1 = halo
-    if (a + K1_BH == G1) fill_dwords<NT>(frames + L1_T1::OFF + (K1_NT1 - 1) * K1_T1_ROW, z_t1, (G1 + 2) * 8, tid);   // T1 row G1
-    if (a == 0 || a + K1_BH == G1) lds_barrier();
-    YF_BAND_PRIO(2);
-    v2::dw2_stage<F, NW, 1, L1_T1, L1_T2, 8, YF_L_LEAKY4, 1, 0, LayK1>(frames, tab, wave, lane);
-    lds_barrier();
-    YF_BAND_PRIO(1);
-    v2::dense2_stage<F, NW, 1, 1, 8, L1_T2, L1_T3, 0, 4, EPI_RAW, 0, L1_T3, 2, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
-    lds_barrier();
-    v2::dense2_stage<F, NW, YF_BAND_TPJ ? 5 : 3, 1, 4, L1_T3, L1_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, L1_T4, 3, -1, 0, -1, LayK1>(frames, nullptr, tab, no_add, wave, lane);
-    fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    store_rows<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);              // halo'd rows a+1 ..
-    if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
-  }
-}
-
-// ---- K23: K2 and K3 fused (round 3) ------------------------------------------------------------------------------------
-// One band job = 8 rows of the 40x40 grid through pool_8 .. conv2d_23: T4 rows in, T15 rows out; the pooled half of concat_22, T7 and T8
-// never leave the chip (three tensors cross HBM instead of five: 0.73 -> 0.49 MB per frame).  conv2d_15's 3x3 window needs T8 rows
-// p0-1 .. p0+8, so conv2d_10 / 12 / 13 run on TEN rows per band (the T4 rows they need, 2p0-3 .. 2p0+17, are inside the 22 rows the
-// pool already loads); rows outside the image are computed from whatever the LDS holds and then overwritten with the halo.
-// LDS: [LUTs][T4 22 rows -> T8 10 rows | T9][HB 22 rows -> T6 10 rows | T7 10 rows -> T11 | T15][T14 8 rows] = 79 KB, two per CU.
-constexpr int K23_BP = 8, K23_BANDS = G2 / K23_BP, K23_NR = 2 * K23_BP + 6, K23_NM = K23_BP + 2;      // pooled rows, T4 rows, T6/T7/T8 rows
-static_assert(G2 % K23_BP == 0 && K23_BP % 4 == 0, "band height must divide the grid; the vertical pool pass sweeps 4 rows");
-constexpr int K23_RA = LB, K23_RA_BYTES = K23_NR * T4_ROW;                                  // region A: T4, later T8 | T9
-constexpr int K23_RH = K23_RA + K23_RA_BYTES, K23_RH_BYTES = K23_NR * G2 * 20;               // region H: HB, later T6 | T7, later T11 | T15
-constexpr int K23_R14 = K23_RH + K23_RH_BYTES;                                              // concat_22 rows of the band
-typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4;       // local row l = T4 row 2p0-3+l
-typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4_DW;    // conv2d_10's view: output row t (T6 row p0-1+t) reads local rows 2t .. 2t+2
-typedef Buf<K23_RH,                              G2, K23_NR, 20, G2,     0, 0> L23_HB;
-typedef Buf<K23_RH,                              G2, K23_NM, 32, G2,     0, 0> L23_T6;       // aliases HB (dead after the vertical pool pass)
-typedef Buf<K23_RH + K23_NM * G2 * 32,           G2, K23_NM,  8, G2,     0, 0> L23_T7;       // rows p0-1 .. p0+8
-typedef Buf<L23_T7::OFF + G2 * 8,                G2, K23_BP,  8, G2,     0, 0> L23_T7C;      // rows p0 .. p0+7: the residual input of eltwise_18
-// T8's 1584-byte rows put the second row of a 32-lane tap read 12 banks behind the first (4 of 16 lanes collide); 16 bytes of skew make it 16
-#ifndef YF_K23_T8_SKEW
-#define YF_K23_T8_SKEW 16
-#endif
-constexpr int K23_T8_ROW = T8_ROW + YF_K23_T8_SKEW;
-typedef Buf<K23_RA,                              G2, K23_NM, 36, T8_RS,  0, 1, BUF_FS, YF_K23_T8_SKEW> L23_T8;       // aliases T4 (dead after conv2d_10); halo'd rows p0 .. p0+9
-typedef Buf<K23_RA + K23_NM * K23_T8_ROW,        G2, K23_BP, 48, G2,     0, 0> L23_T9;
-typedef Buf<K23_RH,                              G2, K23_BP,  8, G2,     0, 0> L23_T11;      // aliases T6 (dead after conv2d_12)
-typedef Buf<K23_R14,                             G2, K23_BP, 48, G2,     0, 0> L23_T14;
-typedef Buf<K23_RH + K23_BP * G2 * 8,            G2, K23_BP, 24, T15_RS, 0, 1> L23_T15;      // behind T11, on T6's old bytes
-constexpr int K23_LDS = K23_R14 + K23_BP * G2 * 48;
-static_assert(K23_NM * G2 * 32 + K23_NM * G2 * 8 <= K23_RH_BYTES && K23_NM * K23_T8_ROW + K23_BP * G2 * 48 <= K23_RA_BYTES, "aliases fit");
-static_assert(K23_BP * G2 * 8 + K23_BP * T15_ROW <= K23_NM * G2 * 32, "T11 | T15 fit T6's bytes (T7 behind them stays alive until conv2d_17)");
-static_assert(K23_LDS <= 81920 && K23_RA % 16 == 0 && K23_RH % 16 == 0 && K23_R14 % 16 == 0 && L23_T9::OFF % 16 == 0 && L23_T15::OFF % 16 == 0, "two workgroups per CU, aligned buffers");
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  int vz = 0;
-  asm volatile("" : "+v"(vz));
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  const uint32_t z_t8 = splat(load_halo_zp(tab, YF_W_DW15)), z_t15 = splat(load_halo_zp(tab, YF_W_DW27));
-  constexpr int JT_DW10 = 0, JT_DW15 = 8 * v2::DwGeo<1, 2, L23_T4_DW, L23_T6>::JPG;
-  __syncthreads();
-  load_resident<LayK23, NT>(smem, tab, tid);
-  v2::fill_jobtab<1, 2, L23_T4_DW, L23_T6, JT_DW10, LayK23>(smem, tid);
-  v2::fill_jobtab<1, 1, L23_T8, L23_T9, JT_DW15, LayK23>(smem, tid);
-  char* frames = smem;
-  const long jobs = prm.n * K23_BANDS;
-  Prefetch<NT, K23_NR * T4_ROW / 16> pre;
-  // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
-  auto range = [&](long job, const char*& src, int& lo_local, int& n16) {
-    const long fr = job / K23_BANDS;
-    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;
-    const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K23_NR, G1 + 1);
-    src = prm.arena + fr * (long)ARENA_BYTES + A_T4 + lo * T4_ROW;
-    lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
-  };
-  long job = blockIdx.x;
-  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
-  for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K23_BANDS;
-    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;           // first 40x40 row of the band
-    char* arena = prm.arena + fr * (long)ARENA_BYTES;
-    lds_barrier();
-    YF_BAND_PRIO(3);
-    { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L23_T4::OFF + ll * T4_ROW, n16, tid); }
-    lds_barrier();
-    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
-    {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
-      constexpr int NO = 5, NCH = G2 / NO;
-      static_assert(G2 % NO == 0, "sweeps of 5 outputs");
-      for (int i = tid; i < K23_NR * NCH * 5; i += NT) {
-        const int cg = i % 5; int t = i / 5;
-        const int k = t % NCH; const int l = t / NCH;
-        const char* row = frames + L23_T4::OFF + l * T4_ROW + 20 + 4 * cg;                // pixel 0 sits behind the halo column
-        char* dst = frames + L23_HB::OFF + l * (G2 * 20) + 4 * cg;
-        pool8_sweep<NO, G1 - 1>(k * NO, [&](int x) { return lds_u32(row + x * 20); },
-                                [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
-      }
-    }
-    lds_barrier();
-    {   // vertical pass + QUANTIZE#21 straight into the pooled half of the band's concat_22 rows
-      constexpr int NO = 4, NSW = K23_BP / NO;
-      for (int i = tid; i < NSW * G2 * 5; i += NT) {
-        const int cg = i % 5; int t = i / 5;
-        const int ox = t % G2; const int sw = t / G2;
-        const char* col = frames + L23_HB::OFF + ox * 20 + 4 * cg;
-        char* dst = frames + L23_T14::OFF + ox * 48 + 4 * cg;
-        pool8_sweep<NO, G1 - 1>(p0 + sw * NO, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
-                                [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 48)) = lut4_raw<YF_L_Q21>(v); });
-      }
-    }
-    lds_barrier();                                                 // T6 (written next) aliases HB
-    YF_BAND_PRIO(2);
-    v2::dw2_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11, 4, JT_DW10, LayK23>(frames, tab, wave, lane);               // ten rows
-    lds_barrier();
-    v2::dense2_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7, 5, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-    lds_barrier();
-    v2::dense2_stage<F, NW, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8, 6, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
-    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
-    lds_barrier();
-    if (p0 == 0) fill_dwords<NT>(frames + L23_T8::OFF, z_t8, T8_ROW, tid);                                       // T8 row -1 = halo
-    if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * K23_T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
-    if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
-    YF_BAND_PRIO(1);
-    v2::dw2_stage<F, NW, 1, L23_T8, L23_T9, 36, YF_L_LEAKY16, 7, JT_DW15, LayK23>(frames, tab, wave, lane);
-    lds_barrier();
-    v2::dense2_stage<F, NW, 1, 3, 16, L23_T9, L23_T11, 0, 6, EPI_ADD, YF_A_ADD18, L23_T7C, 8, -1, 0, -1, LayK23>(frames, nullptr, tab, addctx(YF_A_ADD18), wave, lane);
-    lds_barrier();
-    v2::dense2_stage<F, NW, 2, 1, 8, L23_T11, L23_T14, YF_T14_CONV_BASE, 18, EPI_LUT, YF_L_LEAKY20, L23_T14, 9, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-    lds_barrier();
-    YF_BAND_PRIO(0);
-    v2::dense2_stage<F, NW, 2, 3, 16, L23_T14, L23_T15, 0, 24, EPI_LUT, YF_L_LEAKY24, L23_T15, 10, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
-    fill_column<NT, T15_ROW, 24>(frames + L23_T15::OFF, 0, K23_BP, z_t15, tid);
-    lds_barrier();
-    store_rows<NT>(arena + A_T15 + (p0 + 1) * T15_ROW, frames + L23_T15::OFF, K23_BP * T15_ROW, tid);
-    if (p0 == 0) fill_dwords<NT>(arena + A_T15, z_t15, T15_ROW, tid);
-  }
-}
-
-// ---- K4: the 20x20 tail ------------------------------------------------------------------------------------------------
-// Two 8-wave workgroups per CU (78 KB each) instead of one 16-wave workgroup with the whole T15 (41 KB) in LDS: the tail's
-// stages are latency chains with few jobs, so two independent frames per CU with twice the jobs per wave are faster, and two
-// workgroups in different phases profit from the priority ladder.  T15 is consumed in two halves of rows (pool_25 and
-// conv2d_27 for output rows 0-9, then 10-19) through the slot that later holds T19 and the small tensors; T17 sits on T20's
-// slot (dead before conv2d_32 writes it), T33 on T19's.
-constexpr int K4_HALF = G3 / 2, K4_ROWS0 = 2 * K4_HALF + 2, K4_ROWS1 = (G2 + 1) - 2 * K4_HALF;      // T15 halo'd rows of the halves
-static_assert(G3 % 2 == 0 && K4_HALF >= 4 && K4_ROWS1 <= K4_ROWS0, "two halves of output rows");
-constexpr int K4_T19_BYTES = ((G3 + 2) * ((G3 + 2) * 40 + YF_BAND_SKEW) + 15) & ~15;
-constexpr int K4_R1 = K4_T19_BYTES + 3 * G3 * G3 * 8;                                     // T19 | T18 | T22 | T26
-// T15's rows are 1008 bytes in HBM (16-byte rows for the band copies) = 252 dwords: conv2d_27's stride-2 tap reads (lanes 12 dwords apart, tile rows
-// 504 apart) put all 64 lanes on the eight banks 4k -- the probe's worst pattern.  In LDS the rows are one dword longer (pf_commit_rows): tile rows land on
-// different bank classes, two lanes per bank instead of eight.
-#ifndef YF_K4_T15_SKEW
-#define YF_K4_T15_SKEW 4
-#endif
-constexpr int K4_T15_PITCH = T15_ROW + YF_K4_T15_SKEW;
-static_assert(K4_ROWS0 * K4_T15_PITCH <= K4_R1, "a T15 half fits the slot of T19 and the small tensors");
-typedef Buf<LB,                                   G2, K4_ROWS0,   24, T15_RS, 0, 1, BUF_FS, YF_K4_T15_SKEW> L4_T15H;  // halo'd rows of one half (halo'd row 0 at OFF)
-typedef Buf<LB,                                   G3, G3, 40, G3 + 2, 1, 1, BUF_FS, YF_BAND_SKEW> L4_T19;
-typedef Buf<LB + K4_T19_BYTES,                    G3, G3,  8, G3,     0, 0> L4_T18;
-typedef Buf<L4_T18::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T22;
-typedef Buf<L4_T22::OFF + G3 * G3 * 8,            G3, G3,  8, G3,     0, 0> L4_T26;
-typedef Buf<LB + K4_R1,                           G3, G3, 48, G3,     0, 0> L4_T20;
-typedef Buf<L4_T20::OFF,                          G3, G3, 32, G3,     0, 0> L4_T17;   // aliases T20
-typedef Buf<L4_T20::OFF,                          G3, K4_HALF, 32, G3, 0, 0> L4_T17A; // rows 0 .. HALF-1 (conv2d_27 writes one half at a time)
-typedef Buf<L4_T20::OFF + K4_HALF * G3 * 32,      G3, K4_HALF, 32, G3, 0, 0> L4_T17B; // rows HALF .. G3-1
-typedef Buf<L4_T20::OFF + G3 * G3 * 48,           G3, G3, 48, G3,     0, 0> L4_T30;
-typedef Buf<LB,                                   G3, G3, 32, G3,     0, 0> L4_T33;   // aliases T19 (dead after conv2d_49)
-constexpr int K4_BUFS_END = L4_T30::OFF + G3 * G3 * 48;
-// lean stage forms in band_k4 (round 3): a frame's thirteen stages need 19 KB of constants -- not resident, but through TWO RING SLOTS in
-// LUT-area bytes the tail never indexes: even const-stages (largest: conv2d_47, 2240 B) on LUTs 0-8 [0, 2304), odd ones (largest: a
-// depthwise conv, 1760 B) on eltwise_18's add tables [4864, 6912).  conv2d_34 / 40 read their add tables from the resident area instead of
-// from their blocks (which would not fit).  Zeros and the three depthwise job tables sit behind the buffers.
-struct LayK4 {
-  static constexpr int ZERO = K4_BUFS_END, JT = K4_BUFS_END + v2::ZERO_B, JT_BYTES = 256;
-  static constexpr int slot(int cs) { return (cs & 1) ? YF_N_LUT * 256 : 0; }
-};
-constexpr bool k4_ring_ok() {
-  for (int cs = 11; cs <= 23; ++cs) {
-    const int b = PLAN.vb_bytes[cs] - (yf_cs_add[cs] >= 0 ? 2048 : 0);
-    if (b > ((cs & 1) ? 2048 : 2304)) return false;
-  }
-  return true;
-}
-static_assert(k4_ring_ok(), "every tail block (without its add tables) fits its ring slot");
-constexpr int K4_LDS = K4_BUFS_END + v2::ZERO_B + LayK4::JT_BYTES;
-static_assert(K4_LDS <= 81920, "two workgroups per CU");
-
-// pool_25 for output rows [oy0, oy0 + K4_HALF) from a T15 half whose first halo'd row is h0
-template <int NT>
-YF_STAGE_FN void pool25_half(char* frames, int oy0, int h0, int tid) {
-  constexpr int OW = G3, LIM = G2 - 1;
-  for (int i = tid; i < K4_HALF * OW * 6; i += NT) {
-    const int cg = i % 6; const int p = i / 6;
-    const int oy = oy0 + p / OW, ox = p % OW;
-    SplitB m;
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx)
-        m = m.mx(SplitB(lds_u32(frames + L4_T15H::OFF + (clampi(2 * oy - 1 + ky, 0, LIM) + 1 - h0) * K4_T15_PITCH + (clampi(2 * ox - 1 + kx, 0, LIM) + 1) * 24 + 4 * cg)));
-    *reinterpret_cast<uint32_t*>(frames + L4_T30::at(oy, ox) + 4 * cg) = lut4_raw<YF_L_Q45>(m);
-  }
-}
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 4) band_k4(const Params prm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64, F = 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint8_t* __restrict__ tab = prm.tab;
-  load_luts<NT>(reinterpret_cast<uint8_t*>(smem), tab, tid);
-  const AddK no_add = {};
-  auto addctx = [&](int k) {
-    const uint8_t* a = tab + offsetof(yf_table_index, add) + k * sizeof(yf_add);
-    return AddK{uniform_u32(a + offsetof(yf_add, mo2)), uniform_u32(a + offsetof(yf_add, zro)),
-                (unsigned long)uniform_u32(a + offsetof(yf_add, c64o)) | ((unsigned long)uniform_u32(a + offsetof(yf_add, c64o) + 4) << 32),
-                (int)uniform_u32(a + offsetof(yf_add, rso))};
-  };
-  // zeros and the depthwise job tables behind the buffers (the ring slots themselves are filled per stage)
-  constexpr int JT_A = 0, JT_B = JT_A + 8 * v2::DwGeo<1, 2, L4_T15H, L4_T17A>::JPG, JT_32 = JT_B + 8 * v2::DwGeo<1, 2, L4_T15H, L4_T17B>::JPG;
-  static_assert(JT_32 + 8 * v2::DwGeo<1, 1, L4_T19, L4_T20>::JPG <= LayK4::JT_BYTES, "job tables fit");
-  for (int i = tid; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + LayK4::ZERO)[i] = uint4{0, 0, 0, 0};
-  v2::fill_jobtab<1, 2, L4_T15H, L4_T17A, JT_A, LayK4>(smem, tid);
-  v2::fill_jobtab<1, 2, L4_T15H, L4_T17B, JT_B, LayK4>(smem, tid);
-  v2::fill_jobtab<1, 1, L4_T19, L4_T20, JT_32, LayK4>(smem, tid);
-  constexpr int LA35 = YF_N_LUT * 256 + YF_A_ADD35 * 2048, LA41 = YF_N_LUT * 256 + YF_A_ADD41 * 2048;      // add tables: resident with the LUTs
-  // a stage's constants arrive by LDS-DMA one stage ahead; the barrier that ends a stage waits for the transfer first
-#define K4_FETCH(CS) v2::fetch_consts<CS, LayK4, PLAN.vb_bytes[CS] - (yf_cs_add[CS] >= 0 ? 2048 : 0)>(tab, wave, lane)
-#define K4_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); } while (0)
-#define K4_DENSE(TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, AD, CS, LAABS) \
-  v2::dense2_stage<F, NW, TPJ, KS, BW, IN, OUT, CH0, COUT, EPI, LUT, ADDB, CS, -1, 0, -1, LayK4, LAABS>(frames, out_all, tab, AD, wave, lane)
-  char* frames = smem;
-  constexpr int N0 = K4_ROWS0 * T15_ROW / 16, N1 = K4_ROWS1 * T15_ROW / 16, H1 = 2 * K4_HALF;     // halves: vectors, first halo'd row of the second
-  Prefetch<NT, N0> pre;
-  long fr = blockIdx.x;
-  if (fr < prm.n) pf_fetch(pre, prm.arena + fr * (long)ARENA_BYTES + A_T15, N0, tid);
-  for (; fr < prm.n; fr += gridDim.x) {
-    char* out_all = reinterpret_cast<char*>(prm.out) + fr * (long)OUT_FRAME_BYTES;
-    const char* t15 = prm.arena + fr * (long)ARENA_BYTES + A_T15;
-    YF_BAND_PRIO(3);
-    lds_barrier();                                                                    // every wave has left the previous frame's head stage (ring slots, buffers)
-    K4_FETCH(11);
-    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N0, tid);    // halo'd rows 0 .. ROWS0-1
-    K4_SYNC();
-    pf_fetch(pre, t15 + H1 * T15_ROW, N1, tid);                                       // second half, behind the first half's compute
-    pool25_half<NT>(frames, 0, 0, tid);
-    v2::dw2_stage<F, NW, 2, L4_T15H, L4_T17A, 24, YF_L_LEAKY28, 11, JT_A, LayK4>(frames, tab, wave, lane);
-    lds_barrier();
-    pf_commit_rows<T15_ROW / 16, K4_T15_PITCH>(pre, frames + L4_T15H::OFF, N1, tid);    // halo'd rows H1 .. G2
-    lds_barrier();
-    if (fr + gridDim.x < prm.n) pf_fetch(pre, prm.arena + (fr + gridDim.x) * (long)ARENA_BYTES + A_T15, N0, tid);
-    K4_FETCH(12);
-    pool25_half<NT>(frames, K4_HALF, H1, tid);
-    v2::dw2_stage<F, NW, 2, L4_T15H, L4_T17B, 24, YF_L_LEAKY28, 11, JT_B, LayK4>(frames, tab, wave, lane);
-    K4_SYNC();
-    YF_BAND_PRIO(2);
-    K4_FETCH(13);
-    K4_DENSE(1, 2, 16, L4_T17, L4_T18, 0, 8, EPI_RAW, 0, L4_T18, no_add, 12, -1);                              // conv2d_29
-    K4_SYNC();
-    K4_FETCH(14);
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW32), tid);
-    K4_DENSE(3, 1, 8, L4_T18, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY31, L4_T19, no_add, 13, -1);                   // conv2d_30
-    K4_SYNC();
-    K4_FETCH(15);
-    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY33, 14, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_32
-    K4_SYNC();
-    YF_BAND_PRIO(1);
-    K4_FETCH(16);
-    K4_DENSE(1, 3, 16, L4_T20, L4_T22, 0, 8, EPI_ADD, YF_A_ADD35, L4_T18, addctx(YF_A_ADD35), 15, LA35);       // conv2d_34 + eltwise_35
-    K4_SYNC();
-    K4_FETCH(17);
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW38), tid);
-    K4_DENSE(3, 1, 8, L4_T22, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY37, L4_T19, no_add, 16, -1);                   // conv2d_36
-    K4_SYNC();
-    K4_FETCH(18);
-    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY39, 17, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_38
-    K4_SYNC();
-    K4_FETCH(19);
-    K4_DENSE(1, 3, 16, L4_T20, L4_T26, 0, 8, EPI_ADD, YF_A_ADD41, L4_T22, addctx(YF_A_ADD41), 18, LA41);       // conv2d_40 + eltwise_41
-    K4_SYNC();
-    YF_BAND_PRIO(0);
-    K4_FETCH(20);
-    K4_DENSE(2, 1, 8, L4_T26, L4_T30, 24, 24, EPI_LUT, YF_L_L43Q44, L4_T30, no_add, 19, -1);                   // conv2d_42 -> concat_46
-    K4_SYNC();
-    K4_FETCH(21);
-    fill_halo<L4_T19, true, F, NT>(frames, load_halo_zp(tab, YF_W_DW49), tid);
-    K4_DENSE(2, 3, 16, L4_T30, L4_T19, 0, 40, EPI_LUT, YF_L_LEAKY48, L4_T19, no_add, 20, -1);                  // conv2d_47
-    K4_SYNC();
-    K4_FETCH(22);
-    v2::dw2_stage<F, NW, 1, L4_T19, L4_T20, 40, YF_L_LEAKY50, 21, JT_32, LayK4>(frames, tab, wave, lane);      // conv2d_49
-    K4_SYNC();
-    K4_FETCH(23);
-    K4_DENSE(2, 3, 16, L4_T20, L4_T33, 0, 32, EPI_LUT, YF_L_LEAKY52, L4_T33, no_add, 22, -1);                  // conv2d_51
-    K4_SYNC();
-    K4_DENSE(1, 2, 16, L4_T33, L4_T33, 0, 18, EPI_HEAD, 0, L4_T33, no_add, 23, -1);                            // conv2d_53 -> head
-  }
-#undef K4_FETCH
-#undef K4_SYNC
-#undef K4_DENSE
-}
-}  // namespace band
+#include "yf_band160.hip.h"         // the three banded 160x160 kernels
 #endif  // YF_GENERIC
 
 }  // namespace YF_NS
