@@ -602,26 +602,22 @@ __device__ __forceinline__ void pool8_sweep(MAX mx, LOADC loadc, STORE store) {
 typedef __attribute__((address_space(3))) uint32_t* lds_u32w_p;
 __device__ __forceinline__ uint32_t ld32(int a) { return *(const lds_u32w_p)(uintptr_t)(uint32_t)a; }
 __device__ __forceinline__ void st32(int a, uint32_t v) { *(lds_u32w_p)(uintptr_t)(uint32_t)a = v; }
-// pool_8, horizontal pass: T4 [28][28] x 18 ch -> HB [28 rows][14].  An item = (row, 8-byte chunk of the 40-byte pixel: four channels) sweeps HALF a
-// row (seven outputs, twenty ds_read_b64); the half is wave-uniform (waves 0-2: outputs 0..6, waves 3-5: 7..13), so its coordinates are immediates.
-// 2 x 140 items on six waves.
-template <int O0>
-__device__ __forceinline__ void pool8_h_half(int row, int dst, bool two) {
-  auto mx = [](uint2 a, uint2 b) { return uint2{pkmaxh(a.x, b.x), pkmaxh(a.y, b.y)}; };
-  pool8_sweep<O0, 7, 27, uint2>(mx, [&](int x) { return ld64(row + x * B_T4::S); },
-                                [&](int ox, uint2 v) { st32(dst + ox * B_HB::S, v.x); if (two) st32(dst + ox * B_HB::S + 4, v.y); });
-}
-__device__ __forceinline__ void pool8_h(int wave, int lane) {
+// pool_8, horizontal pass: T4 [28][28] x 18 ch -> HB [28 rows][14].  An item = (row, 8-byte chunk of the 40-byte pixel: four channels) sweeps its WHOLE row
+// (fourteen outputs, twenty-eight ds_read_b64 at immediate offsets): 140 items = three waves, which run beside conv2d_10 on the other five -- both only
+// read T4 (round 4; as a stage of its own the pass swept half rows on six waves and cost a barrier interval of 2.4 k cycles per frame).
+constexpr int POOL8H_WAVES = 3;
+__device__ __forceinline__ void pool8_h(int pw, int lane) {
   static_assert(B_T4::S == 40 && B_T4::OFF % 8 == 0 && B_T4::ROWB % 8 == 0 && B_HB::S == 36, "8-byte chunks of T4's pixels, dword stores into HB's");
-  if (wave >= 6) return;
-  const int hw = wave >= 3 ? 1 : 0;
-  const int it = min((wave - 3 * hw) * 64 + lane, 139);          // surplus lanes redo the last item (same values, same addresses)
+  const int it = min(pw * 64 + lane, 139);                       // surplus lanes redo the last item (same values, same addresses)
   const int q = (it * 2341) >> 16, y = it - 28 * q;              // chunk = it / 28 (rows vary fastest: 34-dword row pitch mod 64 spreads the lanes over the banks)
   const int row = B_T4::at(y, 0) + 8 * q, dst = B_HB::OFF + y * (14 * B_HB::S) + 8 * q;
-  if (hw == 0) pool8_h_half<0>(row, dst, q < 4); else pool8_h_half<7>(row, dst, q < 4);
+  const bool two = q < 4;                                        // the fifth chunk holds channels 16, 17 and two padding channels
+  auto mx = [](uint2 a, uint2 b) { return uint2{pkmaxh(a.x, b.x), pkmaxh(a.y, b.y)}; };
+  pool8_sweep<0, 14, 27, uint2>(mx, [&](int x) { return ld64(row + x * B_T4::S); },
+                                [&](int ox, uint2 v) { st32(dst + ox * B_HB::S, v.x); if (two) st32(dst + ox * B_HB::S + 4, v.y); });
 }
 // pool_8, vertical pass: HB -> pool half of concat_22 (T14 channels 0..17).  An item = (column, channel dword) sweeps its whole column (fourteen outputs,
-// twenty-eight loads at immediate offsets): 126 items = two waves; the other waves of the stage run conv2d_10, which does not touch HB or T14.
+// twenty-eight loads at immediate offsets): 126 items = two waves; the other waves of the stage run conv2d_12 (T6 -> T7), which does not touch HB or T14.
 constexpr int POOL8V_WAVES = 2;
 __device__ __forceinline__ void pool8_v(int item) {
   const int it = min(item, 14 * 9 - 1);
@@ -840,7 +836,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no] = __builtin_readcyclecounter(); __syncthreads(); \
     if (prof_on && (tid0 & 63) == 0 && bar_no < 40) prof_out[2 * bar_no + 1] = __builtin_readcyclecounter(); ++bar_no; } while (0)
 #elif defined(YF16_STAGEPMC)
-  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop = 1 .. 13, every frame is abandoned behind its barrier number `stop`
+  // per-stage counters (tools/fp16_stage_pmc.py): one launch per value of prm.stop = 1 .. 12, every frame is abandoned behind its barrier number `stop`
   // and the tail phase is skipped; stop = 0 runs everything.  The differences between consecutive launches are the stages' instruction counts.  Results
   // are wrong by construction.
   int stage_no = 0;
@@ -934,14 +930,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     fill_halo<B_T4, false, NT>(lds, tid);
     dense_pair_stage<2, 1, 4, EPI_LINEAR, NoBuf, NoBuf, ZSLACK, 3, NW, 5, 18, B_T2, B_T4, 0, ZSLACK>(wave, lane);            // conv2d_5 -> conv2d_6
     SYNC();
-    pool8_h(wave, lane);
-    SYNC();
+    // pool_8 and the branch beside it share two stages: {horizontal pass || conv2d_10} both only read T4, {vertical pass || conv2d_12} touch disjoint buffers
+    // (HB -> concat_22's pool half; T6 -> T7).  One barrier interval less per frame than {h}, {v || conv2d_10}, {conv2d_12}.
     FETCH(4);
-    if (wave < POOL8V_WAVES) pool8_v(wave * 64 + lane);                                               // pool_8 -> concat_22[0,18) ...
-    else conv3x3_stage<4, NW - POOL8V_WAVES, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave - POOL8V_WAVES, lane);   // ... beside conv2d_10 (dw, stride 2)
+    if (wave < POOL8H_WAVES) pool8_h(wave, lane);                                                     // pool_8 h: T4 -> HB ...
+    else conv3x3_stage<4, NW - POOL8H_WAVES, 2, B_T4, B_T6, 18, true>(lds, tab, conv_at(4), wave - POOL8H_WAVES, lane);   // ... beside conv2d_10 (dw, stride 2): T4 -> T6
     SYNC();
     FETCH(5);
-    dense_tile_stage<5, NW, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(wave, lane);   // conv2d_12
+    if (wave < POOL8V_WAVES) pool8_v(wave * 64 + lane);                                               // pool_8 v: HB -> concat_22[0,18) ...
+    else dense_tile_stage<5, NW - POOL8V_WAVES, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(wave - POOL8V_WAVES, lane);   // ... beside conv2d_12: T6 -> T7
     SYNC();
     FETCH(6);
     fill_halo<B_T8, true, NT>(lds, tid);

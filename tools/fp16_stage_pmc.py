@@ -9,10 +9,10 @@ import csv, glob, importlib, os, sys
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = 4096
-# barrier-delimited front stages in launch order (stop = 1 ... 13: every frame is abandoned behind that barrier, no tail phase), then the full kernel
-# (stop = 0): its difference to stop = 13 is the tail phase (conv2d_29 .. conv2d_53, one frame per wave) + the per-batch arena clear / weight fetch
+# barrier-delimited front stages in launch order (stop = 1 ... 12: every frame is abandoned behind that barrier, no tail phase), then the full kernel
+# (stop = 0): its difference to stop = 12 is the tail phase (conv2d_29 .. conv2d_53, one frame per wave) + the per-batch arena clear / weight fetch
 STAGES = [("input staging + halo fills", 0), ("conv2d_1", 6272), ("conv2d_3 (dw)", 6272),
-          ("conv2d_5 -> conv2d_6", 3136 + 14112), ("pool_8 h", 0), ("pool_8 v | conv2d_10 (dw)", 3528), ("conv2d_12", 1176), ("conv2d_13", 7056),
+          ("conv2d_5 -> conv2d_6", 3136 + 14112), ("pool_8 h | conv2d_10 (dw)", 3528), ("pool_8 v | conv2d_12", 1176), ("conv2d_13", 7056),
           ("conv2d_15 (dw)", 7056), ("conv2d_17+add", 1176), ("conv2d_19", 3528), ("conv2d_23", 4704),
           ("pool_25 | conv2d_27 (dw) -> park", 1176),
           ("tail phase: conv2d_29 .. conv2d_53", 392 + 1960 * 3 + 392 * 2 + 1960 * 2 + 1176 + 1960 + 1568 + 882)]
@@ -24,7 +24,7 @@ def run():
     x = (np.random.default_rng(3).integers(0, 256, (N, 56, 56, 3)).astype(np.float32) / 255.0).astype(np.float16)
     net = yf.Network().init(); net.fp16_init()
     d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((N, 7, 7, 18), dtype=torch.float32, device="cuda")
-    for k in list(range(1, len(STAGES))) + [0]:      # stops 1 .. 13, then everything
+    for k in list(range(1, len(STAGES))) + [0]:      # stops 1 .. 12, then everything
         os.environ["YF16_STOP_STAGE"] = str(k)
         net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), N)
     torch.cuda.synchronize()

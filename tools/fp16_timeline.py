@@ -21,9 +21,9 @@ del os.environ["YF16_PROF_OUT"]
 wgs, nw = (256 if os.environ.get('YF16_ONE_WG_PER_CU') else 512), 8
 p = np.fromfile(path, np.int64).reshape(wgs, nw, 40, 2).astype(np.float64)
 arrive, leave = p[..., 0], p[..., 1]
-# entries 0..12: the barriers of the workgroup's second frame (front stages); 20, 21: the two barriers of the tail phase of its first batch
-names = ["input staging + halo fills", "conv2d_1", "conv2d_3 (dw)", "conv2d_5 -> conv2d_6", "pool_8 h", "pool_8 v | conv2d_10 (dw)",
-         "conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23", "pool_25 | conv2d_27 (dw) -> park slot"]
+# entries 0..11: the barriers of the workgroup's second frame (front stages); 20, 21: the two barriers of the tail phase of its first batch
+names = ["input staging + halo fills", "conv2d_1", "conv2d_3 (dw)", "conv2d_5 -> conv2d_6", "pool_8 h | conv2d_10 (dw)",
+         "pool_8 v | conv2d_12", "conv2d_13", "conv2d_15 (dw)", "conv2d_17+add", "conv2d_19", "conv2d_23", "pool_25 | conv2d_27 (dw) -> park slot"]
 NF = len(names)
 front = leave[:, :, NF - 1] - leave[:, :, 0]
 print(f"{wgs} workgroups x {nw} waves; front stages of one frame (first to last barrier, without the staging stage): mean {front.mean():.0f} cycles "
