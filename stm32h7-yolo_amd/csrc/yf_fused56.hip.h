@@ -51,6 +51,15 @@ static_assert(sizeof(yf_table_index) <= YF_INDEX_RESERVED, "index does not fit i
 
 // Issue priority per stage (s_setprio, 0..3), stage order: staging, conv2d_1, 3, 5, 6, pool_8 h, pool_8 v, conv2d_10, 12, 13, 15,
 // 17, 19, 23, then the thirteen tail stages.  See the kernel: a workgroup's priority FALLS as its group advances.
+#ifndef YF_POOL_MERGE
+#define YF_POOL_MERGE 1          /* pool_8's two passes share stages with conv2d_10 / conv2d_13 (0: five stages of their own, the round-3 order) */
+#endif
+#ifndef YF_POOL8H_WAVES
+#define YF_POOL8H_WAVES 3
+#endif
+#ifndef YF_POOL8V_WAVES
+#define YF_POOL8V_WAVES 3
+#endif
 #ifndef YF_PRIO_LIST
 #define YF_PRIO_LIST 3,3,3,3,3,3,3,3,3,3, 2,2,2,2, 1,1,1,1,1,1, 0,0,0,0,0,0,0
 #endif
@@ -81,6 +90,9 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
+  constexpr bool POOL_MERGE = YF_POOL_MERGE != 0 && !DUMP && NW >= 8;      // (debug builds keep the staged order: their dumps and stop-stage numbers follow it)
+  typedef Buf<B_T14::OFF, 14, 14, 32, 14, 0, 0> B_T6X;                     // conv2d_10's output on concat_22's (still unwritten) bytes
+  typedef typename std::conditional<POOL_MERGE, B_T6X, B_T6>::type B_T6M;
   constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
   typedef TailBufs<BATCH ? FRAME_STRIDE / 2 : FRAME_STRIDE> U;
   constexpr int OUT_ALL_BYTES = BATCH ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15;      // BATCH stages the heads inside the tail sets
@@ -108,7 +120,7 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
     typedef typename JTS::U UT;
     v2::fill_jobtab<F, 1, B_T1, B_T2, JTS::JT_DW3>(smem, tid0);
-    v2::fill_jobtab<F, 2, B_T4, B_T6, JTS::JT_DW10>(smem, tid0);
+    v2::fill_jobtab<F, 2, B_T4, B_T6M, JTS::JT_DW10>(smem, tid0);
     v2::fill_jobtab<F, 1, B_T8, B_T9, JTS::JT_DW15>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 2, typename UT::T15, typename UT::T17, JTS::JT_DW27>(smem, tid0);
     v2::fill_jobtab<JTS::FT, 1, typename UT::T19, typename UT::T20, JTS::JT_DW32>(smem, tid0);
@@ -224,31 +236,54 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     YF_DENSE(F, 5, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50; experimental bit 1024: three)
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
-    YF_PRIO(5);
+    if constexpr (POOL_MERGE) {
+      // pool_8 shares two stages with the branch beside it (the form the fp16 kernel took in round 4): {horizontal pass || conv2d_10} both only read T4,
+      // {vertical pass || conv2d_13} touch disjoint buffers (HB -> concat_22's pool half; T7 -> T8), conv2d_12 in between.  conv2d_10's output T6 cannot
+      // sit on HB's bytes then (its slot in the staged order): it goes to concat_22's region, which nothing writes before the vertical pass.  Two barrier
+      // intervals less per group than {h}, {v}, {conv2d_10}, {conv2d_12}, {conv2d_13}.
+      constexpr int PH = YF_POOL8H_WAVES, PV = YF_POOL8V_WAVES;
+      YF_PRIO(5);
+      YF_FETCH(5, W_m, L_m);
+      if (W_m < PH) pool8_h<F, PH * 64>(frames, tid_m);                                               // pool_8 (h): T4 -> HB ...
+      else v2::dw2_stage<F, NW - PH, 2, B_T4, B_T6M, 18, YF_L_LEAKY11, 4, v2::JobTabs<F, BATCH>::JT_DW10>(frames, tab, W_m - PH, L_m);   // ... beside conv2d_10: T4 -> T6
+      YF_SYNC();
+      YF_PRIO(8);
+      YF_FETCH(6, W_m, L_m);
+      YF_DENSE(F, 1, 2, 16, B_T6M, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);          // conv2d_12
+      YF_SYNC();
+      YF_PRIO(9);
+      YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
+      YF_FETCH(7, W_m, L_m);
+      if (W_m < PV) pool8_v<F, PV * 64, false>(frames, tid_m);                                        // pool_8 (v) + QUANTIZE#21: HB -> concat_22 ...
+      else v2::dense2_stage<F, NW - PV, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, 6>(frames, out_all, tab, no_add, W_m - PV, L_m);   // ... beside conv2d_13: T7 -> T8
+      YF_SYNC();
+    } else {
+  YF_PRIO(5);
 #if !(defined(YF_LAB) && defined(YF_WHATIF_NO_POOL8H))   // what-if (WRONG results): the horizontal pass and its barrier gone -- the bound for folding it into conv2d_6's epilogue
-    pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
-    YF_SYNC();
+      pool8_h<F, NT>(frames, tid_f);                                                                   // pool_8 (h)
+      YF_SYNC();
 #endif
-    YF_STAGE_END()
-    YF_PRIO(6);
-    pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
-    YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
-    YF_PRIO(7);
-    YF_FETCH(5, W_m, L_m);
-    YF_DW(F, 2, B_T4, B_T6, 18, YF_L_LEAKY11, YF_W_DW10, W_m, L_m, 4, JT_DW10);                          // conv2d_10
-    YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T14, 18, P8, YF_T14_CONV_BASE) YF_DUMP(B_T6, 18, T6)
-    YF_STAGE_END()
-    YF_PRIO(8);
-    YF_FETCH(6, W_m, L_m);
-    YF_DENSE(F, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);            // conv2d_12
-    YF_SYNC(); YF_DUMP(B_T7, 6, T7)
-    YF_STAGE_END()
-    YF_PRIO(9);
-    YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
-    YF_FETCH(7, W_m, L_m);
-    YF_DENSE(F, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
-    YF_SYNC(); YF_DUMP(B_T8, 36, T8)
-    YF_STAGE_END()
+      YF_STAGE_END()
+      YF_PRIO(6);
+      pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
+      YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
+      YF_PRIO(7);
+      YF_FETCH(5, W_m, L_m);
+      YF_DW(F, 2, B_T4, B_T6, 18, YF_L_LEAKY11, YF_W_DW10, W_m, L_m, 4, JT_DW10);                          // conv2d_10
+      YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T14, 18, P8, YF_T14_CONV_BASE) YF_DUMP(B_T6, 18, T6)
+      YF_STAGE_END()
+      YF_PRIO(8);
+      YF_FETCH(6, W_m, L_m);
+      YF_DENSE(F, 1, 2, 16, B_T6, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);            // conv2d_12
+      YF_SYNC(); YF_DUMP(B_T7, 6, T7)
+      YF_STAGE_END()
+      YF_PRIO(9);
+      YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
+      YF_FETCH(7, W_m, L_m);
+      YF_DENSE(F, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, YF_D_C13, no_add, W_m, L_m, 6); // conv2d_13
+      YF_SYNC(); YF_DUMP(B_T8, 36, T8)
+      YF_STAGE_END()
+    }
     YF_PRIO(10);
     YF_FETCH(8, W_m, L_m);
     YF_DW(F, 1, B_T8, B_T9, 36, YF_L_LEAKY16, YF_W_DW15, W_m, L_m, 7, JT_DW15);                          // conv2d_15

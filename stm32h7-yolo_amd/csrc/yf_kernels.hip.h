@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 #include "yf_tables.h"
 
 #pragma clang diagnostic push

@@ -29,7 +29,11 @@ span = leave[:, :, -1] - leave[:, :, 0]
 print(f"{wgs} workgroups x {nw} waves, {nb} barriers per group; cycles from the first to the last barrier of a group: "
       f"mean {span.mean():.0f} (min {span.min():.0f} max {span.max():.0f})")
 print(f"working {100 * body.sum(axis=2).mean() / span.mean():.1f}%  waiting in barriers {100 * wait[:, :, 1:].sum(axis=2).mean() / span.mean():.1f}%")
-labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_10 (dw)"] + [f"{nm}" for nm in NAMES[7:]]
+# the production kernel (round 4) runs pool_8's passes beside conv2d_10 / conv2d_13: 26 barriers per group; a -DYF_POOL_MERGE=0 build has the staged order (28)
+if nb == 26:
+    labels = ["top of loop"] + list(NAMES[:5]) + ["pool_8 h | conv2d_10 (dw)", "conv2d_12", "pool_8 v | conv2d_13"] + list(NAMES[9:])
+else:
+    labels = ["top of loop"] + [f"{nm}" for nm in NAMES[:6]] + ["pool_8 v", "conv2d_10 (dw)"] + [f"{nm}" for nm in NAMES[7:]]
 # tail batching: the profiled (second) group of a workgroup fetches the parked group's T15 behind conv2d_23 and then runs the
 # tail for four frames; its interval times are per PAIR of groups
 k23 = next(i for i, nm in enumerate(labels) if nm.startswith("conv2d_23"))
