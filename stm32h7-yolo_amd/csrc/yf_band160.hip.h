@@ -243,8 +243,26 @@ constexpr int K23_R14 = K23_RH + K23_RH_BYTES;                                  
 typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4;       // local row l = T4 row 2p0-3+l
 typedef Buf<K23_RA,                              G1, K23_NR, 20, T4_RS,  0, 1> L23_T4_DW;    // conv2d_10's view: output row t (T6 row p0-1+t) reads local rows 2t .. 2t+2
 typedef Buf<K23_RH,                              G2, K23_NR, 20, G2,     0, 0> L23_HB;
+// pool_8's passes run BESIDE the conv branch (round 4, as in the fused 56x56 kernel): {horizontal pass || conv2d_10}, {conv2d_12}, {vertical pass || conv2d_13}.
+// HB then lives until the vertical pass, so conv2d_10's output T6 sits on concat_22's rows (unwritten until that pass) and T7 behind T9 at the end of region A
+// (T4 is dead there once conv2d_10 is through).  YF_K23_POOL_MERGE=0: the staged order of round 3 (T6 | T7 on HB's bytes).
+#ifndef YF_K23_POOL_MERGE
+#define YF_K23_POOL_MERGE 1
+#endif
+#ifndef YF_K23_PH
+#define YF_K23_PH 3            /* waves of the horizontal pass (the other NW - PH run conv2d_10) */
+#endif
+#ifndef YF_K23_PV
+#define YF_K23_PV 3            /* waves of the vertical pass (the others run conv2d_13) */
+#endif
+constexpr int K23_T8T9_BYTES = K23_NM * (T8_ROW + 16) + K23_BP * G2 * 48;                   // T8 (16 bytes of row skew) | T9 in region A
+#if YF_K23_POOL_MERGE
+typedef Buf<K23_R14,                             G2, K23_NM, 32, G2,     0, 0> L23_T6;       // on concat_22's rows (written by the vertical pass, after conv2d_12)
+typedef Buf<K23_RA + K23_T8T9_BYTES,             G2, K23_NM,  8, G2,     0, 0> L23_T7;       // rows p0-1 .. p0+8, behind T9 in region A
+#else
 typedef Buf<K23_RH,                              G2, K23_NM, 32, G2,     0, 0> L23_T6;       // aliases HB (dead after the vertical pool pass)
 typedef Buf<K23_RH + K23_NM * G2 * 32,           G2, K23_NM,  8, G2,     0, 0> L23_T7;       // rows p0-1 .. p0+8
+#endif
 typedef Buf<L23_T7::OFF + G2 * 8,                G2, K23_BP,  8, G2,     0, 0> L23_T7C;      // rows p0 .. p0+7: the residual input of eltwise_18
 // T8's 1584-byte rows put the second row of a 32-lane tap read 12 banks behind the first (4 of 16 lanes collide); 16 bytes of skew make it 16
 #ifndef YF_K23_T8_SKEW
@@ -257,8 +275,13 @@ typedef Buf<K23_RH,                              G2, K23_BP,  8, G2,     0, 0> L
 typedef Buf<K23_R14,                             G2, K23_BP, 48, G2,     0, 0> L23_T14;
 typedef Buf<K23_RH + K23_BP * G2 * 8,            G2, K23_BP, 24, T15_RS, 0, 1> L23_T15;      // behind T11, on T6's old bytes
 constexpr int K23_LDS = K23_R14 + K23_BP * G2 * 48;
+#if YF_K23_POOL_MERGE
+static_assert(YF_K23_T8_SKEW == 16 && K23_T8T9_BYTES == K23_NM * K23_T8_ROW + K23_BP * G2 * 48 && K23_T8T9_BYTES + K23_NM * G2 * 8 <= K23_RA_BYTES && K23_T8T9_BYTES % 16 == 0, "T8 | T9 | T7 fit region A");
+static_assert(K23_NM * G2 * 32 <= K23_BP * G2 * 48 && K23_BP * G2 * 8 + K23_BP * T15_ROW <= K23_RH_BYTES, "T6 fits concat_22's rows; T11 | T15 fit HB's bytes");
+#else
 static_assert(K23_NM * G2 * 32 + K23_NM * G2 * 8 <= K23_RH_BYTES && K23_NM * K23_T8_ROW + K23_BP * G2 * 48 <= K23_RA_BYTES, "aliases fit");
 static_assert(K23_BP * G2 * 8 + K23_BP * T15_ROW <= K23_NM * G2 * 32, "T11 | T15 fit T6's bytes (T7 behind them stays alive until conv2d_17)");
+#endif
 static_assert(K23_LDS <= 81920 && K23_RA % 16 == 0 && K23_RH % 16 == 0 && K23_R14 % 16 == 0 && L23_T9::OFF % 16 == 0 && L23_T15::OFF % 16 == 0, "two workgroups per CU, aligned buffers");
 
 template <int NW>
@@ -306,10 +329,11 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L23_T4::OFF + ll * T4_ROW, n16, tid); }
     lds_barrier();
     if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
-    {   // pool_8 horizontal pass over every band row (rows outside the image are never read back)
+    // pool_8 horizontal pass over every band row (rows outside the image are never read back), on threads [0, nt)
+    auto pool_h = [&](int t0, int nt) {
       constexpr int NO = 5, NCH = G2 / NO;
       static_assert(G2 % NO == 0, "sweeps of 5 outputs");
-      for (int i = tid; i < K23_NR * NCH * 5; i += NT) {
+      for (int i = t0; i < K23_NR * NCH * 5; i += nt) {
         const int cg = i % 5; int t = i / 5;
         const int k = t % NCH; const int l = t / NCH;
         const char* row = frames + L23_T4::OFF + l * T4_ROW + 20 + 4 * cg;                // pixel 0 sits behind the halo column
@@ -317,11 +341,11 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
         pool8_sweep<NO, G1 - 1>(k * NO, [&](int x) { return lds_u32(row + x * 20); },
                                 [&](int ox, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + ox * 20) = v.merge(); });
       }
-    }
-    lds_barrier();
-    {   // vertical pass + QUANTIZE#21 straight into the pooled half of the band's concat_22 rows
+    };
+    // vertical pass + QUANTIZE#21 straight into the pooled half of the band's concat_22 rows
+    auto pool_v = [&](int t0, int nt) {
       constexpr int NO = 4, NSW = K23_BP / NO;
-      for (int i = tid; i < NSW * G2 * 5; i += NT) {
+      for (int i = t0; i < NSW * G2 * 5; i += nt) {
         const int cg = i % 5; int t = i / 5;
         const int ox = t % G2; const int sw = t / G2;
         const char* col = frames + L23_HB::OFF + ox * 20 + 4 * cg;
@@ -329,7 +353,24 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
         pool8_sweep<NO, G1 - 1>(p0 + sw * NO, [&](int r) { return lds_u32(col + (r - (2 * p0 - 3)) * (G2 * 20)); },
                                 [&](int oy, const SplitB& v) { *reinterpret_cast<uint32_t*>(dst + (oy - p0) * (G2 * 48)) = lut4_raw<YF_L_Q21>(v); });
       }
-    }
+    };
+#if YF_K23_POOL_MERGE
+    constexpr int PH = YF_K23_PH, PV = YF_K23_PV;
+    YF_BAND_PRIO(2);
+    if (wave < PH) pool_h(tid, PH * 64);                                                                                      // T4 -> HB ...
+    else v2::dw2_stage<F, NW - PH, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11, 4, JT_DW10, LayK23>(frames, tab, wave - PH, lane);  // ... beside conv2d_10 (ten rows): T4 -> T6
+    lds_barrier();
+    v2::dense2_stage<F, NW, 1, 2, 16, L23_T6, L23_T7, 0, 6, EPI_RAW, 0, L23_T7, 5, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave, lane);
+    lds_barrier();
+    if (wave < PV) pool_v(tid, PV * 64);                                                                                      // HB -> concat_22 ...
+    else v2::dense2_stage<F, NW - PV, 3, 1, 8, L23_T7, L23_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, L23_T8, 6, -1, 0, -1, LayK23>(frames, nullptr, tab, no_add, wave - PV, lane);   // ... beside conv2d_13: T7 -> T8
+    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
+    fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
+    lds_barrier();
+#else
+    pool_h(tid, NT);
+    lds_barrier();
+    pool_v(tid, NT);
     lds_barrier();                                                 // T6 (written next) aliases HB
     YF_BAND_PRIO(2);
     v2::dw2_stage<F, NW, 2, L23_T4_DW, L23_T6, 18, YF_L_LEAKY11, 4, JT_DW10, LayK23>(frames, tab, wave, lane);               // ten rows
@@ -340,6 +381,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, 0, K23_NM, z_t8, tid);
     fill_column<NT, K23_T8_ROW, 36>(frames + L23_T8::OFF, G2 + 1, K23_NM, z_t8, tid);
     lds_barrier();
+#endif
     if (p0 == 0) fill_dwords<NT>(frames + L23_T8::OFF, z_t8, T8_ROW, tid);                                       // T8 row -1 = halo
     if (p0 + K23_BP == G2) fill_dwords<NT>(frames + L23_T8::OFF + (K23_NM - 1) * K23_T8_ROW, z_t8, T8_ROW, tid);    // T8 row G2
     if (p0 == 0 || p0 + K23_BP == G2) lds_barrier();
