@@ -25,14 +25,14 @@
 
 struct yf_stream_scratch {
   size_t max_regions = 8;                          // the owner may lower it (the 160x160 arena: 4)
-  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; };   // dirty: launched on without an event
+  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired; };   // dirty: launched on without an event; acquired: handed out by get(), its launch not yet marked
   std::mutex mu;
   std::vector<Region> regions;
   unsigned long long clock = 0;
 
   static size_t thread_key(hipStream_t s) { return s == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0; }
   Region* find(hipStream_t s, size_t tk) { for (Region& r : regions) if (r.stream == s && r.thread == tk) return &r; return nullptr; }
-  static bool idle(const Region& r) { return !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
+  static bool idle(const Region& r) { return !r.acquired && !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
 
   // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls mark(s).
   hipError_t get(hipStream_t s, size_t bytes, char** out) {
@@ -42,17 +42,21 @@ struct yf_stream_scratch {
     if (!r) {
       for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
       if (!r && regions.size() < max_regions) {
-        Region n = {s, tk, nullptr, 0, nullptr, false, 0, false};
+        Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false};
         const hipError_t rc = hipEventCreateWithFlags(&n.done, hipEventDisableTiming);
         if (rc != hipSuccess) return rc;
         regions.push_back(n);
         r = &regions.back();
       }
       if (!r) {                                                                       // all busy on other streams: wait for the one marked longest ago
-        for (Region& c : regions) if (!c.dirty && (!r || c.stamp < r->stamp)) r = &c;
+        for (Region& c : regions) if (!c.dirty && !c.acquired && (!r || c.stamp < r->stamp)) r = &c;
         hipError_t rc;
         if (r) rc = hipEventSynchronize(r->done);
-        else { r = &regions[0]; rc = hipDeviceSynchronize(); }                        // (a one-region object whose region is dirty: nothing names its launches)
+        else {                                                                        // only dirty regions left (nothing names their launches): wait for the device
+          for (Region& c : regions) if (!c.acquired) { r = &c; break; }
+          if (!r) return hipErrorNotReady;                                            // every region is between get() and mark() on another thread
+          rc = hipDeviceSynchronize();
+        }
         if (rc != hipSuccess) return rc;
       }
       r->stream = s; r->thread = tk; r->marked = false; r->dirty = false;
@@ -65,6 +69,7 @@ struct yf_stream_scratch {
       r->bytes = bytes;
     }
     r->stamp = ++clock;
+    r->acquired = true;                                                               // not idle between get() and mark(), whoever asks
     *out = r->ptr;
     return hipSuccess;
   }
@@ -73,6 +78,7 @@ struct yf_stream_scratch {
     std::lock_guard<std::mutex> lock(mu);
     Region* r = find(s, thread_key(s));
     if (!r) return hipSuccess;
+    r->acquired = false;
     if (regions.size() == 1) { r->dirty = true; return hipSuccess; }                  // one stream so far: no event between its kernels (see above)
     r->marked = true; r->dirty = false;
     return hipEventRecord(r->done, s);
