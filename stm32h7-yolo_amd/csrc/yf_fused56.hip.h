@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     YF_PRIO(4);
     YF_HALO(B_T4, false, F, G4, H_T4, YF_W_DW10, tid_f);
     YF_FETCH(4, W_f, L_f);
-    YF_DENSE(F, 5, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50; experimental bit 1024: three)
+    YF_DENSE(F, 5, 1, 4, B_T3, B_T4, 0, 18, EPI_LUT, YF_L_LEAKY7, B_T4, YF_D_C6, no_add, W_f, L_f, 3);   // conv2d_6: all five passes per job (25 jobs per two frames instead of 50)
     YF_SYNC(); YF_DUMP(B_T4, 18, T4)
     YF_STAGE_END()
     if constexpr (POOL_MERGE) {

@@ -29,8 +29,9 @@
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"   // absolute LDS addresses (device); the host pass only parses them
-#ifndef YF_LAUNDER
-#define YF_LAUNDER 0
+#if !defined(YF_LAB) || !defined(YF_LAUNDER)
+#undef YF_LAUNDER
+#define YF_LAUNDER 0       /* laboratory builds may set it (profiles/r04_whatif.txt): stage groups whose thread index is recomputed per group instead of parked */
 #endif
 #define YF_ROW_SKEW 4      /* bytes of row skew in the depthwise inputs with 8- / 40-byte pixels (T1, T19: Buf::SK) */
 namespace YF_NS {
@@ -618,7 +619,7 @@ __device__ __forceinline__ v4u lds_v4u(uint32_t a) { return *(lds_v4u_ptr)a; }
 
 // LDS-DMA of const-stage CS's block into its ring slot: wave w moves bytes [1024 w, 1024 w + 1024) -- one wave-instruction of
 // 64 x 16 bytes, no registers.  The compiler does not see the transfer (inline assembly): whoever reads the slot does so behind
-// an explicit s_waitcnt vmcnt(0) + barrier (V2_SYNC in the kernel).  M0 carries the LDS destination and is restored.
+// an explicit s_waitcnt vmcnt(0) + barrier (YF_SYNC in the kernel).  M0 carries the LDS destination and is restored.
 template <int CS, class LAY = Lay56, int BYTES_ = -1>      // BYTES_: only the first BYTES_ bytes of the block (a residual-add stage whose add tables are resident elsewhere)
 __device__ __forceinline__ void fetch_consts(const uint8_t* __restrict__ tab, int wave, int lane) {
   constexpr int BYTES = BYTES_ >= 0 ? BYTES_ : PLAN.vb_bytes[CS], NCHUNK = (BYTES + 1023) / 1024;
@@ -698,8 +699,10 @@ __device__ __forceinline__ void epilogue2_half(char* dstpix, const char* addpix,
     *reinterpret_cast<uint32_t*>(dstpix + chq) = join2(r[0], r[1]) ^ 0x8080u;
   }
 }
-#ifndef YF_CHUNK_UNROLL
-#define YF_CHUNK_UNROLL 0       /* dense stages with at most this many channel chunks unroll their chunk loop at compile time (0: never) */
+#if !defined(YF_LAB) || !defined(YF_CHUNK_UNROLL)
+#undef YF_CHUNK_UNROLL
+#define YF_CHUNK_UNROLL 0       /* laboratory builds may set it: dense stages with at most this many channel chunks unroll their chunk loop at compile time (the form that gave the fp16
+                                   kernel 3 %; here the per-chunk values get parked: scalar instructions -13 %, eight more spills, +0.3 %) */
 #endif
 #define YF_HALF_PASS 1          /* the last pass of a layer with 4k + 2 output channels requantises its two real channels only */
 
