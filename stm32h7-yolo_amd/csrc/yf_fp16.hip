@@ -848,6 +848,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #ifndef YF16_STAGEPMC
 #define SYNC_BATCH() SYNC()
 #endif
+#if defined(YF16_BARPROF) || defined(YF16_STAGEPMC)
+#define SYNC_LDS() SYNC()
+#else
+#define SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#endif
 #define FETCH(U) fetch_unit<U, NW>(tab, conv_at(unit_first(U)).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
   // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
@@ -967,7 +972,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
       if (wave < PW) pool25_cols<B_T15, PARK>(lds, wave * 64 + lane, slot);
       else conv3x3_stage<11, NW - PW, 2, B_T15, PARK, 24, true, true, 48>(lds, tab, conv_at(11), wave - PW, lane, slot);
     }
-    SYNC();                                                       // this frame's buffers are dead, its park slot is written
+    // This barrier orders LDS only (the next frame's staging overwrites what this stage still reads): it does not wait for the acknowledgements of the park
+    // slot's global stores -- ~1 k cycles per frame at the end of a short stage (round 4: -1.5 %).  The slots are read in the tail phase, behind a barrier that
+    // does wait (SYNC_BATCH); no weight DMA is in flight here (conv2d_27's block landed behind conv2d_23's barrier, the next one is issued by the next stage).
+    SYNC_LDS();
     }
     {   // ---- tail phase: weights resident, exchange buffers zeroed, then wave w runs the whole tail of the batch's frame w
       int tid = tid0;
@@ -989,6 +997,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
   }
 #undef SYNC
 #undef SYNC_BATCH
+#undef SYNC_LDS
 #undef SYNC_KEEP_PREFETCH
 #undef FETCH
 }
