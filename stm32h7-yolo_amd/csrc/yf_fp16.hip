@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
       for (int i = tid; i < NW * XB / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
       SYNC_BATCH();
       if (wave < nb) tail_chain<NW>(wave * XB, prm.scratch + ((long)blockIdx.x * NW + wave) * PARK_BYTES, prm.out + (base + wave * G) * (7 * 7 * 18), lane);
-      SYNC_BATCH();                                               // the next batch's clear overwrites the buffers
+      SYNC_LDS();                                                 // the next batch's clear overwrites the buffers (LDS order only: nothing here reads the logits just stored)
     }
   }
 #undef SYNC
