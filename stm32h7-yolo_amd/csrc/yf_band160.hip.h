@@ -36,6 +36,19 @@ struct Params { const int8_t* in; int8_t* out; long n; const uint8_t* tab; char*
 // band kernel writes to HBM is read back by the same kernel, so LDS ordering is all the stages need.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Virtual job index v (= blockIdx.x + k * gridDim.x) -> (frame, band).  Workgroup b runs on XCD b mod 8 and every XCD has an L2 of its own.  The bands of ONE frame
+// read overlapping rows (band_k1: 5 of a band's 37 input rows, band_k23: 6 of its 22 T4 rows), so they go to workgroups of ONE XCD -- v mod 8 picks the frame's
+// class, v / 8 walks (frame, band) inside it -- and the overlap is read from HBM once instead of once per band.  Needs a grid and a batch that are multiples of 8
+// (uniform over the launch); other launches keep the plain order.
+#ifndef YF_BAND_XCD
+#define YF_BAND_XCD 1
+#endif
+template <int BANDS>
+__device__ __forceinline__ void split_job(long v, bool xcd, long& fr, int& band) {
+  if (xcd) { const long l = v >> 3; const long q = l / BANDS; fr = (v & 7) + 8 * q; band = (int)(l - q * BANDS); }
+  else { fr = v / BANDS; band = (int)(v - fr * BANDS); }
+}
+
 // N bytes LDS -> HBM as 16-byte vectors (both 16-byte aligned, N a multiple of 16)
 template <int NT>
 __device__ __forceinline__ void store_rows(char* dst, const char* src, int bytes, int tid) {
@@ -168,11 +181,12 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
   const uint32_t z_t1 = splat(load_halo_zp(tab, YF_W_DW3)), z_t4 = splat(load_halo_zp(tab, YF_W_DW10));
   char* frames = smem;                                            // band-local buffers live at their LDS offsets
   const long jobs = prm.n * K1_BANDS;
+  const bool xcd = YF_BAND_XCD && gridDim.x % 8 == 0 && prm.n % 8 == 0;
   uint32_t pre[PER][3];
   // input rows of a band: local row l <-> input row 2(a-1)+l-1, out of range = zero point
   auto fetch = [&](long job) {
-    const long fr = job / K1_BANDS;
-    const int a = (int)(job - fr * K1_BANDS) * K1_BH;
+    long fr; int bnd; split_job<K1_BANDS>(job, xcd, fr, bnd);
+    const int a = bnd * K1_BH;
     const int8_t* in = prm.in + fr * (long)IN_FRAME_BYTES;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -189,8 +203,8 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
   long job = blockIdx.x;
   if (job < jobs) fetch(job);
   for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K1_BANDS;
-    const int a = (int)(job - fr * K1_BANDS) * K1_BH;              // first T4 row of the band
+    long fr; int bnd; split_job<K1_BANDS>(job, xcd, fr, bnd);
+    const int a = bnd * K1_BH;                                     // first T4 row of the band
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
     YF_BAND_PRIO(3);
     lds_barrier();                                                // previous band's buffers are dead
@@ -309,11 +323,12 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
   v2::fill_jobtab<1, 1, L23_T8, L23_T9, JT_DW15, LayK23>(smem, tid);
   char* frames = smem;
   const long jobs = prm.n * K23_BANDS;
+  const bool xcd = YF_BAND_XCD && gridDim.x % 8 == 0 && prm.n % 8 == 0;
   Prefetch<NT, K23_NR * T4_ROW / 16> pre;
   // T4 halo'd rows [2p0-2, 2p0-2+NR) that exist (0 .. G1): contiguous in the arena
   auto range = [&](long job, const char*& src, int& lo_local, int& n16) {
-    const long fr = job / K23_BANDS;
-    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;
+    long fr; int bnd; split_job<K23_BANDS>(job, xcd, fr, bnd);
+    const int p0 = bnd * K23_BP;
     const int h0 = 2 * p0 - 2, lo = max(h0, 0), hi = min(h0 + K23_NR, G1 + 1);
     src = prm.arena + fr * (long)ARENA_BYTES + A_T4 + lo * T4_ROW;
     lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
@@ -321,8 +336,8 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
   long job = blockIdx.x;
   if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
   for (; job < jobs; job += gridDim.x) {
-    const long fr = job / K23_BANDS;
-    const int p0 = (int)(job - fr * K23_BANDS) * K23_BP;           // first 40x40 row of the band
+    long fr; int bnd; split_job<K23_BANDS>(job, xcd, fr, bnd);
+    const int p0 = bnd * K23_BP;                                   // first 40x40 row of the band
     char* arena = prm.arena + fr * (long)ARENA_BYTES;
     lds_barrier();
     YF_BAND_PRIO(3);
