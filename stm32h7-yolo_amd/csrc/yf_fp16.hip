@@ -677,11 +677,16 @@ constexpr int TAILW0 = (int)conv_at(12).w_off, TAILW_BYTES = (int)conv_at(23).b_
 template <int NW> constexpr int tw(int k) { return NW * XB + (int)conv_at(k).w_off - TAILW0; }     // LDS address of tail conv k's rows / biases
 template <int NW> constexpr int tb(int k) { return NW * XB + (int)conv_at(k).b_off - TAILW0; }
 static_assert(XB % 16 == 0 && TAILW0 % 16 == 0 && TAILW_BYTES % 16 == 0 && 5 * 64 + 16 <= XT::ROWB && 16 * 6 <= XT::ROWB, "tail plan: aligned blocks, a zero halo row that covers every zero fragment");
-template <int NW>
+// PART 0: the 1 KB chunks that end below the weight ring (their destination -- concat_22 / T11 territory -- is dead once conv2d_23 is through: they are issued during
+// the batch's last {pool_25 || conv2d_27} stage); PART 1: the chunks on the ring itself, where conv2d_27's block is still being read then (issued in front of the
+// tail phase's first barrier); PART 2: all of them.
+template <int NW> constexpr int tailw_early_chunks() { const int c = (RING0 - NW * XB) / 1024; return c < 0 ? 0 : c; }
+template <int NW, int PART = 2>
 __device__ __forceinline__ void fetch_tailw(const uint8_t* __restrict__ tab, int wave, int lane) {
   static_assert(NW * XB + TAILW_BYTES <= LDS_TOTAL, "exchange buffers and resident tail weights fit the workgroup's LDS (arena and ring are dead in the tail phase; the arena is cleared before the next batch)");
-  constexpr int NCHUNK = (TAILW_BYTES + 1023) / 1024;
-  for (int j = wave; j < NCHUNK; j += NW) {
+  constexpr int NCHUNK = (TAILW_BYTES + 1023) / 1024, EARLY = tailw_early_chunks<NW>() < NCHUNK ? tailw_early_chunks<NW>() : NCHUNK;
+  constexpr int J0 = PART == 1 ? EARLY : 0, J1 = PART == 0 ? EARLY : NCHUNK;
+  for (int j = J0 + wave; j < J1; j += NW) {
     const int off = j * 1024 + lane * 16;
     if (off < TAILW_BYTES) {
       const uint8_t* src = tab + TAILW0 + off;
@@ -969,6 +974,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
       constexpr int PW = POOL25_WAVES;
       static_assert(PW < NW, "waves left for conv2d_27");
       char* slot = prm.scratch + ((long)blockIdx.x * NW + k) * PARK_BYTES;
+#if !defined(YF16_STAGEPMC)
+      // the batch's last frame: the tail phase's resident weights (21.5 KB) start their way into LDS here -- their place behind the exchange buffers is dead since
+      // conv2d_23 (concat_22 / T11 territory), and the tail phase's first barrier waits for them -- instead of in front of that barrier with nothing to hide behind
+      if (!more) fetch_tailw<NW, 0>(tab0, wave, lane);
+#endif
       if (wave < PW) pool25_cols<B_T15, PARK>(lds, wave * 64 + lane, slot);
       else conv3x3_stage<11, NW - PW, 2, B_T15, PARK, 24, true, true, 48>(lds, tab, conv_at(11), wave - PW, lane, slot);
     }
@@ -988,7 +998,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #ifdef YF16_STAGEPMC
       if (prm.stop > 0) continue;                                 // counting a front stage: no tail phase
 #endif
-      fetch_tailw<NW>(tab0, wave, lane);
+#if defined(YF16_STAGEPMC)
+      fetch_tailw<NW, 2>(tab0, wave, lane);
+#else
+      fetch_tailw<NW, 1>(tab0, wave, lane);
+#endif
       for (int i = tid; i < NW * XB / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
       SYNC_BATCH();
       if (wave < nb) tail_chain<NW>(wave * XB, prm.scratch + ((long)blockIdx.x * NW + wave) * PARK_BYTES, prm.out + (base + wave * G) * (7 * 7 * 18), lane);
