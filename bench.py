@@ -37,6 +37,8 @@ VALU_CYCLES_PER_INSTR = 4.0                  # issue cost of a wave64 VALU instr
                                              # ops, 2.3-2.7 for add/and/shift/mov (profiles/r01_e_valu_issue_rates.txt)
 A160_BYTES_PER_FRAME = 160 * 160 * 3 + 20 * 20 * 18          # 84 000 B: algorithmic bytes of the 160x160 variant
 FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp32 logits out
+PROFILE_160 = "profiles/r05_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
+PROFILE_FP16 = "profiles/r05_fp16/summary.json"              # stamped with the build id they were taken on
 
 
 def kernel_source_hash():
@@ -115,12 +117,9 @@ def settle(fn, ms):
         torch.cuda.synchronize()
 
 
-def secondary_configs(net, dev, stream, settle_ms=60.0):
-    """BASELINE configs[4] (160x160, batch 1024) and configs[3] (fp16, batch 4096), timed after the headline region with
-    HIP events on the launch stream, each after the headline's clock settle (`settle`).  Parity of both is the job of
-    tests/test_gpu_parity.py; here only time."""
+def secondary_160(net, dev, stream, settle_ms=60.0, iters=20):
+    """BASELINE configs[4]: 160x160, batch 1024 (three banded launches per step)."""
     sp = stream.cuda_stream
-    out = {}
     rng = np.random.default_rng(4)
     n = 1024
     d_in = torch.from_numpy(rng.integers(-128, 128, (n, 160, 160, 3), dtype=np.int8)).to(dev)
@@ -129,20 +128,27 @@ def secondary_configs(net, dev, stream, settle_ms=60.0):
     for _ in range(3):
         run()
     settle(run, settle_ms)
-    ms = event_time_ms(stream, run, 20)
+    ms = event_time_ms(stream, run, iters)
     gbs = n * A160_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
-    out["int8_160x160"] = {"workload": "BASELINE configs[4]: batch=1024 int8 160x160x3 frames, one GPU", "ms_per_step": round(ms, 4),
-                           "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * A160_BYTES_PER_FRAME,
-                           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
-                           "kernel": "band_k1, band_k23, band_k4: three launches, each a group of fused stages over row bands staged through LDS (DESIGN.md, 160x160)",
-                           "kernel_source_hash": kernel_source_hash()}
-    prof, why = stamped_profile("profiles/r04_160/summary.json", lambda d: d.get("total", {}).get("source_hash"))
-    out["int8_160x160"]["roofline"]["traffic"] = round(prof["total"]["hbm_bytes_per_batch"]) if prof else None
-    out["int8_160x160"]["roofline"]["traffic_source" if prof else "traffic_missing"] = \
-        "profiles/r04_160/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 1024-frame batch)" if prof else why
-    del d_in, d_out
-    # camera-format pipeline: 112x112 RGB565 frames -> heads + firmware-mode boxes, the frame preparation
-    # fused into the kernel's input staging (ONE launch) against the two-launch form (separate preparation kernel)
+    res = {"workload": "BASELINE configs[4]: batch=1024 int8 160x160x3 frames, one GPU", "ms_per_step": round(ms, 4), "timed_steps": iters,
+           "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * A160_BYTES_PER_FRAME,
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
+           "kernel": "band_k1, band_k23, band_k4: three launches, each a group of fused stages over row bands staged through LDS (DESIGN.md, 160x160)",
+           "kernel_source_hash": kernel_source_hash()}
+    prof, why = stamped_profile(PROFILE_160, lambda d: d.get("total", {}).get("source_hash"))
+    res["roofline"]["traffic"] = round(prof["total"]["hbm_bytes_per_batch"]) if prof else None
+    res["roofline"]["traffic_source" if prof else "traffic_missing"] = \
+        f"{PROFILE_160} (FETCH_SIZE / WRITE_SIZE passes, bytes per 1024-frame batch)" if prof else why
+    if prof and prof["total"].get("timed_kernel_us_sum"):
+        res["roofline"]["kernel_us_in_trace"] = round(prof["total"]["timed_kernel_us_sum"], 2)     # the three kernels of a step, timed launches of the profiled bench command
+    return res
+
+
+def secondary_camera(net, dev, stream, settle_ms=60.0, iters=20):
+    """Camera-format pipeline: 112x112 RGB565 frames -> heads + firmware-mode boxes, the frame preparation fused
+    into the kernel's input staging (ONE launch) against the two-launch form (separate preparation kernel)."""
+    sp = stream.cuda_stream
+    rng = np.random.default_rng(5)
     n = 4096
     d_raw = torch.from_numpy(rng.integers(0, 256, (n, 112 * 112 * 2), dtype=np.uint8)).to(dev)
     d_x = torch.zeros((n, 56, 56, 3), dtype=torch.int8, device=dev)
@@ -157,11 +163,16 @@ def secondary_configs(net, dev, stream, settle_ms=60.0):
     for _ in range(3):
         one(); two()
     settle(one, settle_ms)
-    ms1, ms2 = event_time_ms(stream, one, 20), event_time_ms(stream, two, 20)
-    out["camera_rgb565_112x112"] = {"workload": "batch=4096 camera frames (112x112 big-endian RGB565, 25 088 B each) -> int8 heads + firmware-mode boxes",
-                                    "ms_per_step": round(ms1, 4), "images_per_s": round(n / ms1 * 1e3, 1),
-                                    "two_launch_form_ms_per_step": round(ms2, 4), "two_launch_form_images_per_s": round(n / ms2 * 1e3, 1)}
-    del d_raw, d_x, d_h, d_d, d_c
+    ms1, ms2 = event_time_ms(stream, one, iters), event_time_ms(stream, two, iters)
+    return {"workload": "batch=4096 camera frames (112x112 big-endian RGB565, 25 088 B each) -> int8 heads + firmware-mode boxes",
+            "ms_per_step": round(ms1, 4), "timed_steps": iters, "images_per_s": round(n / ms1 * 1e3, 1),
+            "two_launch_form_ms_per_step": round(ms2, 4), "two_launch_form_images_per_s": round(n / ms2 * 1e3, 1)}
+
+
+def secondary_fp16(net, dev, stream, settle_ms=60.0, iters=20):
+    """BASELINE configs[3]: fp16 weights of the reference's ONNX export, batch 4096, one fused launch per step."""
+    sp = stream.cuda_stream
+    rng = np.random.default_rng(6)
     n = 4096
     net.fp16_init()
     d_in = torch.from_numpy((rng.integers(0, 256, (n, 56, 56, 3)).astype(np.float32) / 255).astype(np.float16)).to(dev)
@@ -170,17 +181,30 @@ def secondary_configs(net, dev, stream, settle_ms=60.0):
     for _ in range(3):
         run()
     settle(run, settle_ms)
-    ms = event_time_ms(stream, run, 20)
+    ms = event_time_ms(stream, run, iters)
     gbs = n * FP16_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
-    out["fp16_56x56"] = {"workload": "BASELINE configs[3]: batch=4096 fp16 56x56x3 frames (weights of the reference's ONNX export), one GPU",
-                         "ms_per_step": round(ms, 4), "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * FP16_BYTES_PER_FRAME,
-                         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
-                         "dtype": "f16 (f32 accumulate)", "kernel": "yoloface56_f16_fused<8>", "kernel_source_hash": kernel_source_hash()}
-    prof, why = stamped_profile("profiles/r04_fp16/summary.json", lambda d: d.get("source_hash"))
-    out["fp16_56x56"]["roofline"]["traffic"] = round(prof["hbm_bytes_per_launch"]) if prof else None
-    out["fp16_56x56"]["roofline"]["traffic_source" if prof else "traffic_missing"] = \
-        "profiles/r04_fp16/summary.json (FETCH_SIZE / WRITE_SIZE passes, bytes per 4096-frame launch)" if prof else why
-    return out
+    res = {"workload": "BASELINE configs[3]: batch=4096 fp16 56x56x3 frames (weights of the reference's ONNX export), one GPU",
+           "ms_per_step": round(ms, 4), "timed_steps": iters, "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * FP16_BYTES_PER_FRAME,
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)},
+           "dtype": "f16 (f32 accumulate)", "kernel": "yoloface56_f16_fused<8>", "kernel_source_hash": kernel_source_hash()}
+    prof, why = stamped_profile(PROFILE_FP16, lambda d: d.get("source_hash"))
+    res["roofline"]["traffic"] = round(prof["hbm_bytes_per_launch"]) if prof else None
+    res["roofline"]["traffic_source" if prof else "traffic_missing"] = \
+        f"{PROFILE_FP16} (FETCH_SIZE / WRITE_SIZE passes, bytes per 4096-frame launch)" if prof else why
+    if prof and prof.get("trace", {}).get("timed_avg_us"):
+        res["roofline"]["kernel_us_in_trace"] = round(prof["trace"]["timed_avg_us"], 2)        # timed launches of the profiled bench command
+    return res
+
+
+SECONDARY = {"int8_160x160": secondary_160, "camera_rgb565_112x112": secondary_camera, "fp16_56x56": secondary_fp16}
+
+
+def secondary_configs(net, dev, stream, settle_ms=60.0, iters=20, only=None):
+    """The side configurations of BASELINE.json, timed after the headline region with HIP events on the launch stream, each after the
+    headline's clock settle (`settle`).  Parity of all of them is the job of tests/test_gpu_parity.py; here only time.  `only` = one
+    section's name: what `bench.py --only-secondary NAME` runs, which is the command the rocprofv3 summaries under profiles/r05_* are
+    taken on -- the kernel time of a secondary line and its trace come from ONE command in ONE clock regime."""
+    return {name: fn(net, dev, stream, settle_ms, iters) for name, fn in SECONDARY.items() if only in (None, name)}
 
 
 def self_launch(n_ranks):
@@ -213,6 +237,10 @@ def main():
     ap.add_argument("--det-cap", type=int, default=4, help="detection records kept (and exchanged) per frame; the count is always the true count")
     ap.add_argument("--gather-heads", action="store_true", help="also all-gather the int8 heads (882 B per frame) at N > 1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 160x160 and fp16 side configurations")
+    ap.add_argument("--only-secondary", choices=sorted(SECONDARY), default=None,
+                    help="run ONLY this side configuration (after the same clock settle) and print its line: the command the rocprofv3 "
+                         "summaries of the secondaries are taken on (tools/profile_secondary.sh), N = 1 only")
+    ap.add_argument("--secondary-iters", type=int, default=20, help="timed steps of each side configuration")
     ap.add_argument("--clock-settle-ms", type=float, default=60.0,
                     help="before the W warm-up steps keep the GPU busy with untimed launches of the same kernel for this long: a GPU "
                          "that has idled runs its first ~10 ms at a lower engine clock (tools/step_probe.py), and W = 5 steps are 1 ms; 0 = off")
@@ -239,6 +267,14 @@ def main():
     yf = importlib.import_module("stm32h7-yolo_amd")
     sharding = importlib.import_module("stm32h7-yolo_amd.sharding")
     net = yf.Network(device=dev_index, frames_per_wg=args.frames_per_wg, waves_per_wg=args.waves_per_wg).init()
+
+    if args.only_secondary:
+        if world != 1:
+            raise SystemExit("--only-secondary is a one-GPU run")
+        sec = secondary_configs(net, dev, torch.cuda.current_stream(), args.clock_settle_ms, args.secondary_iters, only=args.only_secondary)
+        print(json.dumps({"only_secondary": args.only_secondary, "n_gpus": 1, "clock_settle_ms": args.clock_settle_ms, "data": "synthetic",
+                          "secondary": sec}), flush=True)
+        return
 
     n, n_total = FRAMES_PER_GPU, FRAMES_PER_GPU * world
     a, b = sharding.shard_range(n_total, rank, world)
@@ -448,7 +484,7 @@ def main():
             if mism or problems:
                 fail = f"GPU result differs from the oracle ({mism} head bytes; {problems})"
             elif not args.no_secondary:
-                line["secondary"] = secondary_configs(net, dev, stream, args.clock_settle_ms)
+                line["secondary"] = secondary_configs(net, dev, stream, args.clock_settle_ms, args.secondary_iters)
         else:
             line["all_gather_ok"] = ok_gather
             line["parity"] = "every rank: heads of its first 256 frames and decoded records of its first 64 frames equal the oracle; golden detections equal tests/golden" \

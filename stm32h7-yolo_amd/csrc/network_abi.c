@@ -15,6 +15,7 @@
 #include "yf_host_prep.h"
 #include "yf_impl.h"
 #include "yf_fp16.h"
+#include "gen/yf_model_gen.h"
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -32,6 +33,9 @@ typedef struct {
   yf_fp16* fp16;
   int device;
   int cfg_frames, cfg_waves;
+  ai_platform_version tools_api;          /* what the network was created with (network.c:3376: AI_TOOLS_API_VERSION_*); reports return it */
+  const void* bound_weights;              /* what ai_network_init was handed: the reports describe these buffers */
+  ai_handle bound_activations;
   char err_text[512];
 } yf_context;
 
@@ -49,6 +53,7 @@ void yf_impl_fail_init(ai_handle network, unsigned code, const char* text) {
   if (c) latch(c, AI_ERROR_INIT_FAILED, code, text);
 }
 
+static ai_platform_version version3(unsigned a, unsigned b, unsigned c);
 static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = type; e.code = code; return e; }
 
 /* ------------------------------------------------------------------------------------------------ create / destroy */
@@ -62,6 +67,7 @@ ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
   memset(&g_network, 0, sizeof g_network);
   g_network.state = ST_CREATED;
   g_network.device = dev; g_network.cfg_frames = cf; g_network.cfg_waves = cw;
+  g_network.tools_api = version3(YF_REPORT_TOOLS_API_VERSION);
   *network = (ai_handle)&g_network;
   return mk_error(AI_ERROR_NONE, AI_ERROR_CODE_NONE);
 }
@@ -143,6 +149,8 @@ ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
     }
   }
   c->state = ST_READY;
+  c->bound_weights = blob;
+  c->bound_activations = act ? act->data : NULL;
   return true;
 }
 
@@ -208,35 +216,69 @@ void yf_impl_fail_run(ai_handle network, unsigned code, const char* text) {
 /* ------------------------------------------------------------------------------------------------ report */
 static ai_buffer g_io_in = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_IN_1_HEIGHT, AI_NETWORK_IN_1_WIDTH, AI_NETWORK_IN_1_CHANNEL, NULL, NULL };
 static ai_buffer g_io_out = { AI_BUFFER_FORMAT_S8, 1, AI_NETWORK_OUT_1_HEIGHT, AI_NETWORK_OUT_1_WIDTH, AI_NETWORK_OUT_1_CHANNEL, NULL, NULL };
+static ai_buffer g_rep_weights[1], g_rep_activations[1];     /* what a report's map_weights / map_activations point at */
 
-ai_bool yf_impl_get_report(ai_handle network, ai_network_report* report) {
+static ai_platform_version version3(unsigned a, unsigned b, unsigned c) { ai_platform_version v; v.major = (ai_u8)a; v.minor = (ai_u8)b; v.micro = (ai_u8)c; v.reserved = 0; return v; }
+const char* yf_impl_runtime_revision(void) { return "yf-mi355x (gfx950 fused int8 engine)"; }
+ai_platform_version yf_impl_runtime_version(void) { return version3(0, 1, 0); }
+ai_platform_version yf_impl_api_version(void) { return version3(YF_REPORT_PLATFORM_API_VERSION); }          /* AI_PLATFORM_API_VERSION, network_config.h:33-38 */
+ai_platform_version yf_impl_interface_api_version(void) { return version3(1, 3, 0); }                       /* AI_PLATFORM_INTERFACE_API 1.3.0 of the 7.0.0 runtime */
+
+void yf_impl_set_tools_api_version(ai_handle network, unsigned major, unsigned minor, unsigned micro) {
   yf_context* c = acquire(network);
-  if (!c || !report) return false;
-  memset(report, 0, sizeof *report);
-  report->model_name = "network";                         /* AI_NETWORK_MODEL_NAME, network.h:29 */
-  report->model_signature = "yoloface_int8";              /* origin model, network.h:30 */
-  report->model_datetime = "";
-  report->compile_datetime = __DATE__ " " __TIME__;
-  report->runtime_revision = "yf-mi355x (gfx950 fused int8 engine)";
-  report->runtime_version.major = 0; report->runtime_version.minor = 1;
-  report->tool_revision = "tools/gen_model.py";
-  report->tool_version.major = 7;                         /* X-CUBE-AI 7.0.0 generated the reference tables */
-  report->tool_api_version.major = 1; report->tool_api_version.minor = 4;
-  report->api_version.major = 1; report->api_version.minor = 1;
-  report->interface_api_version.major = 1; report->interface_api_version.minor = 3;
-  report->n_macc = 1344320;                               /* network.c:3298, network_generate_report.txt:20 */
-  report->n_inputs = 1; report->n_outputs = 1;
-  report->inputs = &g_io_in; report->outputs = &g_io_out;
-  report->params.format = (ai_buffer_format)(AI_BUFFER_FORMAT_U8 | AI_BUFFER_FMT_FLAG_CONST);
-  report->params.n_batches = 1; report->params.height = 1; report->params.width = 1; report->params.channels = AI_NETWORK_DATA_WEIGHTS_SIZE;
-  report->activations.format = AI_BUFFER_FORMAT_U8;
-  report->activations.n_batches = 1; report->activations.height = 1; report->activations.width = 1; report->activations.channels = AI_NETWORK_DATA_ACTIVATIONS_SIZE;
-  report->n_nodes = AI_NETWORK_N_NODES;
-  report->signature = 0;
+  if (c) c->tools_api = version3(major, minor, micro);
+}
+
+/* The RUNTIME's half of a report (the closed library's ai_platform_api_get_network_report, ai_platform_interface.h:818-825, which the reference's
+ * network.c:3307,3352 calls on a report it has pre-filled): I/O descriptors, node count, the tools API version the network was created with, and the
+ * buffer description in the arm of the union the caller asked for -- ai_network_get_report pre-sets map_signature = AI_MAGIC_SIGNATURE
+ * (network.c:3346) and gets map_weights / map_activations, the deprecated ai_network_get_info leaves it 0 (network.c:3301-3302) and gets the legacy
+ * params / activations pair.  data = what ai_network_init was given (NULL before it). */
+ai_bool yf_impl_fill_report(ai_handle network, ai_network_report* r) {
+  yf_context* c = acquire(network);
+  if (!c || !r) return false;
+  const ai_buffer w = { (ai_buffer_format)(AI_BUFFER_FORMAT_U8 | AI_BUFFER_FMT_FLAG_CONST), 1, 1, 1, AI_NETWORK_DATA_WEIGHTS_SIZE, (ai_handle)c->bound_weights, NULL };
+  const ai_buffer a = { AI_BUFFER_FORMAT_U8, 1, 1, 1, AI_NETWORK_DATA_ACTIVATIONS_SIZE, c->bound_activations, NULL };
+  r->tool_api_version = c->tools_api;
+  r->n_inputs = 1; r->n_outputs = 1;
+  r->inputs = &g_io_in; r->outputs = &g_io_out;
+  if (r->map_signature == (ai_signature)AI_MAGIC_SIGNATURE) {
+    g_rep_weights[0] = w; g_rep_activations[0] = a;
+    r->map_weights.flags = 0; r->map_weights.size = 1; r->map_weights.buffer = g_rep_weights;
+    r->map_activations.flags = 0; r->map_activations.size = 1; r->map_activations.buffer = g_rep_activations;
+  } else {
+    r->params = w; r->activations = a;
+  }
+  r->n_nodes = AI_NETWORK_N_NODES;
+  r->signature = 0;
   return true;
 }
 
-
+/* network.c's half (network.c:3271-3361): the identity of the generated model, as the #defines of the reference's generated files give it
+ * (gen/yf_model_gen.h, written by tools/gen_model.py).  compile_datetime is this library's. */
+static ai_bool report(ai_handle network, ai_network_report* out, int buffer_maps) {
+  yf_context* c = acquire(network);
+  if (!c || !out) return false;
+  ai_network_report r;
+  memset(&r, 0, sizeof r);
+  r.model_name = YF_REPORT_MODEL_NAME;
+  r.model_signature = YF_REPORT_MODEL_SIGNATURE;
+  r.model_datetime = YF_REPORT_MODEL_DATETIME;
+  r.compile_datetime = __DATE__ " " __TIME__;
+  r.runtime_revision = yf_impl_runtime_revision();
+  r.runtime_version = yf_impl_runtime_version();
+  r.tool_revision = YF_REPORT_TOOLS_REVISION_ID;
+  r.tool_version = version3(YF_REPORT_TOOLS_VERSION);
+  r.api_version = yf_impl_api_version();
+  r.interface_api_version = yf_impl_interface_api_version();
+  r.n_macc = YF_REPORT_N_MACC;                           /* network.c:3298, network_generate_report.txt:20 */
+  if (buffer_maps) r.map_signature = (ai_signature)AI_MAGIC_SIGNATURE;
+  if (!yf_impl_fill_report(network, &r)) return false;
+  *out = r;
+  return true;
+}
+ai_bool yf_impl_get_report(ai_handle network, ai_network_report* r) { return report(network, r, 1); }
+ai_bool yf_impl_get_info(ai_handle network, ai_network_report* r) { return report(network, r, 0); }
 
 /* ------------------------------------------------------------------------------------------------ public boundary
  * Thin wrappers: the implementations above carry private names so that the runtime-level entry points
@@ -249,7 +291,7 @@ YF_API ai_bool   ai_network_init(ai_handle network, const ai_network_params* par
 YF_API ai_i32    ai_network_run(ai_handle network, const ai_buffer* input, ai_buffer* output) { return yf_impl_run(network, input, output); }
 YF_API ai_i32    ai_network_forward(ai_handle network, const ai_buffer* input) { return yf_impl_forward(network, input); }
 YF_API ai_bool   ai_network_get_report(ai_handle network, ai_network_report* report) { return yf_impl_get_report(network, report); }
-YF_API ai_bool   ai_network_get_info(ai_handle network, ai_network_report* report) { return yf_impl_get_report(network, report); }
+YF_API ai_bool   ai_network_get_info(ai_handle network, ai_network_report* report) { return yf_impl_get_info(network, report); }
 
 /* ------------------------------------------------------------------------------------------------ network_data */
 YF_API ai_handle ai_network_data_weights_get(void) {

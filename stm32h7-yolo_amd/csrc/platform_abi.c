@@ -33,13 +33,13 @@ YF_API void* ai_platform_context_acquire(const ai_handle handle) { return own(ha
 YF_API ai_error ai_platform_network_create(ai_handle* network, const ai_buffer* network_config, void* net_ctx,
                                            const ai_u8 tool_major, const ai_u8 tool_minor, const ai_u8 tool_micro) {
   ai_error e; e.type = AI_ERROR_NONE; e.code = AI_ERROR_CODE_NONE;
-  (void)tool_minor; (void)tool_micro;
   if (!network || !net_ctx) { e.type = AI_ERROR_CREATE_FAILED; e.code = AI_ERROR_CODE_INVALID_PTR; return e; }
   if (tool_major != 1) {                       /* tools API 1.x generated the reference model (network_config.h:34-46) */
     *network = AI_HANDLE_NULL; e.type = AI_ERROR_TOOL_PLATFORM_API_MISMATCH; e.code = AI_ERROR_CODE_NETWORK; return e;
   }
   e = yf_impl_create(&g_own, network_config);
   if (e.type != AI_ERROR_NONE) { *network = AI_HANDLE_NULL; return e; }
+  yf_impl_set_tools_api_version(g_own, tool_major, tool_minor, tool_micro);     /* reports return it as tool_api_version */
   g_tag = net_ctx;
   *network = (ai_handle)net_ctx;
   return e;
@@ -370,20 +370,13 @@ YF_API ai_bool ai_platform_get_activations_map(ai_ptr* map, const ai_size map_si
 /* network.c:3317-3361 pre-fills names, dates and MACC; the runtime completes I/O descriptors and counts */
 YF_API ai_bool ai_platform_api_get_network_report(ai_handle network, ai_network_report* r) {
   if (!own(network) || !r) return false;
-  ai_network_report mine;
-  if (!yf_impl_get_report(g_own, &mine)) return false;
-  r->n_inputs = mine.n_inputs; r->n_outputs = mine.n_outputs;
-  r->inputs = mine.inputs; r->outputs = mine.outputs;
-  r->n_nodes = mine.n_nodes;
-  r->signature = 0;
-  return true;
+  return yf_impl_fill_report(g_own, r);          /* same function as behind this library's own ai_network_get_report / get_info */
 }
 
-YF_API const char* ai_platform_runtime_get_revision(void) { return "yf-mi355x (gfx950 fused int8 engine)"; }
-static ai_platform_version ver(unsigned a, unsigned b, unsigned c) { ai_platform_version v; v.major = (ai_u8)a; v.minor = (ai_u8)b; v.micro = (ai_u8)c; v.reserved = 0; return v; }
-YF_API ai_platform_version ai_platform_runtime_get_version(void) { return ver(0, 1, 0); }
-YF_API ai_platform_version ai_platform_api_get_version(void) { return ver(1, 1, 0); }
-YF_API ai_platform_version ai_platform_interface_api_get_version(void) { return ver(1, 3, 0); }
+YF_API const char* ai_platform_runtime_get_revision(void) { return yf_impl_runtime_revision(); }
+YF_API ai_platform_version ai_platform_runtime_get_version(void) { return yf_impl_runtime_version(); }
+YF_API ai_platform_version ai_platform_api_get_version(void) { return yf_impl_api_version(); }
+YF_API ai_platform_version ai_platform_interface_api_get_version(void) { return yf_impl_interface_api_version(); }
 
 /* Layer kernels of the ST runtime: network.c stores their addresses in its layer objects (network.c:2204-2927) but
  * nothing on this path ever calls them -- the fused engine replaces the node walk.  Calling one is a usage error. */

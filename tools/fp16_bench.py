@@ -10,7 +10,12 @@ x = (np.random.default_rng(3).integers(0, 256, (n, 56, 56, 3)).astype(np.float32
 net = yf.Network().init()
 net.fp16_init()
 d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros((n, 7, 7, 18), dtype=torch.float32, device="cuda")
-for _ in range(60): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+# the same clock settle as bench.py's (an idle GPU ramps its clock over ~10 ms: 60 launches = 8 ms would leave the timed loop inside the ramp)
+SETTLE_MS = float(os.environ.get("YF_SETTLE_MS", "60"))
+t0 = time.perf_counter()
+while (time.perf_counter() - t0) * 1e3 < SETTLE_MS:
+    for _ in range(8): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(50): net.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50

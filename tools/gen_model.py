@@ -108,6 +108,29 @@ def st_luts():
     return out
 
 
+def st_report_identity():
+    """The identity fields ai_network_get_report / get_info return (reference network.c:38-49,3271-3361): values of the #defines in the generated
+    files network.c / network.h / network_config.h, read as DATA (the library must answer with the same strings and numbers)."""
+    def define(path, name, pattern=r'"([^"]*)"'):
+        src = open(path, encoding="latin-1").read()
+        found = re.findall(rf"#define\s+{name}\s+\(?{pattern}\)?", src)
+        assert found, (path, name)
+        return found[-1]
+    app = os.path.dirname(NETC)
+    num = r"(\d+)"
+    ident = {"MODEL_NAME": define(f"{app}/network.h", "AI_NETWORK_MODEL_NAME"),
+             "ORIGIN_MODEL_NAME": define(f"{app}/network.h", "AI_NETWORK_ORIGIN_MODEL_NAME"),
+             "MODEL_SIGNATURE": define(NETC, "AI_NETWORK_MODEL_SIGNATURE"),
+             "MODEL_DATETIME": define(NETC, "AI_TOOLS_DATE_TIME"),
+             "TOOLS_REVISION_ID": define(NETC, "AI_TOOLS_REVISION_ID")}
+    vers = {"TOOLS_VERSION": [int(define(f"{app}/network_config.h", f"AI_TOOLS_VERSION_{p}", num)) for p in ("MAJOR", "MINOR", "MICRO")],
+            "TOOLS_API_VERSION": [int(define(f"{app}/network_config.h", f"AI_TOOLS_API_VERSION_{p}", num)) for p in ("MAJOR", "MINOR", "MICRO")],
+            "PLATFORM_API_VERSION": [int(define(f"{app}/network_config.h", f"AI_PLATFORM_API_{p}", num)) for p in ("MAJOR", "MINOR", "MICRO")]}
+    macc = set(re.findall(r"\.n_macc\s*=\s*(\d+)", open(NETC, encoding="latin-1").read()))
+    assert len(macc) == 1
+    return ident, vers, int(macc.pop())
+
+
 def st_blob():
     src = open(NETD, encoding="latin-1").read()
     body = src[src.index("s_network_weights_array_u64"):]
@@ -174,6 +197,14 @@ def main():
                 "#ifndef YF_MODEL_GEN_H\n#define YF_MODEL_GEN_H\n#include <stdint.h>\n\n"
                 f"#define YF_N_TENSORS {len(T)}\n#define YF_N_CONVS {len(conv_rows)}\n"
                 "#define YF_WEIGHTS_BLOB_BYTES 11304\n\n")
+        ident, vers, macc = st_report_identity()
+        f.write("/* what ai_network_get_report / ai_network_get_info answer (reference network.c:38-49,3271-3361; network.h:29-30;\n"
+                " * network_config.h:25-46): the #define values of the generated reference files */\n")
+        for k, v in ident.items():
+            f.write(f'#define YF_REPORT_{k} "{v}"\n')
+        for k, v in vers.items():
+            f.write(f"#define YF_REPORT_{k} {v[0]}, {v[1]}, {v[2]}\n")
+        f.write(f"#define YF_REPORT_N_MACC {macc}u\n\n")
         f.write("static const uint32_t yf_tensor_scale_bits[YF_N_TENSORS] = {\n")
         for k in range(0, len(T), 6):
             f.write("  " + ", ".join(f"0x{f32bits(t['scale'][0]) if len(t['scale']) else 0:08x}u" for t in T[k:k + 6]) + ",\n")

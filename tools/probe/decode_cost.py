@@ -14,8 +14,11 @@ def run(decode, k):
     x = ins[k % 8]
     if decode: net.run_decode_device(x.data_ptr(), d_out.data_ptr(), n, d_dets.data_ptr(), d_cnt.data_ptr(), cap)
     else: net.run_device(x.data_ptr(), d_out.data_ptr(), n)
-for k in range(400): run(k & 1, k)
-torch.cuda.synchronize()
+import time
+t0, k = time.perf_counter(), 0      # the same clock settle as bench.py's: untimed launches for 60 ms
+while (time.perf_counter() - t0) * 1e3 < float(os.environ.get("YF_SETTLE_MS", "60")):
+    for _ in range(8): run(k & 1, k); k += 1
+    torch.cuda.synchronize()
 res = {0: [], 1: []}
 for rnd in range(10):
     for dec in (0, 1):
