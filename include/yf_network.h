@@ -150,7 +150,11 @@ YF_API ai_i32    ai_network_forward(ai_handle network, const ai_buffer* input);
 YF_API ai_error  ai_network_get_error(ai_handle network);
 /* replaces network.c:3379-3383 */
 YF_API ai_handle ai_network_destroy(ai_handle network);
-/* replace network.c:3271-3361 */
+/* replace network.c:3271-3361.  Field for field what the reference's generated file answers: model_name "network", model_signature /
+ * model_datetime / tool_revision = AI_NETWORK_MODEL_SIGNATURE / AI_TOOLS_DATE_TIME / AI_TOOLS_REVISION_ID of network.c:38-46, tool_version
+ * 7.0.0, tool_api_version 1.4.0, api_version 1.1.0 (network_config.h:25-46), n_macc 1344320; get_report describes the buffers as
+ * map_signature / map_weights / map_activations (network.c:3346-3348), the deprecated get_info as the legacy params / activations pair
+ * (network.c:3301-3302).  compile_datetime, runtime_revision and runtime_version are this library's own. */
 YF_API ai_bool   ai_network_get_info(ai_handle network, ai_network_report* report);
 YF_API ai_bool   ai_network_get_report(ai_handle network, ai_network_report* report);
 /* replace network_data.c:393-403 and :412-432 (this library ships its own copy of the weight blob) */

@@ -65,8 +65,36 @@ def test_reference_network_data_links_against_library():
     exe = os.path.join(ROOT, "oracle", "_ref", "abi_ref_caller")
     undefined = subprocess.check_output(["nm", "-u", exe]).decode()
     needed = sorted(set(re.findall(r"U (ai_\w+)", undefined)))
-    assert needed == ["ai_network_create", "ai_network_destroy", "ai_network_get_error", "ai_network_get_report",
+    assert needed == ["ai_network_create", "ai_network_destroy", "ai_network_get_error", "ai_network_get_info", "ai_network_get_report",
                       "ai_network_init", "ai_network_run", "ai_platform_bind_network_params"]
+
+
+def _report_lines(binary, *args):
+    exe = os.path.join(ROOT, "oracle", "_ref", binary)
+    r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return [ln for ln in r.stdout.splitlines() if ln.startswith(("report[", "info["))]
+
+
+@pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
+def test_reports_equal_the_reference_network_c_field_for_field():
+    """ai_network_get_report / ai_network_get_info (row a4): abi_ref_caller asks THIS library's functions, abi_ref_runtime_caller the reference's own
+    generated network.c:3271-3361 (which pre-fills a report and hands it to ai_platform_api_get_network_report, here platform_abi.c).  Every string
+    and integer of both reports must be equal -- model signature, date, tool revision, the three versions, the arm of the params union each call
+    fills -- except compile_datetime (the compile time of network.c / of this library)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    mine, ref = _report_lines("abi_ref_caller", "report"), _report_lines("abi_ref_runtime_caller", "report")
+    assert len(mine) == len(ref) == 23 + 20
+    keep = lambda lines: [ln for ln in lines if ".compile_datetime " not in ln]      # noqa: E731
+    assert keep(mine) == keep(ref)
+    d = dict(ln.split(" ", 1) for ln in mine)
+    # ... and against the #defines of the reference's generated files themselves (network.c:38-49, network_config.h:25-46)
+    netc = open("/root/reference/stm32/X-CUBE-AI/App/network.c", encoding="latin-1").read()
+    assert d["report[created].model_signature"] == re.search(r'#define AI_NETWORK_MODEL_SIGNATURE\s+"(\w+)"', netc).group(1)
+    assert d["report[created].model_datetime"] == re.search(r'#define AI_TOOLS_DATE_TIME\s+"([^"]+)"', netc).group(1)
+    assert d["report[created].tool_revision"] == "[]" and d["report[created].tool_version"] == "7.0.0.0" and d["report[created].tool_api_version"] == "1.4.0.0"
+    assert d["report[created].map_signature"] == "0xa1facade" and "info[created].map_signature" not in d
+    assert d["info[created].params"].startswith("format=0x40040440 n_batches=1 height=1 width=1 channels=11304")
 
 
 @pytest.mark.skipif(not has_reference(), reason="container only: needs /root/reference")
@@ -204,6 +232,9 @@ def test_handle_and_param_validation(yf):
     r = b.AiNetworkReport()
     assert lib.ai_network_get_report(h, ctypes.byref(r))
     assert r.model_name == b"network" and r.n_macc == 1344320 and r.n_nodes == 31 and r.n_inputs == 1
+    assert r.model_signature == b"6e73621b74e22de6d49ea182d7122906" and r.model_datetime == b"Thu Nov  6 21:23:50 2025" and r.tool_revision == b""
+    assert (r.tool_version.major, r.tool_version.minor, r.tool_version.micro) == (7, 0, 0) and (r.tool_api_version.major, r.tool_api_version.minor) == (1, 4)
+    assert (r.api_version.major, r.api_version.minor, r.interface_api_version.major, r.interface_api_version.minor) == (1, 1, 1, 3)
     assert (r.inputs[0].height, r.inputs[0].width, r.inputs[0].channels) == (56, 56, 3)
     assert (r.outputs[0].height, r.outputs[0].width, r.outputs[0].channels) == (7, 7, 18)
     assert lib.ai_network_destroy(h) is None

@@ -741,6 +741,27 @@ def test_reference_header_caller_binary(golden, tmp_path, binary):
         assert np.array_equal(np.fromfile(fout, np.int8).reshape(6, 7, 7, 18), golden["heads"])
 
 
+def test_reports_of_a_running_network_equal_the_reference_network_c(tmp_path):
+    """Row a4 on the GPU box: after init + run, ai_network_get_report / ai_network_get_info of this library and of the reference's own generated
+    network.c (over platform_abi.c) print the same fields -- now with the weights / activations buffers bound --, compile_datetime excepted."""
+    outs = []
+    for binary in ("abi_ref_caller", "abi_ref_runtime_caller"):
+        exe = os.path.join(ROOT, "oracle", "_ref", binary)
+        if not os.path.exists(exe):
+            pytest.skip(f"oracle/_ref/{binary} was not built (needs /root/reference at build time)")
+        per_form = []
+        for extra in ([], ["map"]):
+            r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), str(tmp_path / "h.bin"), "6"] + extra, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            per_form.append([ln for ln in r.stdout.splitlines() if ln.startswith(("report[", "info[")) and ".compile_datetime " not in ln])
+        outs.append(per_form)
+    assert outs[0] == outs[1] and len(outs[0][0]) == 41
+    d = dict(ln.split(" ", 1) for ln in outs[0][0])
+    assert d["report[ready].model_signature"] == "6e73621b74e22de6d49ea182d7122906"
+    assert "data=set" in d["report[ready].map_weights.buffer[]"] and "data=set" in d["report[ready].map_activations.buffer[]"]
+    assert "data=set" in d["info[ready].params"] and "channels=29784 data=set" in d["info[ready].activations"]
+
+
 def test_per_node_observer_through_the_reference_headers(oracle, tmp_path):
     """oracle/_ref/abi_observer_probe = the reference's generated network.c (unchanged) + a client of ai_platform_observer_* written against
     the reference's headers (ai_platform_interface.h:684-731, 981-1024).  An observed ai_network_run calls the client before and after each
