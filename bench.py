@@ -74,26 +74,39 @@ def stamped_profile(rel_path, hash_of):
     return d, None
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(x, got_heads):
-    """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames,
-    3 repetitions (~20 s of CPU work); also the in-bench parity check of the GPU result."""
+    """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames, 3 repetitions (~20 s of CPU work);
+    also the in-bench parity check of the GPU result.  `value` is the MEDIAN of the repetitions; the best is reported beside
+    it, with what the box has: the cores this process may run on, the CPU model, the threads actually used."""
     from oracle.oracle import Oracle
     orc = Oracle()
-    cores = min(len(os.sched_getaffinity(0)), 16)     # a 1-GPU box's CPU share is 16 cores
-    reps, best = 3, None
+    affinity = len(os.sched_getaffinity(0))
+    cores = min(affinity, 16)                 # a 1-GPU box's CPU share is 16 cores
+    reps, times = 3, []
     ref = None
     for _ in range(reps):
         t0 = time.perf_counter()
         ref = orc.run(x, threads=cores)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        times.append(time.perf_counter() - t0)
+    median, best = sorted(times)[reps // 2], min(times)
     t0 = time.perf_counter()
     orc.run(x[:512], threads=1)
     one = 512 / (time.perf_counter() - t0)
     mism = int((ref != got_heads).sum())
-    return dict(value=round(x.shape[0] / best, 1), unit="images/s", cores=cores, kind="port",
-                sample=f"{reps} x {x.shape[0]} frames (the bench batch), best of {reps}, {cores} threads; "
-                       f"single thread: {one:.0f} images/s",
+    return dict(value=round(x.shape[0] / median, 1), unit="images/s", cores=cores, kind="port",
+                sample=f"{reps} x {x.shape[0]} frames (the bench batch), median of {reps}, {cores} threads of {affinity} usable "
+                       f"({os.cpu_count()} in the box, {cpu_model()}); best {x.shape[0] / best:.0f} images/s; single thread: {one:.0f} images/s",
+                best_images_per_s=round(x.shape[0] / best, 1), affinity_cores=affinity, box_cores=os.cpu_count(), cpu_model=cpu_model(),
                 single_thread_images_per_s=round(one, 1)), mism
 
 

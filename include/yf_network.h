@@ -299,6 +299,8 @@ YF_API const char* yf_network_kernel_name_for(ai_handle network, long n);
  * compiler flags they were built with (csrc/Makefile, BUILD_ID).  Profiles are stamped with it; bench.py reports counters of a
  * profile only when the stamp equals the id of the library it is running.  Host-only, no GPU. */
 YF_API const char* yf_network_build_id(void);
+/* ... and of the C host layer (sha256 over csrc/flags.mk HOST_SRCS and the C flags): binding.py checks both when it cannot run make */
+YF_API const char* yf_network_host_id(void);
 
 /* ---- per-node observer of the runtime-level interface (reference ai_platform_interface.h:684-731 datatypes, 981-1024 entry points).
  * Available to callers that link the reference's generated network.c against this library (the node list is theirs): an observed

@@ -88,7 +88,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_release_stream", "yf_network_scratch_bytes", "yf_network_last_error_text",
-           "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id",
+           "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id", "yf_network_host_id",
            "ai_platform_observer_node_info", "ai_platform_observer_register", "ai_platform_observer_register_s",
            "ai_platform_observer_unregister", "ai_platform_observer_unregister_s",
            # runtime-level boundary (csrc/platform_abi.c): what the reference's generated network.c references
@@ -115,13 +115,29 @@ def expected_build_id(extra_hipflags="", extra_fp16flags=""):
     return h.hexdigest()[:16]
 
 
+def expected_host_id():
+    """The id of the C host layer csrc/Makefile bakes into the library (yf_network_host_id): sha256 over HOST_SRCS and the C flags."""
+    import hashlib
+    import re
+    csrc = os.path.join(_PKG, "csrc")
+    flags = open(os.path.join(csrc, "flags.mk")).read()
+    srcs = re.search(r"^HOST_SRCS\s*=\s*(.*)$", flags, re.M).group(1).split()
+    cflags = re.search(r"^CFLAGS\s*=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1).strip()
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update((cflags + "\n").encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU).  One build at a time: the processes that share a checkout
-    (the two ranks of bench.py's self-launch, parallel test workers, profiler-wrapped tools) serialise on a lock file in the output directory."""
+    (the two ranks of bench.py's self-launch, parallel test workers, profiler-wrapped tools) serialise on a lock file beside the Makefile -- not
+    in the output directory, which `make clean` empties while a forced build holds the lock."""
     import fcntl
     out = os.path.join(_PKG, "lib")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, ".build.lock"), "w") as lk:
+    with open(os.path.join(_PKG, "csrc", ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         if force:
             subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "clean"], stdout=subprocess.DEVNULL)
@@ -171,7 +187,7 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise
             import warnings
-            warnings.warn(f"stm32h7-yolo_amd: could not run the build ({e}); loading the existing library after checking its build id")
+            warnings.warn(f"stm32h7-yolo_amd: could not run the build ({e}); loading the existing library after checking its device and host build ids")
             check_id = True
     _one_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
@@ -180,6 +196,10 @@ def load():
         have, want = (lib.yf_network_build_id() or b"").decode(), expected_build_id()
         if have != want:
             raise RuntimeError(f"{LIB_PATH} was built from other sources or flags (build id {have}, expected {want}) and cannot be rebuilt here")
+        lib.yf_network_host_id.restype = ctypes.c_char_p
+        have, want = (lib.yf_network_host_id() or b"").decode(), expected_host_id()
+        if have != want:
+            raise RuntimeError(f"{LIB_PATH}: its C host layer was built from other sources (host id {have}, expected {want}) and cannot be rebuilt here")
     vp, cl = ctypes.c_void_p, ctypes.c_long
     lib.ai_network_create.restype = AiError
     lib.ai_network_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(AiBuffer)]

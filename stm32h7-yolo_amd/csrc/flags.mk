@@ -10,3 +10,5 @@ HIPFLAGS_BASE = --offload-arch=gfx950 -Os -std=c++17 -fPIC -fvisibility=hidden -
 # iterative-ilp or max-ilp on top -1 %)
 FP16FLAGS_BASE = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wall -mllvm -disable-lsr
 DEVICE_SRCS = yf_engine.hip yf_kernels.hip.h yf_fused56.hip.h yf_band160.hip.h yf_lab_stages.hip.h yf_lab_layerwise.hip.h yf_decode.hip.h yf_tables.h yf_stream_scratch.h gen/yf_decode_tables_gen.h yf_fp16.hip yf_fp16.h
+# the C host layer: everything the library's HOST ID is computed from (Makefile: HOST_ID; binding.py: expected_host_id) -- a library with stale host code must not pass for current on a box without make
+HOST_SRCS = network_abi.c platform_abi.c yf_host_prep.c yf_host_prep.h yf_impl.h yf_engine.h yf_fp16.h st_graph_view.h yf_tables.h gen/yf_model_gen.h gen/yf_weights_blob_gen.c ../../include/yf_network.h

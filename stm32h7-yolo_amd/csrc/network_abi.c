@@ -539,6 +539,10 @@ YF_API const char* yf_network_last_error_text(ai_handle network) {
 }
 
 YF_API const char* yf_network_build_id(void) { return yf_engine_build_id(); }
+#ifndef YF_HOST_ID
+#define YF_HOST_ID "unknown"
+#endif
+YF_API const char* yf_network_host_id(void) { return YF_HOST_ID; }
 
 YF_API const char* yf_network_kernel_name(ai_handle network) {
   yf_context* c = acquire(network);

@@ -88,6 +88,10 @@ const Variant k_variants[] = {
 struct yf_engine {
   int device = 0;
   int cus = 0;
+  size_t lds_per_cu = 0;                         // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
+#ifdef YF_LAB
+  int fail_next_launch = 0;                      // laboratory: the next k fused launches get an invalid grid (tests the scratch lease on the failure path)
+#endif
   uint8_t* d_tab = nullptr;
   yf_table_index ix;
   const Variant* var = nullptr;
@@ -233,6 +237,9 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   if ((rc = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(rc, "hipGetDeviceProperties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return quit(std::string("unsupported GPU ") + prop.gcnArchName + " (this library is gfx950 only)", YF_ENG_ERR_NO_DEVICE);
   e->cus = prop.multiProcessorCount;
+  e->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;      // 160 KB on gfx950: how many workgroups of a shape a CU holds (grid size, scratch slots)
+  for (const Variant& v : k_variants)
+    if (e->lds_per_cu < v.lds) return quit("the device reports " + std::to_string(e->lds_per_cu) + " bytes of LDS per CU, " + v.name + " needs " + std::to_string(v.lds), YF_ENG_ERR_NO_DEVICE);
   {   // the kernels address the tables at compiled-in offsets (yf_kernels.hip.h, TablePlan): the blob must be laid out that way
     bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
     for (int i = 0; i < YF_N_DENSE; ++i) same = same && (int)ix->dense[i].w_off == yf::PLAN.w_off[i] && (int)ix->dense[i].c_off == yf::PLAN.c_off[i];
@@ -279,11 +286,14 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   };
   for (BandKernel& k : k_band_fused) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
   { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
+#ifdef YF_LAB
+  { const char* fl = getenv("YF_LAB_FAIL_LAUNCHES"); if (fl) e->fail_next_launch = atoi(fl); }
+#endif
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
     for (const Variant& v : k_variants) park = v.park > park ? v.park : park;
     size_t slots = 4;
-    for (const Variant& v : k_variants) { const size_t need = (163840 / v.lds) * (size_t)v.f; slots = need > slots ? need : slots; }   // (a lab what-if with overlapping arenas holds three workgroups per CU)
+    for (const Variant& v : k_variants) { const size_t need = (e->lds_per_cu / v.lds) * (size_t)v.f; slots = need > slots ? need : slots; }   // (a lab what-if with overlapping arenas holds three workgroups per CU)
     e->park_region = (size_t)e->cus * slots * park;      // allocated per stream on its first launch (launch())
   }
   if ((rc = hipStreamCreate(&e->own_stream)) != hipSuccess) return bail(rc, "hipStreamCreate");
@@ -389,19 +399,24 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   if (dec) { prm.dets = (yf_det*)dec->dets; prm.counts = (int*)dec->counts; prm.cap = dec->cap; prm.mode = dec->mode; prm.w_scale = dec->w_scale; prm.h_scale = dec->h_scale;
              prm.q_thr = yf_decode_q_threshold(dec->mode); }
   const long groups = (n + v->f - 1) / v->f;
-  const int per_cu = (int)(163840 / v->lds) > 0 ? (int)(163840 / v->lds) : 1;
+  const int per_cu = (int)(e->lds_per_cu / v->lds) > 0 ? (int)(e->lds_per_cu / v->lds) : 1;
   long grid = (long)e->cus * per_cu;
   if (grid > groups) grid = groups;
   prm.scratch = nullptr;
+  yf_stream_scratch::Lease lease;    // marks its region on EVERY way out of this function (a failed launch must not keep a region acquired)
   if (v->park) {   // tail batching: a workgroup parks one group's T15 (f frames) in HBM, slot = blockIdx.x.  The region belongs to
                    // the launch STREAM: launches on one stream serialise, launches on different streams never share bytes.
     const size_t need = (size_t)grid * v->f * v->park;
     if (need > e->park_region) { e->err = "tail scratch region too small for this kernel shape"; return YF_ENG_ERR_VARIANT; }
-    HIPCHK(e, e->park.get(s, e->park_region, &prm.scratch));
+    HIPCHK(e, e->park.get(s, e->park_region, &lease));
+    prm.scratch = lease.ptr;
   }
+#ifdef YF_LAB
+  if (e->fail_next_launch > 0) { --e->fail_next_launch; grid = 0; }    // laboratory only (YF_LAB_FAIL_LAUNCHES=k): an invalid grid for the first k launches, to rehearse the failure path below
+#endif
   hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->nw * 64), v->lds, s, prm);
   HIPCHK(e, hipGetLastError());
-  if (v->park) HIPCHK(e, e->park.mark(s));                   // the region is busy until this launch has completed (yf_stream_scratch.h)
+  HIPCHK(e, lease.mark());                                   // the region is busy until this launch has completed (yf_stream_scratch.h)
   return YF_ENG_OK;
 }
 
@@ -581,8 +596,9 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
 #else
   const size_t per_frame = (size_t)yf160::band::ARENA_BYTES;
 #endif
-  char* arena = nullptr;                                     // owned by the launch stream: overlapping launches never share it
-  HIPCHK(e, e->arena160.get((hipStream_t)stream, (size_t)cap * per_frame, &arena));
+  yf_stream_scratch::Lease lease;                            // owned by the launch stream: overlapping launches never share it; marked on every way out
+  HIPCHK(e, e->arena160.get((hipStream_t)stream, (size_t)cap * per_frame, &lease));
+  char* arena = lease.ptr;
   for (long done = 0; done < n; done += cap) {
     const long m = (n - done) < cap ? (n - done) : cap;
     int rc;
@@ -604,7 +620,7 @@ int yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long n
     }
     if (rc) return rc;
   }
-  HIPCHK(e, e->arena160.mark((hipStream_t)stream));
+  HIPCHK(e, lease.mark());
   return YF_ENG_OK;
 }
 

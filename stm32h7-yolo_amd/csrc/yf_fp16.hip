@@ -686,6 +686,10 @@ __device__ __forceinline__ void fetch_tailw(const uint8_t* __restrict__ tab, int
   static_assert(NW * XB + TAILW_BYTES <= LDS_TOTAL, "exchange buffers and resident tail weights fit the workgroup's LDS (arena and ring are dead in the tail phase; the arena is cleared before the next batch)");
   constexpr int NCHUNK = (TAILW_BYTES + 1023) / 1024, EARLY = tailw_early_chunks<NW>() < NCHUNK ? tailw_early_chunks<NW>() : NCHUNK;
   constexpr int J0 = PART == 1 ? EARLY : 0, J1 = PART == 0 ? EARLY : NCHUNK;
+  // PART 0 lands while the batch's last {pool_25 || conv2d_27} stage still READS T15 and the zero spot: its destination [NW * XB, NW * XB + EARLY KB) must lie
+  // above T15's last row and below the zero spot (and below the ring, which tailw_early_chunks bounds) -- whatever XB, NW or the arena plan become
+  static_assert(NW * XB >= B_T15::OFF + 15 * B_T15::ROWB, "the early tail-weight DMA must not land on T15, which the stage it is issued in still reads");
+  static_assert(NW * XB + EARLY * 1024 <= ZSLACK && NW * XB + EARLY * 1024 <= RING0, "the early tail-weight DMA must stay below the zero spot and the weight ring");
   for (int j = J0 + wave; j < J1; j += NW) {
     const int off = j * 1024 + lane * 16;
     if (off < TAILW_BYTES) {
@@ -1026,7 +1030,7 @@ namespace {
 
 struct yf_fp16 {
   int device = 0;
-  int cus = 0;
+  int cus = 0, wgs_per_cu = 2;
   uint8_t* d_tab = nullptr;
   yf_stream_scratch park; size_t park_region = 0;      // tail scratch: one region per launch stream (yf_stream_scratch.h)
   std::string err;
@@ -1115,11 +1119,13 @@ int yf_fp16_create(int device, const void* yfw, size_t bytes, yf_fp16** out, cha
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return fail("hipSetDevice failed"); }
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return fail(std::string("unsupported GPU ") + prop.gcnArchName); }
   c->cus = prop.multiProcessorCount;
+  c->wgs_per_cu = (int)(prop.maxSharedMemoryPerMultiProcessor / (size_t)yf16::LDS_TOTAL);      // two 82 KB workgroups in gfx950's 160 KB
+  if (c->wgs_per_cu < 1) { delete c; return fail("the device's LDS per CU is smaller than one workgroup of the fp16 kernel"); }
   if (hipMalloc((void**)&c->d_tab, blob.size()) != hipSuccess || hipMemcpy(c->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipFuncSetAttribute((const void*)yf16::yoloface56_f16_fused<YF16_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, yf16::LDS_TOTAL) != hipSuccess) {
     yf_fp16_destroy(c); return fail("uploading the fp16 tables failed");
   }
-  c->park_region = (size_t)c->cus * 2 * YF16_NW * yf16::PARK_BYTES;    // a park slot per wave of every workgroup; allocated per stream on first use
+  c->park_region = (size_t)c->cus * c->wgs_per_cu * YF16_NW * yf16::PARK_BYTES;    // a park slot per wave of every workgroup; allocated per stream on first use
   *out = c;
   return 0;
 }
@@ -1143,8 +1149,10 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
 #ifdef YF16_STAGEPMC
   if (getenv("YF16_STOP_STAGE")) prm.stop = atoi(getenv("YF16_STOP_STAGE"));
 #endif
-  HIPCHK(c, c->park.get((hipStream_t)stream, c->park_region, &prm.scratch));
-  long grid = (long)c->cus * 2;                              // two 76 KB workgroups per CU, persistent over the frames
+  yf_stream_scratch::Lease lease;                            // marks its region on every way out (yf_stream_scratch.h)
+  HIPCHK(c, c->park.get((hipStream_t)stream, c->park_region, &lease));
+  prm.scratch = lease.ptr;
+  long grid = (long)c->cus * c->wgs_per_cu;                  // two workgroups per CU (LDS), persistent over the frames
   if (grid > n) grid = n;
 #ifdef YF16_BARPROF
   if (getenv("YF16_ONE_WG_PER_CU")) grid = c->cus < n ? c->cus : n;       // dev builds: one workgroup per CU (how much do two share?)
@@ -1154,7 +1162,7 @@ int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* 
 #endif
   hipLaunchKernelGGL(yf16::yoloface56_f16_fused<YF16_NW>, dim3((unsigned)grid), dim3(YF16_NW * 64), yf16::LDS_TOTAL, (hipStream_t)stream, prm);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, c->park.mark((hipStream_t)stream));               // the region is busy until this launch has completed (yf_stream_scratch.h)
+  HIPCHK(c, lease.mark());                                    // the region is busy until this launch has completed (yf_stream_scratch.h)
 #ifdef YF16_BARPROF
   if (prof_path) {
     std::vector<long long> h(prof_bytes / sizeof(long long));

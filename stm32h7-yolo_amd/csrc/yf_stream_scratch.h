@@ -6,14 +6,24 @@
 // region is owned by a stream for as long as a launch on it may still run.  The reference has one context and no streams at all
 // (network.c:2929-2939); an entry point that accepts a stream has to be safe on any, and a host that creates a stream per request must
 // not grow the footprint without bound (round 3 kept one region per stream handle ever seen):
-//   - a launch records an event on its region (mark()); a region whose event has completed is IDLE and is handed to the next
-//     stream that asks (no allocation).  While ONE stream is all the object has ever seen, no event is recorded (an event between two
-//     kernels of a stream costs ~4 us of back-to-back overlap per launch: 2.7 % of the 145 us headline kernel): the region is DIRTY
-//     instead -- never idle -- so the first launch on a second stream gets a region of its own, and from then on every launch records
-//     its event (the first one on the dirty region's stream covers its earlier launches: stream order);
+//   - get() returns a LEASE; the caller launches and calls lease.mark().  A lease that goes out of scope unmarked -- any early return
+//     between get() and mark(): a failed launch, a failed later launch of a multi-launch call -- is marked by its destructor, so a region
+//     never stays "acquired" (round 4 leaked one region per failed launch);
+//   - mark() names the region's launches by an event, and a region whose event has completed is IDLE: the next stream that asks takes it
+//     over (no allocation).  The event is SKIPPED while no other region is in use (every other region idle): an event between two kernels
+//     of a stream costs ~4 us of back-to-back overlap per launch (2.7 % of the headline kernel).  The region is then DIRTY -- launched on,
+//     not named, never idle.  The decision is per mark(), not "one region exists": a stream that has the object to itself again (the
+//     others' launches completed) stops paying for events (round 4: once a second stream had been seen every launch recorded one for good);
+//   - when another stream needs a region and none is idle, the dirty regions get their event LAZILY, recorded on their own stream by the
+//     asking thread (stream order makes it cover every earlier launch).  If that fails -- the owner destroyed the stream -- the region's
+//     launches can only be waited for with the device (taken only when max_regions is reached);
 //   - at most max_regions regions exist; when all are busy on other streams the caller waits for the one marked longest ago;
 //   - release_stream() gives a stream's region back at once (yf_network_release_stream);
-//   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread).
+//   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread), and such a region always
+//     records its event (no other thread could record it lazily).
+// A stream is identified by its handle VALUE.  A host may drop a stream without release_stream() only once its launches have completed
+// (it synchronised the stream or consumed the results): the runtime may hand the same handle value to a new stream, and a launch of the
+// old one still in flight would then share the region with the new one's.
 // The first launch on a new stream may allocate (a blocking hipMalloc): INTEGRATION.md says so.  The map is mutex-protected.
 #ifndef YF_STREAM_SCRATCH_H
 #define YF_STREAM_SCRATCH_H
@@ -25,22 +35,45 @@
 
 struct yf_stream_scratch {
   size_t max_regions = 8;                          // the owner may lower it (the 160x160 arena: 4)
-  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired; };   // dirty: launched on without an event; acquired: handed out by get(), its launch not yet marked
+  // dirty: launched on without an event; acquired: handed out by get(), its launch not yet marked
+  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired; };
   std::mutex mu;
   std::vector<Region> regions;
   unsigned long long clock = 0;
+  unsigned long long events_recorded = 0, events_skipped = 0;     // diagnostics (tests)
+
+  // What get() hands out: the region's bytes, and the duty to mark it.  Movable, not copyable.
+  struct Lease {
+    yf_stream_scratch* owner = nullptr; hipStream_t stream = nullptr; char* ptr = nullptr;
+    Lease() = default;
+    Lease(const Lease&) = delete; Lease& operator=(const Lease&) = delete;
+    Lease(Lease&& o) noexcept : owner(o.owner), stream(o.stream), ptr(o.ptr) { o.owner = nullptr; }
+    Lease& operator=(Lease&& o) noexcept { if (this != &o) { settle(); owner = o.owner; stream = o.stream; ptr = o.ptr; o.owner = nullptr; } return *this; }
+    ~Lease() { settle(); }
+    // after the launch(es) that use the region
+    hipError_t mark() { yf_stream_scratch* o = owner; owner = nullptr; return o ? o->mark(stream) : hipSuccess; }
+   private:
+    void settle() { if (owner) { (void)owner->mark(stream); owner = nullptr; } }     // an abandoned lease: whatever WAS launched is named, nothing stays acquired
+  };
 
   static size_t thread_key(hipStream_t s) { return s == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0; }
   Region* find(hipStream_t s, size_t tk) { for (Region& r : regions) if (r.stream == s && r.thread == tk) return &r; return nullptr; }
   static bool idle(const Region& r) { return !r.acquired && !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
+  // a dirty region gets its event from whoever needs to know when it ends (its own stream's order covers the earlier launches)
+  static void name_lazily(Region& r) {
+    if (!r.dirty || r.acquired || r.thread != 0) return;
+    if (hipEventRecord(r.done, r.stream) == hipSuccess) { r.marked = true; r.dirty = false; }
+    else (void)hipGetLastError();                                                     // the stream is gone: only the device can tell (all-busy path below)
+  }
 
-  // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls mark(s).
-  hipError_t get(hipStream_t s, size_t bytes, char** out) {
+  // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls lease.mark().
+  hipError_t get(hipStream_t s, size_t bytes, Lease* lease) {
     std::lock_guard<std::mutex> lock(mu);
     const size_t tk = thread_key(s);
     Region* r = find(s, tk);
     if (!r) {
       for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
+      if (!r) for (Region& c : regions) name_lazily(c);                               // so that the dirty ones become idle once their launches end
       if (!r && regions.size() < max_regions) {
         Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false};
         const hipError_t rc = hipEventCreateWithFlags(&n.done, hipEventDisableTiming);
@@ -70,17 +103,21 @@ struct yf_stream_scratch {
     }
     r->stamp = ++clock;
     r->acquired = true;                                                               // not idle between get() and mark(), whoever asks
-    *out = r->ptr;
+    *lease = Lease();
+    lease->owner = this; lease->stream = s; lease->ptr = r->ptr;
     return hipSuccess;
   }
-  // after the launch(es) that use the region obtained for `s`
+  // after the launch(es) that use the region obtained for `s` (through the lease)
   hipError_t mark(hipStream_t s) {
     std::lock_guard<std::mutex> lock(mu);
-    Region* r = find(s, thread_key(s));
+    const size_t tk = thread_key(s);
+    Region* r = find(s, tk);
     if (!r) return hipSuccess;
     r->acquired = false;
-    if (regions.size() == 1) { r->dirty = true; return hipSuccess; }                  // one stream so far: no event between its kernels (see above)
-    r->marked = true; r->dirty = false;
+    bool alone = tk == 0;                                                             // nobody else in sight: no event between this stream's kernels
+    for (const Region& c : regions) if (&c != r && !idle(c)) { alone = false; break; }
+    if (alone) { r->marked = false; r->dirty = true; ++events_skipped; return hipSuccess; }      // dirty outranks whatever an older event says: never idle until named
+    r->marked = true; r->dirty = false; ++events_recorded;
     return hipEventRecord(r->done, s);
   }
   // the caller is done with `s` (about to destroy it): its region is freed once its last launch has completed
@@ -99,6 +136,7 @@ struct yf_stream_scratch {
     return hipSuccess;
   }
   size_t count() { std::lock_guard<std::mutex> lock(mu); return regions.size(); }
+  size_t acquired_count() { std::lock_guard<std::mutex> lock(mu); size_t n = 0; for (const Region& r : regions) n += r.acquired; return n; }
   size_t bytes_held() { std::lock_guard<std::mutex> lock(mu); size_t b = 0; for (const Region& r : regions) b += r.bytes; return b; }
   void release() {
     std::lock_guard<std::mutex> lock(mu);

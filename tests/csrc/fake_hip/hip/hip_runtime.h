@@ -1,0 +1,39 @@
+/* A FAKE of the few HIP entry points csrc/yf_stream_scratch.h uses, for the CPU test of the stream-scratch map (tests/csrc/scratch_map_test.cpp):
+ * own-authored, host-only, no GPU.  A "stream" is a small object that counts what was enqueued on it; a launch is `stream->enqueue()`; an
+ * event recorded on a stream completes when the test calls `stream->drain()` (or `fake_hip::drain_all()`).  Destroyed streams are remembered:
+ * recording on one fails, as the runtime's handle check does. */
+#ifndef FAKE_HIP_RUNTIME_H
+#define FAKE_HIP_RUNTIME_H
+#include <cstdlib>
+#include <set>
+#include <vector>
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorInvalidHandle = 400, hipErrorOutOfMemory = 2 };
+enum { hipEventDisableTiming = 2 };
+struct fake_stream { long enqueued = 0, completed = 0; void enqueue() { ++enqueued; } void drain() { completed = enqueued; } };
+struct fake_event { fake_stream* on = nullptr; long at = 0; };
+typedef fake_stream* hipStream_t;
+typedef fake_event* hipEvent_t;
+namespace fake_hip {
+inline std::set<fake_stream*>& live() { static std::set<fake_stream*> s; return s; }
+inline std::vector<fake_stream*>& all() { static std::vector<fake_stream*> s; return s; }
+inline long& mallocs() { static long n = 0; return n; }
+inline long& frees() { static long n = 0; return n; }
+inline long& device_syncs() { static long n = 0; return n; }
+inline long& fail_mallocs() { static long n = 0; return n; }
+inline hipStream_t create() { fake_stream* s = new fake_stream(); live().insert(s); all().push_back(s); return s; }
+inline void destroy(hipStream_t s) { live().erase(s); }            /* the object stays allocated: a stale handle value is still a valid address */
+inline void free_all() { for (fake_stream* s : all()) delete s; all().clear(); live().clear(); }
+inline void drain_all() { for (fake_stream* s : all()) s->drain(); }
+}
+#define hipStreamPerThread ((hipStream_t)2)
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = new fake_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (!fake_hip::live().count(s)) return hipErrorInvalidHandle; e->on = s; e->at = s->enqueued; return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t e) { return (!e->on || e->on->completed >= e->at) ? hipSuccess : hipErrorNotReady; }
+inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e->on && e->on->completed < e->at) e->on->completed = e->at; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { ++fake_hip::device_syncs(); fake_hip::drain_all(); return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { if (fake_hip::fail_mallocs() > 0) { --fake_hip::fail_mallocs(); return hipErrorOutOfMemory; } *p = std::malloc(n); ++fake_hip::mallocs(); return hipSuccess; }
+inline hipError_t hipFree(void* p) { fake_hip::drain_all(); std::free(p); ++fake_hip::frees(); return hipSuccess; }
+#endif

@@ -1,0 +1,111 @@
+// CPU test of csrc/yf_stream_scratch.h against a fake HIP runtime (tests/csrc/fake_hip): the policy of the stream-keyed scratch map, in particular
+// the paths a GPU test cannot reach deterministically -- a launch that fails between get() and mark(), events skipped while a stream is alone
+// and recorded lazily when another stream turns up, a dropped stream's region changing hands.  Built and run by tests/test_sanitizers.py.
+#include "yf_stream_scratch.h"
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+static hipError_t good_launch(yf_stream_scratch& m, hipStream_t s, size_t bytes = 1024, char** ptr = nullptr) {
+  yf_stream_scratch::Lease l;
+  const hipError_t rc = m.get(s, bytes, &l);
+  if (rc != hipSuccess) return rc;
+  if (ptr) *ptr = l.ptr;
+  s->enqueue();
+  return l.mark();
+}
+static hipError_t failing_launch(yf_stream_scratch& m, hipStream_t s) {      // the shape of launch(): HIPCHK returns between get() and mark()
+  yf_stream_scratch::Lease l;
+  const hipError_t rc = m.get(s, 1024, &l);
+  if (rc != hipSuccess) return rc;
+  return hipErrorInvalidHandle;                                                // "hipGetLastError() failed": nothing was enqueued, the lease is dropped
+}
+
+int main() {
+  {   // 1. a failed launch does not keep its region acquired: max_regions failures on distinct streams, then a new stream still gets one
+    yf_stream_scratch m; m.max_regions = 4;
+    hipStream_t s[6];
+    for (auto& x : s) x = fake_hip::create();
+    for (int i = 0; i < 4; ++i) { CHECK(failing_launch(m, s[i]) == hipErrorInvalidHandle); CHECK(m.acquired_count() == 0); }
+    CHECK(m.count() <= 4);
+    CHECK(good_launch(m, s[4]) == hipSuccess);                                 // round 4: hipErrorNotReady here, for good
+    CHECK(good_launch(m, s[5]) == hipSuccess);
+    CHECK(m.count() <= 4 && m.acquired_count() == 0);
+    // a dropped stream whose launch failed: its region is still reusable (recording the lease's event on the dead handle fails and is ignored)
+    fake_hip::destroy(s[0]);
+    CHECK(failing_launch(m, s[0]) == hipErrorInvalidHandle && m.acquired_count() == 0);
+    fake_hip::drain_all();
+    for (int i = 1; i < 6; ++i) CHECK(good_launch(m, s[i]) == hipSuccess);
+    CHECK(m.count() <= 4);
+    m.release();
+  }
+  {   // 2. a stream that is alone records no event; a second stream makes both record; alone again -> no events again
+    yf_stream_scratch m;
+    hipStream_t a = fake_hip::create(), b = fake_hip::create();
+    for (int i = 0; i < 10; ++i) CHECK(good_launch(m, a) == hipSuccess);
+    CHECK(m.events_recorded == 0 && m.events_skipped == 10 && m.count() == 1);
+    char *pa = nullptr, *pb = nullptr;
+    CHECK(good_launch(m, b, 1024, &pb) == hipSuccess);                         // a's launches may still run: b must not get a's bytes
+    CHECK(good_launch(m, a, 1024, &pa) == hipSuccess);
+    CHECK(m.count() == 2 && pa != pb);
+    const unsigned long long rec = m.events_recorded;
+    CHECK(rec >= 2);                                                           // b's launch (a's region dirty -> named lazily, then pending) and a's
+    fake_hip::drain_all();                                                     // everything completed: whoever launches next is alone
+    CHECK(good_launch(m, a) == hipSuccess && good_launch(m, a) == hipSuccess);
+    CHECK(m.events_recorded == rec);                                           // round 4: every launch recorded an event for the life of the object
+    m.release();
+  }
+  {   // 3. a stream that went away while its region was dirty: the next stream names it lazily (fails: handle dead) and takes a NEW region while
+      //    there is room; at the cap the region comes back through a device synchronise, not never
+    yf_stream_scratch m; m.max_regions = 2;
+    hipStream_t a = fake_hip::create(), b = fake_hip::create(), c = fake_hip::create();
+    CHECK(good_launch(m, a) == hipSuccess);                                    // dirty, no event
+    fake_hip::destroy(a);
+    CHECK(good_launch(m, b) == hipSuccess && m.count() == 2);
+    const long syncs = fake_hip::device_syncs();
+    CHECK(good_launch(m, c) == hipSuccess && m.count() == 2);                  // b's region, after waiting for b's event (b is named: a's region was not idle)
+    CHECK(fake_hip::device_syncs() == syncs && m.acquired_count() == 0);
+    m.release();
+    yf_stream_scratch one; one.max_regions = 1;                                // only a dead stream's dirty region left: the device is what can be waited for
+    hipStream_t d = fake_hip::create(), e = fake_hip::create();
+    CHECK(good_launch(one, d) == hipSuccess);
+    fake_hip::destroy(d);
+    CHECK(good_launch(one, e) == hipSuccess && one.count() == 1 && fake_hip::device_syncs() == syncs + 1);
+    one.release();
+  }
+  {   // 4. live stream, dirty region, owner never launches again: named lazily by the next stream, idle once drained, then it changes hands
+    yf_stream_scratch m; m.max_regions = 2;
+    hipStream_t a = fake_hip::create(), b = fake_hip::create(), c = fake_hip::create();
+    char *pa = nullptr, *pc = nullptr;
+    CHECK(good_launch(m, a, 1024, &pa) == hipSuccess);
+    CHECK(good_launch(m, b) == hipSuccess);                                    // names a's region lazily
+    const long syncs = fake_hip::device_syncs(), mallocs = fake_hip::mallocs();
+    a->drain();
+    CHECK(good_launch(m, c, 1024, &pc) == hipSuccess);
+    CHECK(pc == pa && fake_hip::device_syncs() == syncs && fake_hip::mallocs() == mallocs && m.count() == 2);     // no wait, no allocation
+    m.release();
+  }
+  {   // 5. 64 short-lived streams, three launches each, dropped after their work completed, never released: bounded footprint
+    yf_stream_scratch m;
+    for (int i = 0; i < 64; ++i) {
+      hipStream_t s = fake_hip::create();
+      for (int k = 0; k < 3; ++k) CHECK(good_launch(m, s) == hipSuccess);
+      s->drain();
+      fake_hip::destroy(s);
+    }
+    CHECK(m.count() <= 8 && m.acquired_count() == 0);
+    m.release();
+  }
+  {   // 6. a failed allocation leaves nothing acquired and the next get() works
+    yf_stream_scratch m;
+    hipStream_t a = fake_hip::create();
+    fake_hip::fail_mallocs() = 1;
+    yf_stream_scratch::Lease l;
+    CHECK(m.get(a, 4096, &l) == hipErrorOutOfMemory && m.acquired_count() == 0);
+    CHECK(good_launch(m, a, 4096) == hipSuccess);
+    m.release();
+  }
+  fake_hip::free_all();
+  std::printf("scratch map: ok\n");
+  return 0;
+}

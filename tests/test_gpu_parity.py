@@ -258,7 +258,8 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
 
 def test_short_lived_streams_keep_the_scratch_bounded(network, oracle, torch_cuda):
     """A host that creates a stream per request (yf_stream_scratch.h): 64 streams, each used for one int8, one fp16 and one 160x160
-    launch and then dropped WITHOUT a release call.  Regions of completed launches change hands, at most eight regions per kind
+    launch and then left WITHOUT a release call (the handles stay alive until their launches are through: a stream is identified by its handle
+    value, so destroying one with a launch still in flight needs yf_network_release_stream first -- INTEGRATION.md).  Regions of completed launches change hands, at most eight regions per kind
     exist, so the footprint stays under 8 x (park slots + fp16 park slots + one 160x160 arena chunk) whatever the number of
     streams (round 3 kept one region per stream handle ever seen: 64 x 43 MB here, 64 x 320 MB with 1024-frame 160x160 batches).  Every int8 head is compared with the oracle;
     an explicit release of a stream returns its bytes at once."""
@@ -445,6 +446,17 @@ def test_lab_library_shapes_agree(torch_cuda):
     env = dict(os.environ, YF_LIB_PATH=LAB_LIB)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "lab_shapes.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "lab shapes ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(LAB_LIB), reason="the lab library is not built (make -C stm32h7-yolo_amd/csrc lab)")
+def test_a_failed_launch_does_not_keep_its_scratch_region(torch_cuda):
+    """nine launches with an invalid grid on nine streams (lab library, YF_LAB_FAIL_LAUNCHES), then sixteen good launches on
+    nine other streams -- every one gets a region and the oracle's heads (tests/dev/failed_launch.py; the map's policy itself is tested on the CPU
+    against a fake runtime: tests/test_sanitizers.py::test_stream_scratch_map_policy_under_asan)."""
+    import subprocess, sys
+    env = dict(os.environ, YF_LIB_PATH=LAB_LIB, YF_LAB_FAIL_LAUNCHES="9")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "failed_launch.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failed-launch rehearsal ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):
