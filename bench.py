@@ -249,6 +249,14 @@ def main():
     ap.add_argument("--waves-per-wg", type=int, default=0)
     ap.add_argument("--det-cap", type=int, default=4, help="detection records kept (and exchanged) per frame; the count is always the true count")
     ap.add_argument("--gather-heads", action="store_true", help="also all-gather the int8 heads (882 B per frame) at N > 1")
+    ap.add_argument("--gather-every", type=int, default=1, metavar="K",
+                    help="N > 1: ONE all-gather per K steps carrying K steps' records (default 1: the all-gather per step BASELINE.json names); the "
+                         "exchange is latency-bound at 0.48 MB per rank and step, so K steps per collective cost one launch + handshake instead of K")
+    ap.add_argument("--compact-records", action="store_true",
+                    help="N > 1: send 12-byte wire records (cell + the firing anchor's six int8 head values; lossless, sharding.pack_compact) instead of the 28-byte yf_det")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="launch streams consecutive steps alternate between (default 2: the next step's workgroups start on CUs the previous launch "
+                         "has drained, which hides the ~6.6 us of ramp / drain / dispatch gap a launch costs on one stream: tools/probe/batch_rate.py, two_stream.py)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 160x160 and fp16 side configurations")
     ap.add_argument("--only-secondary", choices=sorted(SECONDARY), default=None,
                     help="run ONLY this side configuration (after the same clock settle) and print its line: the command the rocprofv3 "
@@ -305,25 +313,34 @@ def main():
     # Per-rank exchange record [detection records n x cap x 28 B | counts n x 4 B (| heads n x 882 B)] in ONE buffer: ONE all-gather
     # per step at N > 1.  Two buffers alternate: the all-gather of step k runs on RCCL's stream while the kernel of step k+1 fills
     # the other buffer (sharding.DetectionExchange holds the layout and the double-buffer protocol; the CPU gloo test runs it too).
-    ex = sharding.DetectionExchange(n, cap, world, dev, gather_heads=args.gather_heads, backend=args.backend if world > 1 else None)
-    rec_bytes, off_c = ex.rec_bytes, ex.off_c
-    local, heads_local, gath, views = ex.local, [ex.heads(i) for i in range(ex.n_buf)], ex.gathered, ex.views
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
+    # Launch streams: consecutive steps alternate between args.streams streams (one stream: the process's current stream, as in rounds 1-4).  Batches are
+    # independent, every step is still ONE launch over ONE batch; on two streams the workgroups of step k+1 start on CUs step k has left, so a launch's
+    # ramp, drain and dispatch gap overlap the neighbour step instead of adding up (the kernel's OWN duration is what `roofline` reports, below).
+    streams = [torch.cuda.current_stream()] if args.streams == 1 else [torch.cuda.Stream() for _ in range(args.streams)]
+    S = len(streams)
+    ex = sharding.DetectionExchange(n, cap, world, dev, gather_heads=args.gather_heads, backend=args.backend if world > 1 else None,
+                                    gather_every=args.gather_every, compact=args.compact_records, launch_streams=streams if S > 1 else None)
+    rec_bytes = ex.wire_rec_bytes
+    stream = streams[0]
+    Slot0 = sharding.Slot(0, 0)
 
-    def launch(i, k=0):
+    def launch(slot, k=0, s=stream):
         # ONE launch per step: the fused network kernel also decodes the boxes of its frames (heads still in LDS)
-        net.run_decode_device(d_ins[k].data_ptr(), ex.heads(i).data_ptr(), n, ex.dets_ptr(i), ex.counts_ptr(i), cap, yf.YF_DECODE_PY, 1.0, 1.0, sp)
+        net.run_decode_device(d_ins[k].data_ptr(), ex.heads(slot).data_ptr(), n, ex.dets_ptr(slot), ex.counts_ptr(slot), cap, yf.YF_DECODE_PY, 1.0, 1.0, s.cuda_stream)
 
     step_no = 0
 
     def step():
         nonlocal step_no
-        k = step_no % N_INPUT_BATCHES
+        k, s = step_no % N_INPUT_BATCHES, streams[step_no % S]
         step_no += 1
-        i = ex.acquire()                    # waits for the gather that last read buffer i
-        launch(i, k)
-        ex.exchange(i)                      # every rank ends up with every rank's detection records and counts (RCCL over xGMI)
+        if world == 1:                      # nothing to order against: no collective reads the buffers
+            launch(ex.acquire(), k, s)
+            return
+        with torch.cuda.stream(s):          # the exchange orders itself against the CURRENT stream: make it the step's launch stream
+            slot = ex.acquire()             # waits for the gather that last read the slot's buffer
+            launch(slot, k, s)
+            ex.exchange(slot)               # every rank ends up with every rank's detection records and counts (RCCL over xGMI); one collective per K steps
 
     drain = ex.drain
 
@@ -337,7 +354,7 @@ def main():
 
     def settle_launch():
         nonlocal settle_no
-        launch(0, settle_no % N_INPUT_BATCHES)
+        launch(Slot0, settle_no % N_INPUT_BATCHES)
         settle_no += 1
 
     while settled_ms < args.clock_settle_ms:
@@ -355,6 +372,8 @@ def main():
     for _ in range(args.steps):
         step()
     drain()
+    for s_other in streams[1:]:
+        stream.wait_stream(s_other)         # the closing event covers the launches of every stream
     ev_end.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0          # this rank's K steps; the MAX over ranks below is the job's time (a rank that finishes early waits in the barrier,
@@ -364,9 +383,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(ev_begin.elapsed_time(ev_end)) / args.steps
-    if world > 1:           # the timed region above also holds the collectives: time the kernel alone, same stream, same inputs
-        kernel_ms = event_time_ms(stream, settle_launch, 100)
+    region_ms = float(ev_begin.elapsed_time(ev_end)) / args.steps
+    kernel_ms = region_ms
+    if world > 1 or S > 1:  # the timed region above also holds the collectives / overlaps consecutive launches: time the kernel ALONE -- one stream, same
+        kernel_ms = event_time_ms(stream, settle_launch, 100)      # inputs, back to back; with one stream and one rank the timed region is that already
 
     # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames), then compare
     step_no = 0
@@ -374,8 +394,8 @@ def main():
     step()
     drain()
     torch.cuda.synchronize()
-    d_dets, d_counts = views(local[0])
-    heads = heads_local[0].view(torch.int8).view(n, 7, 7, 18).cpu().numpy()
+    d_dets, d_counts = ex.views(ex.local[0])
+    heads = ex.heads(Slot0).view(torch.int8).view(n, 7, 7, 18).cpu().numpy()
     dets = d_dets.cpu().numpy().view(yf.DET_DTYPE).reshape(n, cap)
     counts = d_counts.cpu().numpy()
     from oracle.oracle import Oracle
@@ -402,13 +422,25 @@ def main():
                 problems.append(f"golden frame {f}: detections differ from tests/golden/golden_meta.json")
     ok_gather = True
     if world > 1:   # every rank must hold every rank's records, in rank = frame order
-        ok_gather = ex.check_gathered(0, rank)
-        g_counts = ex.gathered_counts(0)                                              # [n_total]
+        ok_gather = ex.check_gathered(Slot0, rank)
+        g_counts = ex.gathered_counts(Slot0)                                          # [n_total]
         ok_gather = ok_gather and tuple(g_counts.shape) == (n_total,) and bool(torch.equal(g_counts[a:b], d_counts))
-        g_frames = ex.gathered_records(0)[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
         first_rec = np.nonzero(g_counts.cpu().numpy() > 0)[0]
-        # record k of rank r carries its LOCAL frame index: the global order is rank-major
-        ok_gather = ok_gather and all(int(g_frames[i]) == int(i % n) for i in first_rec[:512])
+        if args.compact_records:    # the wire carries cells + logits: decode the sparse heads they stand for with the library's own decode -> the sender's records
+            sparse = ex.gathered_sparse_heads(Slot0).contiguous()
+            r_dets = torch.zeros((n_total, cap, 28), dtype=torch.uint8, device=dev)
+            r_counts = torch.zeros((n_total,), dtype=torch.int32, device=dev)
+            net.decode_device(sparse.data_ptr(), n_total, r_dets.data_ptr(), r_counts.data_ptr(), cap, yf.YF_DECODE_PY, 1.0, 1.0)
+            torch.cuda.synchronize()
+            kept = torch.arange(cap, device=dev)[None, :] < d_counts.clamp(max=cap)[:, None]
+            ok_gather = ok_gather and bool(torch.equal(r_counts[a:b], d_counts.clamp(max=cap)))
+            ok_gather = ok_gather and bool(torch.equal(r_dets[a:b][kept][:, 4:], d_dets[kept][:, 4:]))        # every field but the (positional) frame index
+            g_frames = r_dets[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
+            ok_gather = ok_gather and all(int(g_frames[i]) == int(i) for i in first_rec[:512])                  # rank-major = global frame order
+        else:
+            g_frames = ex.gathered_records(Slot0)[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
+            # record k of rank r carries its LOCAL frame index: the global order is rank-major
+            ok_gather = ok_gather and all(int(g_frames[i]) == int(i % n) for i in first_rec[:512])
         flag = torch.tensor([int(ok_gather and not problems)], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         all_ok = bool(flag.item())
@@ -418,7 +450,8 @@ def main():
     fail = None
     if rank == 0:
         value = n_total * args.steps / elapsed
-        exch = (f" + RCCL all-gather of detection records (cap {cap}) and counts" + (" and heads" if args.gather_heads else "")) if world > 1 else ""
+        exch = (f" + RCCL all-gather of detection records (cap {cap}{', 12-byte wire form' if args.compact_records else ''}) and counts" + (" and heads" if args.gather_heads else "")
+                + (f", one collective per {args.gather_every} steps" if args.gather_every > 1 else "")) if world > 1 else ""
         line = {
             "metric": "images/sec int8 YOLO-face 56x56", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -429,7 +462,8 @@ def main():
                        "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
                        "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
                        "parallelism": f"batch-shard x{world}, all-gather of detections" if world > 1 else "single GPU",
-                       "exchange_bytes_per_rank_per_step": rec_bytes if world > 1 else 0},
+                       "exchange_bytes_per_rank_per_step": rec_bytes if world > 1 else 0, "gather_every": args.gather_every,
+                       "collectives_issued": ex.collectives, "launch_streams": S},
         }
         achieved = n * ALGO_BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
         prof, why = profile_counters(net.kernel_name)
@@ -437,7 +471,16 @@ def main():
                             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
                             "traffic_source": (f"{prof['profile']} (kernel sources {prof['source_hash']})" if prof else why),
                             "kernel": net.kernel_name, "kernel_ms": round(kernel_ms, 4),
+                            "kernel_ms_is": ("the timed region's HIP-event time / steps (one stream, one launch per step, back to back)" if (S == 1 and world == 1) else
+                                             "the kernel's OWN average duration: HIP events around 100 back-to-back launches on ONE stream after the timed region "
+                                             "(same inputs); the rocprofv3 trace of the one-stream launches of this command agrees (profiles/)"),
                             "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_FRAME}
+        if S > 1:   # the JOB's rate against the KERNEL's duration: consecutive steps overlap, so a step takes less than a kernel lasts -- by design, not by mistake
+            line["pipelining"] = {"launch_streams": S, "timed_region_ms_per_step": round(region_ms, 4), "kernel_ms_alone": round(kernel_ms, 4),
+                                  "hidden_per_step_us": round((kernel_ms - region_ms) * 1e3, 2),
+                                  "note": "steps alternate between two HIP streams: the workgroups of step k+1 start on CUs step k has drained, so a launch's ramp, drain and "
+                                          "dispatch gap (6.6 us of fixed cost per launch on one stream, tools/probe/batch_rate.py) overlap the neighbour step.  "
+                                          "ms_per_step < roofline.kernel_ms follows from that; `roofline` prices the kernel alone (--streams 1 reproduces rounds 1-4)"}
         tops = n * DENSE_OPS_PER_FRAME / (kernel_ms * 1e-3) / 1e12
         line["roofline_mfma"] = {"bound": "mfma", "achieved": round(tops, 3), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                                  "frac": round(tops / MFMA_I8_PEAK_TOPS, 6)}

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
   for (int i = tid0; i < v2::ZERO_B / 16; i += NT) reinterpret_cast<uint4*>(smem + v2::ZERO)[i] = uint4{0, 0, 0, 0};
   constexpr int DBG_LUT = PRE + OUT_ALL_BYTES + FRAME_BYTES + (F - 1) * FRAME_STRIDE;      // debug builds: LEAKY_RELU #43 alone, behind the frame arenas
   if constexpr (DUMP) { if (tid0 < YF_DBG_LUT_BYTES / 16) reinterpret_cast<uint4*>(smem + DBG_LUT)[tid0] = reinterpret_cast<const uint4*>(tab + PLAN.lut_off + YF_N_LUT * 256 + YF_ADDLUT_BYTES)[tid0]; }
+#if !(defined(YF_LAB) && defined(YF_WHATIF_NO_PROLOGUE_TABLES))   // what-if (WRONG results): the ten table builds gone -- the bound for fetching host-built tables by LDS-DMA instead
   {   // job tables of the five depthwise geometries (offsets relative to the frame arenas)
     typedef v2::JobTabs<F, tail_batch<DUMP>()> JTS;
     typedef typename JTS::U UT;
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     v2::build_halotab<typename HTS::G15, HTS::H_T15, NT>(smem, tid0);
     v2::build_halotab<typename HTS::G19, HTS::H_T19, NT>(smem, tid0);
   }
+#endif
 
   const long n_groups = (prm.n + F - 1) / F;
   const AddK no_add = {};

@@ -1022,6 +1022,17 @@ YF_STAGE_FN void dw2_stage(char* frames, const uint8_t* __restrict__ tab, int wa
     auto entry = [&](int job) { return *(lds_u2_ptr)(uint32_t)(LAY::JT + JTOFF + 8 * min(job, JPG - 1)); };    // {src, dst} offsets of a job
     auto taps = [&](const v2u e, v4i& b0, v4i& b1, v4i& b2, char*& dst) {
       const char* src = lin + e[0];
+#if defined(YF_LAB) && defined(YF_WHATIF_DW_ROWWIN)
+      // Timing-only what-if (WRONG results; profiles/EXPERIMENTS.md round 5): the bound for taps by KERNEL ROW with a three-row register window in the two
+      // stride-1 stages on the big grids (conv2d_3, conv2d_15) -- a lane walking down a column strip would read 3 new dwords per output row instead of 9.
+      // Here: three of the nine reads are issued, the other six operands reuse them; MFMAs, epilogue and stores unchanged.
+      if constexpr (STRIDE == 1 && G::W >= 14) {
+        b0[0] = (int)lds_u32(src + 2 * TR);    b0[1] = (int)lds_u32(src + 2 * TR + TS); b0[2] = (int)lds_u32(src + 2 * TR + 2 * TS);
+        b0[3] = b0[0]; b1[0] = b0[1]; b1[1] = b0[2]; b1[2] = b0[0]; b1[3] = b0[1]; b2[0] = b0[2];
+        dst = lout + e[1];
+        return;
+      }
+#endif
       b0[0] = (int)lds_u32(src);               b0[1] = (int)lds_u32(src + TS);          b0[2] = (int)lds_u32(src + 2 * TS);
       b0[3] = (int)lds_u32(src + TR);          b1[0] = (int)lds_u32(src + TR + TS);     b1[1] = (int)lds_u32(src + TR + 2 * TS);
       b1[2] = (int)lds_u32(src + 2 * TR);      b1[3] = (int)lds_u32(src + 2 * TR + TS); b2[0] = (int)lds_u32(src + 2 * TR + 2 * TS);

@@ -492,6 +492,10 @@ def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):
         assert (g[m] == 7.0).all()
     err = np.abs(got[:8] - ref)
     assert np.all(err <= 2e-2 + 2e-2 * np.abs(ref)), f"max abs err {err.max():.4f}"
+    # ... and bit for bit what this kernel gave when the fixture was written (tests/golden/make_fp16_golden.py): pins refactors of the kernel -- arena plan,
+    # DMA placement -- that the tolerance above would let through.  Not a reference value: regenerated when the arithmetic order changes on purpose.
+    pinned = np.load(os.path.join(ROOT, "tests", "golden", "fp16_logits_8.npy"))
+    assert np.array_equal(got[:8], pinned), f"fp16 logits differ from the committed fixture (max abs diff {np.abs(got[:8] - pinned).max():.3g})"
     thr = np.log(0.7 / 0.3)                                                          # sigmoid(t) > 0.7  <=>  t > ln(7/3)
     cref, cgot = ref.reshape(8, 49, 3, 6)[..., 4], got[:8].reshape(8, 49, 3, 6)[..., 4]
     clear = np.abs(cref - thr) > 2e-2 + 2e-2 * np.abs(cref)
@@ -881,6 +885,7 @@ def test_bench_two_ranks_exchange_detections(tmp_path):
     assert line["n_gpus"] == 2 and line["all_gather_ok"] is True and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 8192 and line["parity"].startswith("every rank")
     assert 0 < line["config"]["exchange_bytes_per_rank_per_step"] <= 600_000
+    assert line["config"]["launch_streams"] == 2 and line["pipelining"]["launch_streams"] == 2        # the default: steps alternate between two streams
 
 
 def test_bench_two_ranks_gather_heads_and_a_failing_rank():
@@ -895,6 +900,14 @@ def test_bench_two_ranks_gather_heads_and_a_failing_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["all_gather_ok"] is True and line["config"]["exchange_bytes_per_rank_per_step"] > 4096 * 882
+    # (1b) the two exchange knobs of round 5: ONE collective per two steps (three steps: the run ends inside a buffer, drain() sends it) carrying
+    # 12-byte wire records; every rank decodes the sparse heads the gathered records stand for on the GPU and must find its own records in them.
+    # One launch stream here, two in the runs above and below (the default).
+    r = subprocess.run(cmd[:-4] + ["--steps", "3", "--warmup", "1", "--gather-every", "2", "--compact-records", "--streams", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["all_gather_ok"] is True and line["config"]["gather_every"] == 2 and line["config"]["launch_streams"] == 1
+    assert line["config"]["exchange_bytes_per_rank_per_step"] == 4096 * (4 * 12 + 4) and "12-byte wire form" in line["config"]["workload"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, YF_BENCH_TEST_FAIL_RANK="1"))
     assert r.returncode != 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
