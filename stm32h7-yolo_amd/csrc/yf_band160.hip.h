@@ -238,7 +238,9 @@ __global__ void __launch_bounds__(NW * 64, YF_K1_OCC) band_k1(const Params prm) 
     fill_column<NT, T4_ROW, 20>(frames + L1_T4::OFF, 0, K1_BH, z_t4, tid);
     lds_barrier();
     YF_BAND_PRIO(0);
+#if !(defined(YF_LAB) && defined(YF_WHATIF_NO_T4_HBM))   // what-if (WRONG results): T4 never written ...
     store_rows<NT>(arena + A_T4 + (a + 1) * T4_ROW, frames + L1_T4::OFF, K1_BH * T4_ROW, tid);              // halo'd rows a+1 ..
+#endif
     if (a == 0) fill_dwords<NT>(arena + A_T4, z_t4, T4_ROW, tid);                                           // top halo row
   }
 }
@@ -334,7 +336,13 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     lo_local = lo - h0; n16 = (hi - lo) * (T4_ROW / 16);
   };
   long job = blockIdx.x;
-  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); pf_fetch(pre, src, n16, tid); }
+#if defined(YF_LAB) && defined(YF_WHATIF_NO_T4_HBM)       // ... and never read: band_k23 commits whatever its prefetch registers hold.  Together the bound for
+#define YF_K23_FETCH(...) do { } while (0)                // any way of making T4's crossing of HBM cheaper (unpadded T4, crossing at T3): profiles/r05_160/whatif.txt
+  for (auto& v : pre.v) v = v4u{0u, 0u, 0u, 0u};
+#else
+#define YF_K23_FETCH(...) pf_fetch(__VA_ARGS__)
+#endif
+  if (job < jobs) { const char* src; int ll, n16; range(job, src, ll, n16); YF_K23_FETCH(pre, src, n16, tid); }
   for (; job < jobs; job += gridDim.x) {
     long fr; int bnd; split_job<K23_BANDS>(job, xcd, fr, bnd);
     const int p0 = bnd * K23_BP;                                   // first 40x40 row of the band
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(NW * 64, 4) band_k23(const Params prm) {
     YF_BAND_PRIO(3);
     { const char* src; int ll, n16; range(job, src, ll, n16); pf_commit(pre, frames + L23_T4::OFF + ll * T4_ROW, n16, tid); }
     lds_barrier();
-    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); pf_fetch(pre, src, n16, tid); }
+    if (job + gridDim.x < jobs) { const char* src; int ll, n16; range(job + gridDim.x, src, ll, n16); YF_K23_FETCH(pre, src, n16, tid); }
     // pool_8 horizontal pass over every band row (rows outside the image are never read back), on threads [0, nt)
     auto pool_h = [&](int t0, int nt) {
       constexpr int NO = 5, NCH = G2 / NO;

@@ -851,22 +851,39 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
   int stage_no = 0;
 #define SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (++stage_no == prm.stop) continue; }
 #define SYNC_BATCH() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#elif defined(YF16_WHATIF_NO_FRONT_BARRIERS)
+  // Timing-only what-if (WRONG results; profiles/r05_fp16/whatif.txt): the per-frame barriers of the front chain become waits for the wave's OWN memory
+  // operations -- no wave ever waits for another inside a batch; the two batch-level barriers stay.  The bound for any barrier-free form of the 28x28 / 14x14 stages.
+#define SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+#define SYNC_BATCH() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #else
 #define SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
-#ifndef YF16_STAGEPMC
+#if !defined(YF16_STAGEPMC) && !defined(YF16_WHATIF_NO_FRONT_BARRIERS)
 #define SYNC_BATCH() SYNC()
 #endif
 #if defined(YF16_BARPROF) || defined(YF16_STAGEPMC)
 #define SYNC_LDS() SYNC()
+#elif defined(YF16_WHATIF_NO_FRONT_BARRIERS)
+#define SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#endif
+// SYNC_PIX: the barriers whose consumer stage is PIXELWISE in its producer's output (a 1x1 layer behind any layer: conv2d_3 -> 5, 12 -> 13, 15 -> 17, 17 -> 19,
+// 19 -> 23) -- the ones a register-chained merge of the two stages could remove.  YF16_WHATIF_NO_PIXELWISE_BARRIERS (timing only, WRONG results) turns exactly
+// those five into waits for the wave's own operations: the bound for every such merge at zero cost (profiles/r05_fp16/whatif.txt).
+#if defined(YF16_WHATIF_NO_PIXELWISE_BARRIERS)
+#define SYNC_PIX() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define SYNC_PIX() SYNC()
 #endif
 #define FETCH(U) fetch_unit<U, NW>(tab, conv_at(unit_first(U)).w_off, wave, lane)
   // the barrier behind a stage that issued prefetch_in() AFTER its weight DMA: the IN_ITERS youngest loads (global_load_dwordx3 each, checked
   // in the ISA) may stay in flight.  The profiling builds keep the plain barrier.
 #if defined(YF16_BARPROF) || defined(YF16_STAGEPMC)
 #define SYNC_KEEP_PREFETCH() SYNC()
+#elif defined(YF16_WHATIF_NO_FRONT_BARRIERS)
+#define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((56 * 28 + NW * 64 - 1) / (NW * 64)) : "memory"); } while (0)
 #else
 #define SYNC_KEEP_PREFETCH() do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((56 * 28 + NW * 64 - 1) / (NW * 64)) : "memory"); __syncthreads(); } while (0)
 #endif
@@ -939,7 +956,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     SYNC();
     FETCH(2);
     conv3x3_stage<1, NW, 1, B_T1, B_T2, 8, true>(lds, tab, conv_at(1), wave, lane);                     // conv2d_3 (dw)
-    SYNC();
+    SYNC_PIX();
     FETCH(3);
     fill_halo<B_T4, false, NT>(lds, tid);
     dense_pair_stage<2, 1, 4, EPI_LINEAR, NoBuf, NoBuf, ZSLACK, 3, NW, 5, 18, B_T2, B_T4, 0, ZSLACK>(wave, lane);            // conv2d_5 -> conv2d_6
@@ -953,20 +970,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
     FETCH(5);
     if (wave < POOL8V_WAVES) pool8_v(wave * 64 + lane);                                               // pool_8 v: HB -> concat_22[0,18) ...
     else dense_tile_stage<5, NW - POOL8V_WAVES, 1, 3, B_T6, B_T7, 0, 6, EPI_LINEAR, B_T7, ZSLACK>(wave - POOL8V_WAVES, lane);   // ... beside conv2d_12: T6 -> T7
-    SYNC();
+    SYNC_PIX();
     FETCH(6);
     fill_halo<B_T8, true, NT>(lds, tid);
     dense_tile_stage<6, NW, (NW > 8 ? 3 : 5), 1, B_T7, B_T8, 0, 36, EPI_ACT, B_T8, ZSLACK>(wave, lane);     // conv2d_13
     SYNC();
     FETCH(7);
     conv3x3_stage<7, NW, 1, B_T8, B_T9, 36, true>(lds, tab, conv_at(7), wave, lane);                     // conv2d_15 (dw)
-    SYNC();
+    SYNC_PIX();
     FETCH(8);
     dense_tile_stage<8, NW, 1, 5, B_T9, B_T11, 0, 6, EPI_ADD, B_T7, B_T8::OFF>(wave, lane);     // conv2d_17 + eltwise_18
-    SYNC();
+    SYNC_PIX();
     FETCH(9);
     dense_tile_stage<9, NW, (NW > 8 ? 2 : 3), 1, B_T11, B_T14, 20, 18, EPI_ACT, B_T14, ZSLACK>(wave, lane); // conv2d_19 -> concat_22 conv half
-    SYNC();
+    SYNC_PIX();
     FETCH(10);
     const bool more = k + 1 < nb;
     if (more) prefetch_in(fr + G);                                                                    // the next frame's input, behind this stage's weight DMA
@@ -1017,6 +1034,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 2) yoloface56_f16_fused(const Pa
 #undef SYNC_BATCH
 #undef SYNC_LDS
 #undef SYNC_KEEP_PREFETCH
+#undef SYNC_PIX
 #undef FETCH
 }
 
