@@ -90,6 +90,7 @@ struct yf_engine {
   int cus = 0;
   size_t lds_per_cu = 0;                         // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
 #ifdef YF_LAB
+  int grid_div = 1;                              // laboratory (YF_LAB_GRID_DIV): a launch takes 1 / grid_div of the resident grid (launch-policy what-ifs: several launches side by side)
   int fail_next_launch = 0;                      // laboratory: the next k fused launches get an invalid grid (tests the scratch lease on the failure path)
 #endif
   uint8_t* d_tab = nullptr;
@@ -288,6 +289,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
 #ifdef YF_LAB
   { const char* fl = getenv("YF_LAB_FAIL_LAUNCHES"); if (fl) e->fail_next_launch = atoi(fl); }
+  { const char* gd = getenv("YF_LAB_GRID_DIV"); if (gd && atoi(gd) > 1) e->grid_div = atoi(gd); }
 #endif
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
@@ -401,6 +403,9 @@ static int launch(yf_engine* e, const Variant* v, const void* d_in, void* d_out,
   const long groups = (n + v->f - 1) / v->f;
   const int per_cu = (int)(e->lds_per_cu / v->lds) > 0 ? (int)(e->lds_per_cu / v->lds) : 1;
   long grid = (long)e->cus * per_cu;
+#ifdef YF_LAB
+  if (e->grid_div > 1) grid = grid / e->grid_div > 0 ? grid / e->grid_div : 1;
+#endif
   if (grid > groups) grid = groups;
   prm.scratch = nullptr;
   yf_stream_scratch::Lease lease;    // marks its region on EVERY way out of this function (a failed launch must not keep a region acquired)
