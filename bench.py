@@ -521,9 +521,12 @@ def main():
             if not args.no_secondary:   # the ABI's largest batch (ai_network_run takes a 16-bit n_batches): 65 535 frames, 617 MB of host frames
                 xl = np.tile(x, (16, 1, 1, 1))[:65535]
                 out_l = net.run(xl)
-                t1 = time.perf_counter()
-                net.run(xl, out=out_l)
-                line["pcie_inclusive_images_per_s_n65535"] = round(65535 / (time.perf_counter() - t1), 1)
+                best_l = float("inf")
+                for _ in range(3):          # best of three (one call is 12-18 ms: a single sample caught a 3.7 M outlier among 5.3-5.7 M)
+                    t1 = time.perf_counter()
+                    net.run(xl, out=out_l)
+                    best_l = min(best_l, time.perf_counter() - t1)
+                line["pcie_inclusive_images_per_s_n65535"] = round(65535 / best_l, 1)
                 if not np.array_equal(out_l[:n], heads) or not np.array_equal(out_l[-(65535 - 15 * n):], heads[:65535 - 15 * n]):
                     problems.append("ai_network_run on 65535 host frames differs from the device path")
                 del xl, out_l
