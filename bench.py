@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1, metavar="K",
                     help="N > 1: ONE all-gather per K steps carrying K steps' records (default 1: the all-gather per step BASELINE.json names); the "
                          "exchange is latency-bound at 0.48 MB per rank and step, so K steps per collective cost one launch + handshake instead of K")
+    ap.add_argument("--exchange-buffers", type=int, default=0, metavar="B",
+                    help="N > 1: exchange buffers that alternate (0 = automatic).  A step's kernel waits for the gather that last read ITS buffer: with two "
+                         "buffers that is the gather of two steps ago, which on a GPU filled by the kernels can only run once the step in between drains")
     ap.add_argument("--compact-records", action="store_true",
                     help="N > 1: send 12-byte wire records (cell + the firing anchor's six int8 head values; lossless, sharding.pack_compact) instead of the 28-byte yf_det")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
@@ -265,6 +268,9 @@ def main():
     ap.add_argument("--clock-settle-ms", type=float, default=60.0,
                     help="before the W warm-up steps keep the GPU busy with untimed launches of the same kernel for this long: a GPU "
                          "that has idled runs its first ~10 ms at a lower engine clock (tools/step_probe.py), and W = 5 steps are 1 ms; 0 = off")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="N = 1 only: run the N > 1 code path -- process group (backend nccl = RCCL), per-step all-gather, gathered-record checks -- in a "
+                         "ONE-rank group: the only way to execute the torch.distributed / RCCL calls of this file on a one-GPU box (RCCL refuses two ranks on one device)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
@@ -278,7 +284,17 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if args.rccl_one_rank:
+        if world != 1:
+            raise SystemExit("--rccl-one-rank is an N = 1 rehearsal")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    dist_on = world > 1 or args.rccl_one_rank         # the exchange and its checks run (world = 1 with --rccl-one-rank: a one-rank group)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
@@ -318,8 +334,10 @@ def main():
     # ramp, drain and dispatch gap overlap the neighbour step instead of adding up (the kernel's OWN duration is what `roofline` reports, below).
     streams = [torch.cuda.current_stream()] if args.streams == 1 else [torch.cuda.Stream() for _ in range(args.streams)]
     S = len(streams)
-    ex = sharding.DetectionExchange(n, cap, world, dev, gather_heads=args.gather_heads, backend=args.backend if world > 1 else None,
-                                    gather_every=args.gather_every, compact=args.compact_records, launch_streams=streams if S > 1 else None)
+    ex = sharding.DetectionExchange(n, cap, world, dev, gather_heads=args.gather_heads, backend=args.backend if dist_on else None, always=args.rccl_one_rank,
+                                    gather_every=args.gather_every, compact=args.compact_records, launch_streams=streams if S > 1 else None, n_buf=args.exchange_buffers or None,
+                                    packer=lambda d, c, h, w, nn, cp: net.pack_detections_device(d, c, h, w, nn, cp, torch.cuda.current_stream().cuda_stream),
+                                    unpacker=lambda w, c, h, nn, cp: net.unpack_detections_device(w, c, h, nn, cp, torch.cuda.current_stream().cuda_stream))
     rec_bytes = ex.wire_rec_bytes
     stream = streams[0]
     Slot0 = sharding.Slot(0, 0)
@@ -334,7 +352,7 @@ def main():
         nonlocal step_no
         k, s = step_no % N_INPUT_BATCHES, streams[step_no % S]
         step_no += 1
-        if world == 1:                      # nothing to order against: no collective reads the buffers
+        if not dist_on:                     # nothing to order against: no collective reads the buffers
             launch(ex.acquire(), k, s)
             return
         with torch.cuda.stream(s):          # the exchange orders itself against the CURRENT stream: make it the step's launch stream
@@ -364,7 +382,7 @@ def main():
     # One step is ONE kernel launch, so the fused kernel's average duration is the HIP-event time of the whole timed
     # region on the launch stream divided by the steps (a per-step event pair costs ~7 us of pipeline drain per step).
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -377,15 +395,15 @@ def main():
     ev_end.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0          # this rank's K steps; the MAX over ranks below is the job's time (a rank that finishes early waits in the barrier,
-    if world > 1:                               # and the barrier's own collective -- ~0.1 ms against a 2.9 ms region at the driver's flags -- is not a step)
+    if dist_on:                               # and the barrier's own collective -- ~0.1 ms against a 2.9 ms region at the driver's flags -- is not a step)
         dist.barrier()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     region_ms = float(ev_begin.elapsed_time(ev_end)) / args.steps
     kernel_ms = region_ms
-    if world > 1 or S > 1:  # the timed region above also holds the collectives / overlaps consecutive launches: time the kernel ALONE -- one stream, same
+    if dist_on or S > 1:  # the timed region above also holds the collectives / overlaps consecutive launches: time the kernel ALONE -- one stream, same
         kernel_ms = event_time_ms(stream, settle_launch, 100)      # inputs, back to back; with one stream and one rank the timed region is that already
 
     # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames), then compare
@@ -400,12 +418,12 @@ def main():
     counts = d_counts.cpu().numpy()
     from oracle.oracle import Oracle
     orc = Oracle()
-    n_chk = n if world == 1 else 256            # at N > 1 every rank checks a slice of ITS shard (the full check is the N = 1 run's)
+    n_chk = n if not dist_on else 256            # at N > 1 every rank checks a slice of ITS shard (the full check is the N = 1 run's)
     problems = []
-    ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if world > 1 else None
-    if world > 1 and not np.array_equal(heads[:n_chk], ref_heads):
+    ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if dist_on else None
+    if dist_on and not np.array_equal(heads[:n_chk], ref_heads):
         problems.append(f"rank {rank}: heads differ from the oracle on its first {n_chk} frames")
-    if world > 1 and os.environ.get("YF_BENCH_TEST_FAIL_RANK") == str(rank):         # read by ONE test only: rehearses "a rank's check fails -> every
+    if dist_on and os.environ.get("YF_BENCH_TEST_FAIL_RANK") == str(rank):         # read by ONE test only: rehearses "a rank's check fails -> every
         problems.append(f"rank {rank}: parity failure forced by YF_BENCH_TEST_FAIL_RANK")   # rank exits non-zero after rank 0 has printed its line"
     for f in range(min(n_chk, 64)):             # decoded records of the first frames against the oracle's decode of the GPU heads
         want = orc.decode_py(heads[f], f, 1.0, 1.0)
@@ -421,7 +439,7 @@ def main():
             if counts[f] != len(want) or got != want[:cap]:
                 problems.append(f"golden frame {f}: detections differ from tests/golden/golden_meta.json")
     ok_gather = True
-    if world > 1:   # every rank must hold every rank's records, in rank = frame order
+    if dist_on:   # every rank must hold every rank's records, in rank = frame order
         ok_gather = ex.check_gathered(Slot0, rank)
         g_counts = ex.gathered_counts(Slot0)                                          # [n_total]
         ok_gather = ok_gather and tuple(g_counts.shape) == (n_total,) and bool(torch.equal(g_counts[a:b], d_counts))
@@ -451,7 +469,7 @@ def main():
     if rank == 0:
         value = n_total * args.steps / elapsed
         exch = (f" + RCCL all-gather of detection records (cap {cap}{', 12-byte wire form' if args.compact_records else ''}) and counts" + (" and heads" if args.gather_heads else "")
-                + (f", one collective per {args.gather_every} steps" if args.gather_every > 1 else "")) if world > 1 else ""
+                + (f", one collective per {args.gather_every} steps" if args.gather_every > 1 else "")) if dist_on else ""
         line = {
             "metric": "images/sec int8 YOLO-face 56x56", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -461,9 +479,10 @@ def main():
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
                        "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
                        "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
-                       "parallelism": f"batch-shard x{world}, all-gather of detections" if world > 1 else "single GPU",
-                       "exchange_bytes_per_rank_per_step": rec_bytes if world > 1 else 0, "gather_every": args.gather_every,
-                       "collectives_issued": ex.collectives, "launch_streams": S},
+                       "parallelism": f"batch-shard x{world}, all-gather of detections" if dist_on else "single GPU",
+                       "exchange_bytes_per_rank_per_step": rec_bytes if dist_on else 0, "gather_every": args.gather_every,
+                       "collectives_issued": ex.collectives, "launch_streams": S,
+                       **({"rehearsal": "--rccl-one-rank: the N > 1 code path in a ONE-rank RCCL group (not a multi-GPU measurement)"} if args.rccl_one_rank else {})},
         }
         achieved = n * ALGO_BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
         prof, why = profile_counters(net.kernel_name)
@@ -471,7 +490,7 @@ def main():
                             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": prof["hbm_bytes_per_launch"] if prof else None,
                             "traffic_source": (f"{prof['profile']} (kernel sources {prof['source_hash']})" if prof else why),
                             "kernel": net.kernel_name, "kernel_ms": round(kernel_ms, 4),
-                            "kernel_ms_is": ("the timed region's HIP-event time / steps (one stream, one launch per step, back to back)" if (S == 1 and world == 1) else
+                            "kernel_ms_is": ("the timed region's HIP-event time / steps (one stream, one launch per step, back to back)" if (S == 1 and not dist_on) else
                                              "the kernel's OWN average duration: HIP events around 100 back-to-back launches on ONE stream after the timed region "
                                              "(same inputs); the rocprofv3 trace of the one-stream launches of this command agrees (profiles/)"),
                             "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_FRAME}
@@ -502,7 +521,7 @@ def main():
             line["roofline_lds"] = {"bound": "lds-pipe", "achieved": prof["SQ_LDS_IDX_ACTIVE"], "peak": round(cu_cycles), "unit": "LDS-array cycles per launch",
                                     "frac": round(prof["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4), "bank_conflict_cycles": prof.get("SQ_LDS_BANK_CONFLICT"),
                                     "lds_instructions_per_launch": prof.get("SQ_INSTS_LDS"), "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
-        if world == 1:
+        if not dist_on:
             cb, mism = cpu_baseline(x, heads)
             line["cpu_baseline"] = cb
             line["parity"] = ("bit-exact vs oracle on %d/%d frames; decoded boxes of the golden frames equal tests/golden" % (n, n)) if mism == 0 and not problems \
@@ -551,7 +570,7 @@ def main():
             if not all_ok:
                 fail = "all-gather or per-rank parity check failed"
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
         if not all_ok:

@@ -261,6 +261,14 @@ YF_API void yf_network_shard_range(long n, int rank, int world, long* begin, lon
  * the first call and links nothing at build time).  Asynchronous on `stream`.  Returns bytes_per_rank or <= 0. */
 YF_API long yf_network_all_gather_device(ai_handle network, void* nccl_comm, const void* d_send, void* d_recv,
                                          size_t bytes_per_rank, void* stream);
+/* Compact WIRE form of the detection records for that exchange (12 bytes instead of sizeof(yf_det) = 28): {u8 anchor, row, col, 0, i8 q[6], u16 0} -- the
+ * firing cell and the six int8 head values of its anchor, from which frame index (= the record's position), confidence and box edges follow through the
+ * decode tables: lossless whatever the edges are.  pack: d_dets yf_det[n][cap], d_counts int32[n], d_heads int8[n][7][7][18] -> d_wire uint8[n][cap][12]
+ * (slots beyond min(count, cap) zeroed).  unpack: d_wire + the sender's d_counts -> d_heads int8[n][7][7][18], -128 everywhere except the transmitted
+ * cells; yf_network_decode_device on it reproduces the sender's records (min(count, cap) per frame, in the sender's order).  One launch each, asynchronous
+ * on `stream`; return n or <= 0. */
+YF_API long yf_network_pack_detections_device(ai_handle network, const void* d_dets, const void* d_counts, const void* d_heads, void* d_wire, long n, int cap, void* stream);
+YF_API long yf_network_unpack_detections_device(ai_handle network, const void* d_wire, const void* d_counts, void* d_heads, long n, int cap, void* stream);
 /* Frame preparation on the GPU (yoloface.c:26-93): d_rgb565 uint8[n][112*112*2] big-endian RGB565 -> d_out int8[n][56][56][3]. */
 YF_API long yf_network_prepare_rgb565_device(ai_handle network, const void* d_rgb565, void* d_out, long n, void* stream);
 /* The firmware's whole per-frame pipeline in ONE launch (stm32/User/main.c:42-54): camera frames d_rgb565 uint8[n][112][112][2]

@@ -86,7 +86,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_destroy", "ai_network_get_info", "ai_network_get_report", "ai_network_data_weights_get",
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
-           "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
+           "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_pack_detections_device", "yf_network_unpack_detections_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
            "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_release_stream", "yf_network_scratch_bytes", "yf_network_last_error_text",
            "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id", "yf_network_host_id",
            "ai_platform_observer_node_info", "ai_platform_observer_register", "ai_platform_observer_register_s",
@@ -234,6 +234,10 @@ def load():
     lib.yf_network_run_device_hw.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, cl, vp]
     lib.yf_network_decode_device.restype = cl
     lib.yf_network_decode_device.argtypes = [vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
+    lib.yf_network_pack_detections_device.restype = cl
+    lib.yf_network_pack_detections_device.argtypes = [vp, vp, vp, vp, vp, cl, ctypes.c_int, vp]
+    lib.yf_network_unpack_detections_device.restype = cl
+    lib.yf_network_unpack_detections_device.argtypes = [vp, vp, vp, vp, cl, ctypes.c_int, vp]
     lib.yf_network_run_decode_device.restype = cl
     lib.yf_network_run_decode_device.argtypes = [vp, vp, vp, cl, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_int, vp]
     lib.yf_network_prepare_rgb565_device.restype = cl
@@ -412,6 +416,16 @@ class Network:
     def decode_device(self, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
         if self.lib.yf_network_decode_device(self.handle, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream) != n:
             self._raise("yf_network_decode_device")
+
+    def pack_detections_device(self, d_dets, d_counts, d_heads, d_wire, n, cap, stream=None):
+        """yf_det records -> 12-byte wire records (one launch; include/yf_network.h)."""
+        if self.lib.yf_network_pack_detections_device(self.handle, d_dets, d_counts, d_heads, d_wire, n, cap, stream) != n:
+            self._raise("yf_network_pack_detections_device")
+
+    def unpack_detections_device(self, d_wire, d_counts, d_heads, n, cap, stream=None):
+        """wire records + counts -> the sparse int8 heads they stand for (decode_device on them gives the sender's records)."""
+        if self.lib.yf_network_unpack_detections_device(self.handle, d_wire, d_counts, d_heads, n, cap, stream) != n:
+            self._raise("yf_network_unpack_detections_device")
 
     def run_decode_device(self, d_in, d_heads, n, d_dets, d_counts, cap, mode=YF_DECODE_PY, w_scale=1.0, h_scale=1.0, stream=None):
         """Network + box decode in one launch (heads are decoded while still in LDS)."""

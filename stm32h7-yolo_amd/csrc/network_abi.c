@@ -461,6 +461,18 @@ YF_API long yf_network_decode_device(ai_handle network, const void* d_heads, lon
   return finish(c, yf_engine_decode_device(c->engine, d_heads, n, mode, w_scale, h_scale, d_dets, d_counts, cap, stream), n);
 }
 
+YF_API long yf_network_pack_detections_device(ai_handle network, const void* d_dets, const void* d_counts, const void* d_heads, void* d_wire, long n, int cap, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_pack_detections_device(c->engine, d_dets, d_counts, d_heads, d_wire, n, cap, stream), n);
+}
+
+YF_API long yf_network_unpack_detections_device(ai_handle network, const void* d_wire, const void* d_counts, void* d_heads, long n, int cap, void* stream) {
+  yf_context* c = ready(network);
+  if (!c) return 0;
+  return finish(c, yf_engine_unpack_detections_device(c->engine, d_wire, d_counts, d_heads, n, cap, stream), n);
+}
+
 YF_API long yf_network_run_decode_device(ai_handle network, const void* d_in, void* d_heads, long n, int mode, float w_scale, float h_scale,
                                          void* d_dets, void* d_counts, int cap, void* stream) {
   yf_context* c = ready(network);

@@ -37,6 +37,9 @@ int  yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode
 /* network + box decode in ONE launch: every workgroup decodes its frames' heads while they are still in LDS */
 int  yf_engine_run_decode_device(yf_engine* e, const void* d_in, void* d_out, long n, int mode, float w_scale, float h_scale,
                                  void* d_dets, void* d_counts, int cap, void* stream);
+/* 28-byte yf_det records <-> 12-byte wire records (yf_network_pack_detections_device in include/yf_network.h) */
+int  yf_engine_pack_detections_device(yf_engine* e, const void* d_dets, const void* d_counts, const void* d_heads, void* d_wire, long n, int cap, void* stream);
+int  yf_engine_unpack_detections_device(yf_engine* e, const void* d_wire, const void* d_counts, void* d_heads, long n, int cap, void* stream);
 int  yf_engine_prepare_rgb565_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, void* stream);
 /* camera frames -> heads (+ detections if d_dets != NULL) in one launch: frame preparation fused into the input staging */
 int  yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out, long n, int mode, float w_scale, float h_scale,

@@ -42,6 +42,47 @@ __global__ void __launch_bounds__(256) decode_kernel(const int8_t* __restrict__ 
   yfdec::decode_frame(heads + frame * 882, frame, lane, mode, w_scale, h_scale, dets, counts, cap);
 }
 
+// ---------------------------------------------------------------------------------------------- compact wire records (multi-GPU exchange)
+// A yf_det (28 B) carries its frame index (= its position), a float confidence and four int32 box edges -- all functions of the firing cell's six int8
+// head values.  The WIRE form of a record is 12 bytes: {u8 anchor, row, col, 0, i8 q[6], u16 0}; lossless whatever the edges are.  One thread per record;
+// slots beyond min(count, cap) are written as zeros (the record buffer may hold stale bytes there).
+__global__ void __launch_bounds__(256) pack_dets_kernel(const yf_det* __restrict__ dets, const int* __restrict__ counts, const int8_t* __restrict__ heads,
+                                                        uint32_t* __restrict__ wire, long n, int cap) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * cap) return;
+  const long f = i / cap;
+  const int k = (int)(i - f * cap);
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
+  if (k < min(counts[f], cap)) {
+    const yf_det d = dets[i];
+    const int8_t* q = heads + f * 882 + ((int)d.row * 7 + (int)d.col) * 18 + 6 * (int)d.anchor;
+    w0 = (uint32_t)d.anchor | ((uint32_t)d.row << 8) | ((uint32_t)d.col << 16);
+    w1 = (uint32_t)(uint8_t)q[0] | ((uint32_t)(uint8_t)q[1] << 8) | ((uint32_t)(uint8_t)q[2] << 16) | ((uint32_t)(uint8_t)q[3] << 24);
+    w2 = (uint32_t)(uint8_t)q[4] | ((uint32_t)(uint8_t)q[5] << 8);
+  }
+  wire[3 * i] = w0; wire[3 * i + 1] = w1; wire[3 * i + 2] = w2;
+}
+// The receiving side: the sparse int8 head a frame's wire records stand for -- -128 everywhere (a confidence logit that never fires), the six values of
+// every transmitted (anchor, row, col) in their place.  Decoding it (decode_kernel) gives the sender's records in the sender's order.  One wave per frame.
+__global__ void __launch_bounds__(256) unpack_dets_kernel(const uint32_t* __restrict__ wire, const int* __restrict__ counts, int8_t* __restrict__ heads, long n, int cap) {
+  const int lane = threadIdx.x & 63;
+  const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= n) return;
+  int8_t* h = heads + f * 882;
+  for (int b = lane; b < 882; b += 64) h[b] = (int8_t)-128;
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const int m = min(counts[f], cap);
+  for (int k = lane; k < m; k += 64) {
+    const uint32_t w0 = wire[3 * (f * cap + k)], w1 = wire[3 * (f * cap + k) + 1], w2 = wire[3 * (f * cap + k) + 2];
+    const int a = (int)(w0 & 255u), row = (int)((w0 >> 8) & 255u), col = (int)((w0 >> 16) & 255u);
+    if (a > 2 || row > 6 || col > 6) continue;                  // not a record this library packed
+    int8_t* q = h + (row * 7 + col) * 18 + 6 * a;
+    q[0] = (int8_t)(w1 & 255u); q[1] = (int8_t)((w1 >> 8) & 255u); q[2] = (int8_t)((w1 >> 16) & 255u); q[3] = (int8_t)(w1 >> 24);
+    q[4] = (int8_t)(w2 & 255u); q[5] = (int8_t)((w2 >> 8) & 255u);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- frame preparation
 // stm32/X-CUBE-AI/App/yoloface.c:26-93: 112x112 big-endian RGB565 -> 2x2 box average per 5/6/5 field -> re-pack ->
 // shift-expand -> value-128.  One thread per output pixel; 4 x 2-byte loads, 3 byte stores.
@@ -661,6 +702,26 @@ int yf_engine_decode_device(yf_engine* e, const void* d_heads, long n, int mode,
   HIPCHK(e, hipSetDevice(e->device));
   hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const int8_t*)d_heads, n, mode, w_scale, h_scale, (yf_det*)d_dets, (int*)d_counts, cap);
+  HIPCHK(e, hipGetLastError());
+  return YF_ENG_OK;
+}
+
+int yf_engine_pack_detections_device(yf_engine* e, const void* d_dets, const void* d_counts, const void* d_heads, void* d_wire, long n, int cap, void* stream) {
+  if (!e || !d_dets || !d_counts || !d_heads || !d_wire || n < 0 || cap <= 0 || ((uintptr_t)d_wire & 3) != 0 || ((uintptr_t)d_dets & 3) != 0) return YF_ENG_ERR_ARG;
+  if (n == 0) return YF_ENG_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(pack_dets_kernel, dim3((unsigned)((n * cap + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const yf_det*)d_dets, (const int*)d_counts, (const int8_t*)d_heads, (uint32_t*)d_wire, n, cap);
+  HIPCHK(e, hipGetLastError());
+  return YF_ENG_OK;
+}
+
+int yf_engine_unpack_detections_device(yf_engine* e, const void* d_wire, const void* d_counts, void* d_heads, long n, int cap, void* stream) {
+  if (!e || !d_wire || !d_counts || !d_heads || n < 0 || cap <= 0 || ((uintptr_t)d_wire & 3) != 0) return YF_ENG_ERR_ARG;
+  if (n == 0) return YF_ENG_OK;
+  HIPCHK(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(unpack_dets_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)d_wire, (const int*)d_counts, (int8_t*)d_heads, n, cap);
   HIPCHK(e, hipGetLastError());
   return YF_ENG_OK;
 }

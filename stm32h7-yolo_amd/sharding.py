@@ -28,6 +28,29 @@ class _HostGather:
         self.dev_out.copy_(self.host_out)
 
 
+import os as _os
+_WHATIF_COPY = _os.environ.get("YF_EXCHANGE_WHATIF", "")          # "copy" | "copy_engine": tools only (see _SideCopy)
+
+
+class _SideCopy:
+    """What-if stand-in for a one-rank all-gather: dst <- src on a side stream ordered behind the current stream, wait() orders the current stream behind it.
+    "copy": a copy kernel (torch); "copy_engine": hipMemcpyAsync through torch's non-blocking copy -- both leave RCCL and c10d's bookkeeping out."""
+    _side = None
+
+    def __init__(self, dst, src, device):
+        if _SideCopy._side is None:
+            _SideCopy._side = torch.cuda.Stream(device)
+        side = _SideCopy._side
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            dst.copy_(src, non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record(side)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class Slot:
     """Where one step's results go: slot `k` of buffer `i` (a buffer holds `gather_every` steps)."""
     __slots__ = ("i", "k")
@@ -79,8 +102,8 @@ class DetectionExchange:
     aligned sections).  A BUFFER holds `gather_every` (K) such blocks -- K consecutive steps -- and ONE all_gather_into_tensor per buffer
     sends them: K = 1 (default) is the north star's all-gather per step; K > 1 trades latency of the results for collectives (the exchange is
     latency-bound at these sizes -- 0.48 MB per rank and step --, so one collective per K steps costs one launch + handshake, not K, at K x the
-    bytes).  `n_buf` buffers alternate (two at N > 1): the all-gather of a buffer is asynchronous and runs while the kernels of the next K
-    steps fill the other one; a buffer is handed out again (`acquire`) only after `wait()` on the gather that last read it.  `compact` sends
+    bytes).  `n_buf` buffers alternate (two at N > 1, four with two launch streams): the all-gather of a buffer is asynchronous and runs while the
+    kernels of the next steps fill the others; a buffer is handed out again (`acquire`) only after `wait()` on the gather that last read it.  `compact` sends
     12-byte wire records instead of the 28-byte yf_det (`pack_compact`: 0.21 MB instead of 0.48 MB per rank and step at cap 4, lossless); the
     28-byte records stay what the kernel writes and what the C side reads.  Every rank's shard has the same size n (weak scaling: fixed-shape
     collective, no padding).
@@ -96,11 +119,16 @@ class DetectionExchange:
     stream waits for the gather too.  With K = 1 and as many buffers as streams a buffer always meets the same stream and no cross-stream wait
     is ever issued."""
 
-    def __init__(self, n, cap, world, device, gather_heads=False, backend=None, n_buf=None, group=None, gather_every=1, compact=False, launch_streams=None):
+    def __init__(self, n, cap, world, device, gather_heads=False, backend=None, n_buf=None, group=None, gather_every=1, compact=False, launch_streams=None, always=False, packer=None, unpacker=None):
         self.n, self.cap, self.world, self.device, self.group = n, cap, world, torch.device(device), group
         self.gather_heads, self.compact, self.K = bool(gather_heads), bool(compact), int(gather_every)
+        self.active = world > 1 or bool(always)    # `always`: issue the collective in a ONE-rank group too (rehearsal of the RCCL path on a one-GPU box)
         assert self.K >= 1
         self.launch_streams = list(launch_streams) if launch_streams else []
+        # compact records on a GPU: ONE launch of the library's pack kernel per step (packer(dets_ptr, counts_ptr, heads_ptr, wire_ptr, n, cap) on the current
+        # stream: Network.pack_detections_device) -- the tensor-op form below is a dozen small launches, each a neighbour of the CU-filling kernel (+100 us per
+        # step in the one-rank rehearsal); it stays as the statement of the format and as what the CPU (gloo) tests run
+        self.packer, self.unpacker = packer, unpacker
         self.off_c = (n * cap * DET_BYTES + 15) & ~15
         self.off_h = (self.off_c + n * 4 + 15) & ~15
         self.rec_bytes = self.off_h + (((n * HEAD_BYTES + 15) & ~15) if gather_heads else 0)         # one step's block as the kernel fills it
@@ -108,14 +136,18 @@ class DetectionExchange:
         self.w_off_c = (n * cap * WIRE_DET_BYTES + 15) & ~15
         self.w_off_h = (self.w_off_c + n * 4 + 15) & ~15
         self.wire_rec_bytes = (self.w_off_h + (((n * HEAD_BYTES + 15) & ~15) if gather_heads else 0)) if self.compact else self.rec_bytes
-        self.n_buf = n_buf if n_buf is not None else max(2 if world > 1 else 1, len(self.launch_streams))
-        self.backend = backend or (dist.get_backend(group) if world > 1 else "none")
+        # buffers that alternate.  A kernel waits for the gather that last read ITS buffer; on a GPU that the kernels fill, that gather only gets to run when the
+        # step behind its own drains -- with two launch streams and two buffers every kernel then waits for a gather that is waiting for the kernel in front
+        # of it (+13 us per step in the one-rank rehearsal, profiles/r05_exchange_one_rank.txt); with twice as many buffers as streams the gather a kernel waits
+        # for is four steps old and long done (+0.7 us).  (A multiple of the stream count: a buffer then always meets the same stream.)
+        self.n_buf = n_buf if n_buf is not None else (max(2, 2 * len(self.launch_streams)) if self.active else max(1, len(self.launch_streams)))
+        self.backend = backend or (dist.get_backend(group) if self.active else "none")
         dev, K = self.device, self.K
         self.local = [torch.zeros((K * self.rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(self.n_buf)]
         self._heads = [[self._block(self.local[i], k)[self.off_h:self.off_h + n * HEAD_BYTES] if gather_heads
                         else torch.zeros((n * HEAD_BYTES,), dtype=torch.uint8, device=dev) for k in range(K)] for i in range(self.n_buf)]
-        self.wire = [torch.zeros((K * self.wire_rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(self.n_buf)] if (self.compact and world > 1) else self.local
-        self.gathered = [torch.zeros((world * K * self.wire_rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(self.n_buf)] if world > 1 else []
+        self.wire = [torch.zeros((K * self.wire_rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(self.n_buf)] if (self.compact and self.active) else self.local
+        self.gathered = [torch.zeros((world * K * self.wire_rec_bytes,), dtype=torch.uint8, device=dev) for _ in range(self.n_buf)] if self.active else []
         self.pending = [None] * self.n_buf
         self.filled = [0] * self.n_buf      # slots of the buffer filled since it was acquired
         self.step_no = 0
@@ -190,12 +222,17 @@ class DetectionExchange:
             for k in range(self.filled[i]):
                 blk, wblk = self._block(self.local[i], k), self._block(self.wire[i], k, self.wire_rec_bytes)
                 counts = blk[self.off_c:self.off_c + self.n * 4].view(torch.int32)
-                wblk[:self.n * self.cap * WIRE_DET_BYTES] = pack_compact(blk[:self.n * self.cap * DET_BYTES], counts, self._heads[i][k], self.n, self.cap)
+                if self.packer is not None:
+                    self.packer(blk.data_ptr(), blk.data_ptr() + self.off_c, self._heads[i][k].data_ptr(), wblk.data_ptr(), self.n, self.cap)
+                else:
+                    wblk[:self.n * self.cap * WIRE_DET_BYTES] = pack_compact(blk[:self.n * self.cap * DET_BYTES], counts, self._heads[i][k], self.n, self.cap)
                 wblk[self.w_off_c:self.w_off_c + self.n * 4] = blk[self.off_c:self.off_c + self.n * 4]
                 if self.gather_heads:
                     wblk[self.w_off_h:self.w_off_h + self.n * HEAD_BYTES] = self._heads[i][k]
         self.collectives += 1
-        if self.backend == "nccl":            # RCCL on the device buffers, on RCCL's own stream
+        if self.backend == "nccl" and self.world == 1 and _WHATIF_COPY:   # dev what-if (one-rank rehearsal only): the same stream / event pattern around a plain device copy
+            self.pending[i] = _SideCopy(self.gathered[i], self.wire[i], self.device)
+        elif self.backend == "nccl":          # RCCL on the device buffers, on RCCL's own stream
             self.pending[i] = dist.all_gather_into_tensor(self.gathered[i], self.wire[i], group=self.group, async_op=True)
         else:                                 # rehearsal: the same collective over host copies of the same buffers
             host_in = self.wire[i].cpu()
@@ -206,11 +243,11 @@ class DetectionExchange:
     def exchange(self, slot):
         i, k = self._ik(slot)
         self.filled[i] = k + 1
-        if self.world > 1 and k == self.K - 1:
+        if self.active and k == self.K - 1:
             self._send(i)
 
     def drain(self):
-        if self.world > 1:
+        if self.active:
             for i in range(self.n_buf):       # a buffer the run ended in the middle of: its filled slots are sent (fixed-shape collective)
                 if self.pending[i] is None and 0 < self.filled[i] < self.K:
                     self._send(i)
@@ -218,7 +255,7 @@ class DetectionExchange:
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
-            self.filled[i] = 0 if self.world > 1 else self.filled[i]
+            self.filled[i] = 0 if self.active else self.filled[i]
 
     # ---- what every rank must hold after exchange(slot) + drain(): every rank's blocks, in rank (= frame) order
     def check_gathered(self, slot, rank):
@@ -241,4 +278,10 @@ class DetectionExchange:
         """compact form: the sparse int8 heads [world * n, 7, 7, 18] the gathered records of the slot stand for (decode them to get yf_det records)"""
         i, k = self._ik(slot)
         assert self.compact
+        if self.unpacker is not None:          # unpacker(wire_ptr, counts_ptr, heads_ptr, n, cap): Network.unpack_detections_device, one launch per rank's block
+            out = torch.empty((self.world * self.n, 7, 7, 18), dtype=torch.int8, device=self.device)
+            for r in range(self.world):
+                w, c = self.wire_views(self.gathered[i], r, k)
+                self.unpacker(w.data_ptr(), c.data_ptr(), out[r * self.n:(r + 1) * self.n].data_ptr(), self.n, self.cap)
+            return out
         return torch.cat([unpack_compact(*self.wire_views(self.gathered[i], r, k), self.n, self.cap) for r in range(self.world)])

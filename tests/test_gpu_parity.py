@@ -915,6 +915,62 @@ def test_bench_two_ranks_gather_heads_and_a_failing_rank():
     assert json.loads(lines[0])["parity"].startswith("FAILED")
 
 
+def test_compact_wire_records_on_the_gpu(yf, network, oracle, torch_cuda):
+    """yf_network_pack_detections_device / _unpack_ (the 12-byte wire form of the multi-GPU exchange, one launch each): the packed bytes equal the tensor-op
+    statement of the format (sharding.pack_compact) also where the record buffer holds stale bytes beyond a frame's count; the sparse heads equal
+    sharding.unpack_compact's; and decoding the sparse heads on the GPU reproduces the sender's records -- min(count, cap) per frame, same order, every
+    field -- for both a cap that holds every candidate and one that does not."""
+    torch = torch_cuda
+    sh = importlib.import_module("stm32h7-yolo_amd.sharding")
+    frames = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    x = np.concatenate([frames, rnd(77, 229)])                     # real images (they fire) and noise, 256 frames
+    n = x.shape[0]
+    d_in = torch.from_numpy(x).cuda()
+    for cap in (2, 6):
+        d_h = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+        d_d = torch.full((n * cap * 28,), 0xAB, dtype=torch.uint8, device="cuda")      # stale bytes everywhere the kernel does not write
+        d_c = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        network.run_decode_device(d_in.data_ptr(), d_h.data_ptr(), n, d_d.data_ptr(), d_c.data_ptr(), cap)
+        wire = torch.full((n * cap * 12,), 0xCD, dtype=torch.uint8, device="cuda")
+        network.pack_detections_device(d_d.data_ptr(), d_c.data_ptr(), d_h.data_ptr(), wire.data_ptr(), n, cap)
+        torch.cuda.synchronize()
+        assert int((d_c > cap).sum()) > 0 or cap == 6
+        want = sh.pack_compact(d_d, d_c, d_h.view(torch.uint8).view(-1), n, cap)
+        assert torch.equal(wire, want)
+        sparse = torch.zeros((n, 7, 7, 18), dtype=torch.int8, device="cuda")
+        network.unpack_detections_device(wire.data_ptr(), d_c.data_ptr(), sparse.data_ptr(), n, cap)
+        torch.cuda.synchronize()
+        assert torch.equal(sparse, sh.unpack_compact(wire, d_c, n, cap))
+        r_d = torch.zeros((n * cap * 28,), dtype=torch.uint8, device="cuda")
+        r_c = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        network.decode_device(sparse.data_ptr(), n, r_d.data_ptr(), r_c.data_ptr(), cap)
+        torch.cuda.synchronize()
+        kept = torch.arange(cap, device="cuda")[None, :] < d_c.clamp(max=cap)[:, None]
+        assert torch.equal(r_c, d_c.clamp(max=cap)) and int(r_c.sum()) > 0
+        assert torch.equal(r_d.view(n, cap, 28)[kept], d_d.view(n, cap, 28)[kept])
+
+
+def test_bench_exchange_through_rccl_in_a_one_rank_group():
+    """The torch.distributed / RCCL calls of bench.py's N > 1 path have never run with more than one rank (no multi-GPU box), and RCCL refuses two
+    ranks on one device -- so they are executed here in a ONE-rank group (`--rccl-one-rank`): process group with backend nccl bound to the device,
+    asynchronous all_gather_into_tensor of the packed uint8 records on RCCL's stream behind kernels on TWO launch streams, `wait()` from the launch
+    stream before a buffer is reused, barrier, all-reduce of the time and of the verdict, gathered-record checks.  Once per step with 28-byte records,
+    once per two steps with the 12-byte wire records (the receiver-side decode of the sparse heads runs on the GPU)."""
+    import json
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rccl-one-rank", "--steps", "5", "--warmup", "2", "--clock-settle-ms", "5"]
+    for extra, rec in ([], 4096 * (4 * 28 + 4)), (["--gather-every", "2", "--compact-records"], 4096 * (4 * 12 + 4)):
+        r = subprocess.run(cmd + extra, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == 1 and line["all_gather_ok"] is True and line["parity"].startswith("every rank")
+        assert line["config"]["exchange_bytes_per_rank_per_step"] == rec and line["config"]["launch_streams"] == 2 and "rehearsal" in line["config"]
+        assert line["config"]["collectives_issued"] >= 1
+
+
 def test_c_level_all_gather_through_rccl(network, torch_cuda):
     """yf_network_all_gather_device: the exchange step a C host application calls (one process per GPU, its own ncclComm_t).
     With one GPU on the box the communicator has one rank; the call still goes through librccl's ncclAllGather on the
