@@ -28,29 +28,6 @@ class _HostGather:
         self.dev_out.copy_(self.host_out)
 
 
-import os as _os
-_WHATIF_COPY = _os.environ.get("YF_EXCHANGE_WHATIF", "")          # "copy" | "copy_engine": tools only (see _SideCopy)
-
-
-class _SideCopy:
-    """What-if stand-in for a one-rank all-gather: dst <- src on a side stream ordered behind the current stream, wait() orders the current stream behind it.
-    "copy": a copy kernel (torch); "copy_engine": hipMemcpyAsync through torch's non-blocking copy -- both leave RCCL and c10d's bookkeeping out."""
-    _side = None
-
-    def __init__(self, dst, src, device):
-        if _SideCopy._side is None:
-            _SideCopy._side = torch.cuda.Stream(device)
-        side = _SideCopy._side
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            dst.copy_(src, non_blocking=True)
-            self.ev = torch.cuda.Event()
-            self.ev.record(side)
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
 class Slot:
     """Where one step's results go: slot `k` of buffer `i` (a buffer holds `gather_every` steps)."""
     __slots__ = ("i", "k")
@@ -230,9 +207,7 @@ class DetectionExchange:
                 if self.gather_heads:
                     wblk[self.w_off_h:self.w_off_h + self.n * HEAD_BYTES] = self._heads[i][k]
         self.collectives += 1
-        if self.backend == "nccl" and self.world == 1 and _WHATIF_COPY:   # dev what-if (one-rank rehearsal only): the same stream / event pattern around a plain device copy
-            self.pending[i] = _SideCopy(self.gathered[i], self.wire[i], self.device)
-        elif self.backend == "nccl":          # RCCL on the device buffers, on RCCL's own stream
+        if self.backend == "nccl":            # RCCL on the device buffers, on RCCL's own stream
             self.pending[i] = dist.all_gather_into_tensor(self.gathered[i], self.wire[i], group=self.group, async_op=True)
         else:                                 # rehearsal: the same collective over host copies of the same buffers
             host_in = self.wire[i].cpu()
