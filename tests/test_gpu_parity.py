@@ -915,6 +915,22 @@ def test_bench_two_ranks_gather_heads_and_a_failing_rank():
     assert json.loads(lines[0])["parity"].startswith("FAILED")
 
 
+def test_the_bench_step_from_a_pure_c_host():
+    """tools/c_host/yf_bench.c: the reference's aiInit sequence and the bench step (one yf_network_run_decode_device launch per 4096-frame batch, two
+    alternating HIP streams) from a C program that links libyf_network.so and the HIP runtime only -- no Python, no PyTorch.  north_star: "host code in C
+    calling HIP through a thin FFI".  The golden frames inside its first batch must give the golden heads, and its rate must be the bench's (a floor of
+    20 M images/s here: the exact figure is box-dependent and recorded in profiles/)."""
+    import json
+    exe = os.path.join(ROOT, "stm32h7-yolo_amd", "lib", "yf_c_bench")
+    if not os.path.exists(exe):
+        pytest.skip("stm32h7-yolo_amd/lib/yf_c_bench was not built (make -C stm32h7-yolo_amd/csrc chost)")
+    r = subprocess.run([exe, ROOT, "200", "50", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["golden_heads_equal"] is True and line["detections_on_the_real_frame"] > 0 and line["launch_streams"] == 2
+    assert line["value"] > 20e6 and 0.10 < line["kernel_ms_alone"] < 0.20
+
+
 def test_compact_wire_records_on_the_gpu(yf, network, oracle, torch_cuda):
     """yf_network_pack_detections_device / _unpack_ (the 12-byte wire form of the multi-GPU exchange, one launch each): the packed bytes equal the tensor-op
     statement of the format (sharding.pack_compact) also where the record buffer holds stale bytes beyond a frame's count; the sparse heads equal
