@@ -37,6 +37,7 @@ VALU_CYCLES_PER_INSTR = 4.0                  # issue cost of a wave64 VALU instr
                                              # ops, 2.3-2.7 for add/and/shift/mov (profiles/r01_e_valu_issue_rates.txt)
 A160_BYTES_PER_FRAME = 160 * 160 * 3 + 20 * 20 * 18          # 84 000 B: algorithmic bytes of the 160x160 variant
 FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp32 logits out
+CAMERA_BYTES_PER_FRAME = 112 * 112 * 2 + 7 * 7 * 18          # RGB565 camera frame in, int8 head out (the prepared 56x56 frame never exists in HBM)
 PROFILE_160 = "profiles/r05_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
 PROFILE_FP16 = "profiles/r05_fp16/summary.json"              # stamped with the build id they were taken on
 
@@ -177,8 +178,11 @@ def secondary_camera(net, dev, stream, settle_ms=60.0, iters=20):
         one(); two()
     settle(one, settle_ms)
     ms1, ms2 = event_time_ms(stream, one, iters), event_time_ms(stream, two, iters)
+    gbs = n * CAMERA_BYTES_PER_FRAME / (ms1 * 1e-3) / 1e9
     return {"workload": "batch=4096 camera frames (112x112 big-endian RGB565, 25 088 B each) -> int8 heads + firmware-mode boxes",
-            "ms_per_step": round(ms1, 4), "timed_steps": iters, "images_per_s": round(n / ms1 * 1e3, 1),
+            "ms_per_step": round(ms1, 4), "timed_steps": iters, "images_per_s": round(n / ms1 * 1e3, 1), "algorithmic_bytes_per_step": n * CAMERA_BYTES_PER_FRAME,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                         "traffic_missing": "no counter pass is taken on this section (algorithmic bytes: the camera frame in, the head out)"},
             "two_launch_form_ms_per_step": round(ms2, 4), "two_launch_form_images_per_s": round(n / ms2 * 1e3, 1)}
 
 
