@@ -38,6 +38,7 @@ VALU_CYCLES_PER_INSTR = 4.0                  # issue cost of a wave64 VALU instr
 A160_BYTES_PER_FRAME = 160 * 160 * 3 + 20 * 20 * 18          # 84 000 B: algorithmic bytes of the 160x160 variant
 FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp32 logits out
 CAMERA_BYTES_PER_FRAME = 112 * 112 * 2 + 7 * 7 * 18          # RGB565 camera frame in, int8 head out (the prepared 56x56 frame never exists in HBM)
+PROFILE_CAMERA = "profiles/r05_camera/summary.json"
 PROFILE_160 = "profiles/r05_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
 PROFILE_FP16 = "profiles/r05_fp16/summary.json"              # stamped with the build id they were taken on
 
@@ -73,6 +74,17 @@ def stamped_profile(rel_path, hash_of):
     if h != kernel_source_hash():
         return None, f"{rel_path} was taken on build {h}, this build is {kernel_source_hash()}"
     return d, None
+
+
+def _stamped_traffic(rel_path):
+    """roofline.traffic (+ the trace's kernel time) of a side configuration from its stamped summary, or null with the reason"""
+    prof, why = stamped_profile(rel_path, lambda d: d.get("total", {}).get("source_hash"))
+    if not prof:
+        return {"traffic": None, "traffic_missing": why}
+    out = {"traffic": round(prof["total"]["hbm_bytes_per_batch"]), "traffic_source": f"{rel_path} (FETCH_SIZE / WRITE_SIZE passes, bytes per step)"}
+    if prof["total"].get("timed_kernel_us_sum"):
+        out["kernel_us_in_trace"] = round(prof["total"]["timed_kernel_us_sum"], 2)
+    return out
 
 
 def cpu_model():
@@ -182,7 +194,8 @@ def secondary_camera(net, dev, stream, settle_ms=60.0, iters=20):
     return {"workload": "batch=4096 camera frames (112x112 big-endian RGB565, 25 088 B each) -> int8 heads + firmware-mode boxes",
             "ms_per_step": round(ms1, 4), "timed_steps": iters, "images_per_s": round(n / ms1 * 1e3, 1), "algorithmic_bytes_per_step": n * CAMERA_BYTES_PER_FRAME,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                         "traffic_missing": "no counter pass is taken on this section (algorithmic bytes: the camera frame in, the head out)"},
+                         **_stamped_traffic(PROFILE_CAMERA)},
+            "kernel": "yoloface56_fused<F=2,NW=8,RGB565 input>", "kernel_source_hash": kernel_source_hash(),
             "two_launch_form_ms_per_step": round(ms2, 4), "two_launch_form_images_per_s": round(n / ms2 * 1e3, 1)}
 
 

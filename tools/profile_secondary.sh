@@ -3,7 +3,7 @@
 #   python3 bench.py --only-secondary <section>     (same clock settle, same timed region as the `secondary` entry of the full line)
 # Kernel trace first (default settle and steps), then the counter groups in SEPARATE passes (short: per-launch counts do not depend on the
 # clock state; gpurun refuses --pmc combined with trace domains other than --kernel-trace).  Results -> gpurun_out/prof_sec/<section>/<tag>/
-#   usage (through gpurun): bash tools/profile_secondary.sh <fp16_56x56|int8_160x160> <tag>
+#   usage (through gpurun): bash tools/profile_secondary.sh <fp16_56x56|int8_160x160|camera_rgb565_112x112> <tag>
 set -u
 SEC=${1:?section}; TAG=${2:-run}
 OUT=$PWD/gpurun_out/prof_sec/$SEC/$TAG

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Collapse the rocprofv3 CSVs of tools/profile_secondary.sh (taken on `bench.py --only-secondary <section>`) into summary.json.
 
-   usage: summarize_secondary.py <out_dir> <fp16_56x56|int8_160x160>
+   usage: summarize_secondary.py <out_dir> <fp16_56x56|int8_160x160|camera_rgb565_112x112>
 
    Kernel time comes in two forms, both over FULL-BATCH launches only: `avg_us` over every launch of the command (warm-up and clock-settle
    launches included) and `timed_avg_us` over the LAST `timed_steps` launches -- the ones between the bench's two HIP events.  The line the
@@ -14,7 +14,10 @@ import os
 import sys
 
 SECTIONS = {"fp16_56x56": (("f16_fused",), 4096, 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4),
-            "int8_160x160": (("band_k1", "band_k23", "band_k4"), 1024, 160 * 160 * 3 + 20 * 20 * 18)}
+            "int8_160x160": (("band_k1", "band_k23", "band_k4"), 1024, 160 * 160 * 3 + 20 * 20 * 18),
+            # the camera-input build of the fused kernel (template arguments <2, 8, false, true>); the section also times the two-launch form, whose launches
+            # (prepare_rgb565_kernel + the int8-input build) do not carry this name
+            "camera_rgb565_112x112": (("8, false, true>",), 4096, 112 * 112 * 2 + 7 * 7 * 18)}
 
 
 def short(name, keys):
