@@ -126,6 +126,50 @@ def test_edge_frames(network, oracle):
     assert np.array_equal(network.run(x), oracle.run(x))
 
 
+def test_structured_extreme_frames(network, oracle, torch_cuda):
+    """Frames built to drive accumulators and requantisation to their edges rather than to look like images: the eight corner colours, stripes and
+    checkerboards of +127 / -128 at periods 1, 2, 4 and 7 (stride-2 layers see them in and out of phase), single hot and cold pixels at the borders and
+    corners (the halo / padding paths), frames matched to the SIGN of conv2d_1's weights for each of its eight output channels (the largest accumulators
+    that layer can produce, both signs), and per-pixel random extremes.  Every head byte must equal the oracle's, through the device path on a ragged batch."""
+    torch = torch_cuda
+    from oracle.np_restatement import load_yfm
+    m = load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+    frames = []
+    for r in (-128, 127):
+        for g in (-128, 127):
+            for b in (-128, 127):
+                frames.append(np.broadcast_to(np.array([r, g, b], np.int8), (56, 56, 3)).copy())
+    yy, xx = np.mgrid[0:56, 0:56]
+    for period in (1, 2, 4, 7):
+        for pat in ((xx // period) % 2, (yy // period) % 2, ((xx // period) + (yy // period)) % 2):
+            f = np.where(pat[..., None] == 1, 127, -128).astype(np.int8)
+            frames += [np.broadcast_to(f, (56, 56, 3)).copy(), (-1 - np.broadcast_to(f, (56, 56, 3))).astype(np.int8)]
+    for (y, x) in ((0, 0), (0, 55), (55, 0), (55, 55), (0, 27), (27, 0), (55, 28), (28, 55), (27, 27)):
+        for base, hot in ((-128, 127), (127, -128), (0, 127)):
+            f = np.full((56, 56, 3), base, np.int8)
+            f[y, x] = hot
+            frames.append(f)
+    conv1 = next(o for o in m["ops"] if o["op"] == 3)                            # CONV_2D #1: conv2d_1, 3x3 stride 2 behind the explicit top/left PAD
+    w = np.asarray(m["tensors"][conv1["ins"][1]]["data"]).reshape(8, 3, 3, 3)   # OHWI int8
+    ky = np.where((np.arange(56) + 1) % 2 == 1, 1, 0)                             # input row y is padded row y + 1: odd -> the window's middle tap, even -> its first
+    for o in range(8):
+        for sign in (1, -1):
+            t = w[o][ky][:, ky].astype(np.int32) * sign                           # [56, 56, 3]: the weight each input value meets in (one of) its windows
+            frames.append(np.where(t >= 0, 127, -128).astype(np.int8))
+    rng = np.random.default_rng(99)
+    frames += list(np.where(rng.integers(0, 2, (12, 56, 56, 3)) == 1, 127, -128).astype(np.int8))
+    x = np.stack(frames)
+    ref = oracle.run(x, threads=16)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.full((x.shape[0] + 1, 7, 7, 18), 55, dtype=torch.int8, device="cuda")
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), x.shape[0])
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:-1], ref) and (got[-1] == 55).all()
+    assert len({ref[i].tobytes() for i in range(ref.shape[0])}) > ref.shape[0] // 2      # the frames do reach different heads (not all saturated to one answer)
+    assert np.array_equal(network.run(x), ref)                                            # and through ai_network_run on host arrays
+
+
 def test_every_fused_stage_equals_the_matching_tflite_op(network, oracle, torch_cuda):
     """Observer-style dump (yf_network_run_device_dump) vs the oracle's per-op outputs: the 25 fused stage tensors and the six
     tensors only the per-node observer needs (raw max-pools, the convolutions in front of the residual adds, LEAKY_RELU #43 alone)."""
@@ -424,6 +468,47 @@ def test_baseline_config5_160x160(network, oracle, torch_cuda):
     with pytest.raises(Exception) as ei:
         network.run_device_hw(64, 64, d_in.data_ptr(), d_out.data_ptr(), 1)
     assert (ei.value.type, ei.value.code) == (0x12, 0x18)
+
+
+def test_160x160_band_edges(network, oracle, torch_cuda):
+    """The banded 160x160 kernels cut a frame into row bands (band_k1: 16 rows of the 80x80 grid = 32 input rows; band_k23: 8 rows of 40x40 = 32 input rows;
+    band_k4 takes T15 in two halves) and pass halo rows between them through HBM.  Frames that put their only structure ON those cuts -- single hot rows,
+    hot pixels and short vertical bars at input rows 30..33, 62..65, 94..97, 126..129 and at the image's first / last rows and columns, stripes whose period
+    is the band height or half of it, a frame per band that is noise inside ONE band and constant elsewhere -- must give the oracle's heads bit for bit."""
+    torch = torch_cuda
+    frames = []
+    for cut in (32, 64, 96, 128):
+        for dy in (-2, -1, 0, 1):
+            f = np.full((160, 160, 3), -128, np.int8)
+            f[cut + dy, :, :] = 127                                           # one hot row next to / on a band cut
+            frames.append(f)
+        f = np.full((160, 160, 3), 127, np.int8)
+        f[cut - 3:cut + 3, 40:43, :] = -128                                   # a short cold bar across the cut
+        f[cut - 1, 0, :] = -128; f[cut, 159, :] = -128                        # ... and cold pixels on the cut at both borders
+        frames.append(f)
+    for y, x in ((0, 0), (0, 159), (159, 0), (159, 159), (0, 80), (159, 79), (80, 0), (79, 159)):
+        f = np.zeros((160, 160, 3), np.int8)
+        f[y, x] = (127, -128, 127)
+        frames.append(f)
+    yy = np.arange(160)[:, None, None]
+    for period in (8, 16, 32):
+        frames.append(np.broadcast_to(np.where((yy // period) % 2 == 1, 127, -128), (160, 160, 3)).astype(np.int8).copy())
+        frames.append(np.broadcast_to(np.where(((yy + period // 2) // period) % 2 == 1, 127, -128), (160, 160, 3)).astype(np.int8).copy())
+    rng = np.random.default_rng(160)
+    for band in range(5):
+        f = np.full((160, 160, 3), 3, np.int8)
+        f[32 * band:32 * band + 32] = rng.integers(-128, 128, (32, 160, 3), dtype=np.int8)      # noise inside one band only
+        frames.append(f)
+    x = np.stack(frames)
+    ref = oracle.run(x, threads=16)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.full((x.shape[0] + 1, 20, 20, 18), 77, dtype=torch.int8, device="cuda")
+    network.run_device_hw(160, 160, d_in.data_ptr(), d_out.data_ptr(), x.shape[0])
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    bad = [i for i in range(x.shape[0]) if not np.array_equal(got[i], ref[i])]
+    assert not bad and (got[-1] == 77).all(), f"frames {bad} differ from the oracle"
+    assert len({ref[i].tobytes() for i in range(ref.shape[0])}) > ref.shape[0] // 2
 
 
 @pytest.mark.skipif(not os.path.exists(LAB_LIB), reason="the lab library is not built (make -C stm32h7-yolo_amd/csrc lab)")
