@@ -588,6 +588,37 @@ def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):
     assert (cref[5] > thr).any()                                                     # the real image fires in fp32 too
 
 
+def test_fp16_tolerance_on_structured_extreme_frames(network, torch_cuda):
+    """The fp16 configuration on frames that are all contrast: black / white, the eight corner colours, stripes and checkerboards of period 1, 2, 4, 7, random
+    black-and-white pixels.  Activations are as large as this network makes them (logits up to 19) and fp16 rounding accumulates most; the tolerance of
+    SURVEY.md 8(d) -- atol 2e-2 + rtol 2e-2 against the fp32 numpy evaluation of the ONNX graph -- still holds on every logit (the worst one uses 99 % of it)."""
+    torch = torch_cuda
+    from oracle.np_fp32 import load_yfw, run_fp32
+    convs = load_yfw(os.path.join(ROOT, "stm32h7-yolo_amd", "model", "yoloface_fp32.yfw"))
+    frames = [np.full((56, 56, 3), v, np.uint8) for v in (0, 255)]
+    for r in (0, 255):
+        for g in (0, 255):
+            for b in (0, 255):
+                frames.append(np.broadcast_to(np.array([r, g, b], np.uint8), (56, 56, 3)).copy())
+    yy, xx = np.mgrid[0:56, 0:56]
+    for period in (1, 2, 4, 7):
+        for pat in ((xx // period) % 2, (yy // period) % 2, ((xx // period) + (yy // period)) % 2):
+            frames.append(np.broadcast_to(np.where(pat[..., None] == 1, 255, 0).astype(np.uint8), (56, 56, 3)).copy())
+    frames += list(np.where(np.random.default_rng(7).integers(0, 2, (6, 56, 56, 3)) == 1, 255, 0).astype(np.uint8))
+    x32 = np.stack(frames).astype(np.float32) / 255
+    ref = np.stack([run_fp32(convs, f) for f in x32])
+    n = x32.shape[0]
+    network.fp16_init()
+    d_in = torch.from_numpy(x32.astype(np.float16)).cuda()
+    d_out = torch.zeros((n, 7, 7, 18), dtype=torch.float32, device="cuda")
+    network.fp16_run_device(d_in.data_ptr(), d_out.data_ptr(), n)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    err = np.abs(got - ref)
+    assert np.isfinite(got).all() and np.abs(ref).max() > 10
+    assert np.all(err <= 2e-2 + 2e-2 * np.abs(ref)), f"max abs err {err.max():.4f}, worst use of the tolerance {(err / (2e-2 + 2e-2 * np.abs(ref))).max():.3f}"
+
+
 def test_max_n_batches_65535_through_the_abi(network, oracle):
     """ai_buffer.n_batches is 16 bit (ai_platform.h:519): the largest single ai_network_run call."""
     lib = network.lib
