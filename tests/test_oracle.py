@@ -64,6 +64,27 @@ def test_c_oracle_equals_numpy_restatement(oracle):
         assert np.array_equal(np.concatenate([o.reshape(-1) for o in outs]), dump[f])
 
 
+def test_c_oracle_equals_numpy_restatement_on_extreme_frames(oracle):
+    """The two independent restatements (C, numpy) on frames that push accumulators and requantisation to their edges: all +127, the corner colour
+    (+127, -128, +127), a period-1 checkerboard, a period-2 row stripe, a cold pixel in the top-left corner of a hot frame, random +127 / -128 pixels.
+    Every one of the 54 op outputs must agree, not only the head."""
+    from oracle.np_restatement import NpModel
+    npm = NpModel(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+    yy, xx = np.mgrid[0:56, 0:56]
+    frames = [np.full((56, 56, 3), 127, np.int8), np.broadcast_to(np.array([127, -128, 127], np.int8), (56, 56, 3)).copy(),
+              np.broadcast_to(np.where(((xx + yy) % 2)[..., None] == 1, 127, -128).astype(np.int8), (56, 56, 3)).copy(),
+              np.broadcast_to(np.where(((yy // 2) % 2)[..., None] == 1, 127, -128).astype(np.int8), (56, 56, 3)).copy()]
+    f = np.full((56, 56, 3), 127, np.int8)
+    f[0, 0] = -128
+    frames += [f, np.where(np.random.default_rng(11).integers(0, 2, (56, 56, 3)) == 1, 127, -128).astype(np.int8)]
+    x = np.stack(frames)
+    heads, dump = oracle.run(x, dump=True)
+    for k in range(x.shape[0]):
+        h2, outs = npm.run(x[k], dump=True)
+        assert np.array_equal(h2, heads[k]), k
+        assert np.array_equal(np.concatenate([o.reshape(-1) for o in outs]), dump[k]), k
+
+
 def test_c_oracle_equals_numpy_restatement_other_size(oracle):
     """Ragged / non-56 input (80x72): exercises SAME/VALID shape inference and the pool borders."""
     from oracle.np_restatement import NpModel
