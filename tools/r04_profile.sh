@@ -1,4 +1,5 @@
 #!/bin/bash
+# SUPERSEDED by tools/r05_profile.sh (round 5: the side configurations are profiled on `bench.py --only-secondary ...`); kept because profiles/README.md names it for the r04 tags.
 # Round-4 evidence run on the GPU box (through gpurun): the headline int8 kernel (kernel trace + counter passes over bench.py), its stage timeline, the
 # fp16 kernel (trace, counters, per-stage counters, stage timeline), the 160x160 path, then the default bench line.  Results -> gpurun_out/r04/
 #   usage: bash tools/r04_profile.sh [part ...]     parts: int8 timeline fp16 f16stage 160 bench   (default: all)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# SUPERSEDED (round 4's copy step for tools/r04_profile.sh); round 5 copies by hand from gpurun_out/r05p and gpurun_out/prof_sec (profiles/README.md).
 # Copies the results of tools/r04_profile.sh (gpurun_out/r04/, merged back by gpurun) into profiles/ under a tag: the headline files as profiles/r04_<tag>_*,
 # the fp16 / 160x160 summaries into their directories, pmc_current.json (what bench.py reads for roofline.traffic; stamped with the build id).  The bench
 # lines of that run carry no counter traffic yet (their build's stamp was not in profiles/ when they ran): re-run `python3 bench.py` twice afterwards

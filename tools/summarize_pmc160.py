@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collapse the rocprofv3 CSVs of tools/profile_160.sh into a per-kernel table (160x160 path: band_k1..k4 or the 27 stage kernels)."""
+"""SUPERSEDED by tools/summarize_secondary.py (round 5).  Collapse the rocprofv3 CSVs of the round 2-4 form of tools/profile_160.sh into a per-kernel table (160x160 path: band_k1..k4 or the 27 stage kernels)."""
 import csv
 import glob
 import json
