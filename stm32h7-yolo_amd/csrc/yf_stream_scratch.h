@@ -14,13 +14,14 @@
 //     of a stream costs ~4 us of back-to-back overlap per launch (2.7 % of the headline kernel).  The region is then DIRTY -- launched on,
 //     not named, never idle.  The decision is per mark(), not "one region exists": a stream that has the object to itself again (the
 //     others' launches completed) stops paying for events (round 4: once a second stream had been seen every launch recorded one for good);
-//   - when another stream needs a region and none is idle, the dirty regions get their event LAZILY, recorded on their own stream by the
-//     asking thread (stream order makes it cover every earlier launch).  If that fails -- the owner destroyed the stream -- the region's
-//     launches can only be waited for with the device (taken only when max_regions is reached);
+//   - the map NEVER hands a stored stream handle to the runtime: a host may have destroyed that stream (below), and this runtime does not validate
+//     handles -- hipStreamQuery / hipEventRecord on a destroyed stream is a segmentation fault (tools/probe/dead_stream_probe.py).  Every HIP call here
+//     takes the CALLER's stream, or an event.  A dirty region whose stream never launches again therefore stays dirty (nothing can name its launches)
+//     until release_stream(), or until every other region is busy and the device is synchronised (the all-busy path);
 //   - at most max_regions regions exist; when all are busy on other streams the caller waits for the one marked longest ago;
 //   - release_stream() gives a stream's region back at once (yf_network_release_stream);
 //   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread), and such a region always
-//     records its event (no other thread could record it lazily).
+//     records its event.
 // A stream is identified by its handle VALUE.  A host may drop a stream without release_stream() only once its launches have completed
 // (it synchronised the stream or consumed the results): the runtime may hand the same handle value to a new stream, and a launch of the
 // old one still in flight would then share the region with the new one's.
@@ -59,13 +60,6 @@ struct yf_stream_scratch {
   static size_t thread_key(hipStream_t s) { return s == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0; }
   Region* find(hipStream_t s, size_t tk) { for (Region& r : regions) if (r.stream == s && r.thread == tk) return &r; return nullptr; }
   static bool idle(const Region& r) { return !r.acquired && !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
-  // a dirty region gets its event from whoever needs to know when it ends (its own stream's order covers the earlier launches)
-  static void name_lazily(Region& r) {
-    if (!r.dirty || r.acquired || r.thread != 0) return;
-    if (hipEventRecord(r.done, r.stream) == hipSuccess) { r.marked = true; r.dirty = false; }
-    else (void)hipGetLastError();                                                     // the stream is gone: only the device can tell (all-busy path below)
-  }
-
   // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls lease.mark().
   hipError_t get(hipStream_t s, size_t bytes, Lease* lease) {
     std::lock_guard<std::mutex> lock(mu);
@@ -73,7 +67,6 @@ struct yf_stream_scratch {
     Region* r = find(s, tk);
     if (!r) {
       for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
-      if (!r) for (Region& c : regions) name_lazily(c);                               // so that the dirty ones become idle once their launches end
       if (!r && regions.size() < max_regions) {
         Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false};
         const hipError_t rc = hipEventCreateWithFlags(&n.done, hipEventDisableTiming);

@@ -1,9 +1,11 @@
 /* A FAKE of the few HIP entry points csrc/yf_stream_scratch.h uses, for the CPU test of the stream-scratch map (tests/csrc/scratch_map_test.cpp):
  * own-authored, host-only, no GPU.  A "stream" is a small object that counts what was enqueued on it; a launch is `stream->enqueue()`; an
  * event recorded on a stream completes when the test calls `stream->drain()` (or `fake_hip::drain_all()`).  Destroyed streams are remembered:
- * recording on one fails, as the runtime's handle check does. */
+ * handing one to the runtime ABORTS the test -- the real runtime does not validate stream handles, a call on a destroyed stream is a segmentation fault
+ * (tools/probe/dead_stream_probe.py) -- so the map under test must never do it. */
 #ifndef FAKE_HIP_RUNTIME_H
 #define FAKE_HIP_RUNTIME_H
+#include <cstdio>
 #include <cstdlib>
 #include <set>
 #include <vector>
@@ -29,7 +31,10 @@ inline void drain_all() { for (fake_stream* s : all()) s->drain(); }
 #define hipStreamPerThread ((hipStream_t)2)
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = new fake_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { if (!fake_hip::live().count(s)) return hipErrorInvalidHandle; e->on = s; e->at = s->enqueued; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (!fake_hip::live().count(s)) { std::fprintf(stderr, "fake HIP: hipEventRecord on a destroyed stream (a crash in the real runtime)\n"); std::abort(); }
+  e->on = s; e->at = s->enqueued; return hipSuccess;
+}
 inline hipError_t hipEventQuery(hipEvent_t e) { return (!e->on || e->on->completed >= e->at) ? hipSuccess : hipErrorNotReady; }
 inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e->on && e->on->completed < e->at) e->on->completed = e->at; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { ++fake_hip::device_syncs(); fake_hip::drain_all(); return hipSuccess; }

@@ -1,6 +1,6 @@
 // CPU test of csrc/yf_stream_scratch.h against a fake HIP runtime (tests/csrc/fake_hip): the policy of the stream-keyed scratch map, in particular
 // the paths a GPU test cannot reach deterministically -- a launch that fails between get() and mark(), events skipped while a stream is alone
-// and recorded lazily when another stream turns up, a dropped stream's region changing hands.  Built and run by tests/test_sanitizers.py.
+// and recorded again when another stream turns up, destroyed streams whose handles must never reach the runtime.  Built and run by tests/test_sanitizers.py.
 #include "yf_stream_scratch.h"
 #include <cstdio>
 #include <cstdlib>
@@ -31,9 +31,6 @@ int main() {
     CHECK(good_launch(m, s[4]) == hipSuccess);                                 // round 4: hipErrorNotReady here, for good
     CHECK(good_launch(m, s[5]) == hipSuccess);
     CHECK(m.count() <= 4 && m.acquired_count() == 0);
-    // a dropped stream whose launch failed: its region is still reusable (recording the lease's event on the dead handle fails and is ignored)
-    fake_hip::destroy(s[0]);
-    CHECK(failing_launch(m, s[0]) == hipErrorInvalidHandle && m.acquired_count() == 0);
     fake_hip::drain_all();
     for (int i = 1; i < 6; ++i) CHECK(good_launch(m, s[i]) == hipSuccess);
     CHECK(m.count() <= 4);
@@ -49,40 +46,43 @@ int main() {
     CHECK(good_launch(m, a, 1024, &pa) == hipSuccess);
     CHECK(m.count() == 2 && pa != pb);
     const unsigned long long rec = m.events_recorded;
-    CHECK(rec >= 2);                                                           // b's launch (a's region dirty -> named lazily, then pending) and a's
+    CHECK(rec >= 2);                                                           // b's launch (a's region is dirty, i.e. not idle) and a's
     fake_hip::drain_all();                                                     // everything completed: whoever launches next is alone
     CHECK(good_launch(m, a) == hipSuccess && good_launch(m, a) == hipSuccess);
     CHECK(m.events_recorded == rec);                                           // round 4: every launch recorded an event for the life of the object
     m.release();
   }
-  {   // 3. a stream that went away while its region was dirty: the next stream names it lazily (fails: handle dead) and takes a NEW region while
-      //    there is room; at the cap the region comes back through a device synchronise, not never
+  {   // 3. a stream that was synchronised and DESTROYED while its region was dirty (launched on without an event): the map must never hand that handle to
+      //    the runtime (the fake aborts if it does).  While there is room the next stream gets a new region; at the cap a named region is waited for; and
+      //    when only the dead stream's dirty region is left, the device is what can be waited for
     yf_stream_scratch m; m.max_regions = 2;
     hipStream_t a = fake_hip::create(), b = fake_hip::create(), c = fake_hip::create();
-    CHECK(good_launch(m, a) == hipSuccess);                                    // dirty, no event
+    CHECK(good_launch(m, a) == hipSuccess);                                    // alone: dirty, no event
+    a->drain();
     fake_hip::destroy(a);
-    CHECK(good_launch(m, b) == hipSuccess && m.count() == 2);
+    CHECK(good_launch(m, b) == hipSuccess && m.count() == 2);                  // a's region is not idle (nothing names its launches): b gets its own, and records
     const long syncs = fake_hip::device_syncs();
-    CHECK(good_launch(m, c) == hipSuccess && m.count() == 2);                  // b's region, after waiting for b's event (b is named: a's region was not idle)
+    CHECK(good_launch(m, c) == hipSuccess && m.count() == 2);                  // the cap: b's region, after waiting for b's event
     CHECK(fake_hip::device_syncs() == syncs && m.acquired_count() == 0);
     m.release();
-    yf_stream_scratch one; one.max_regions = 1;                                // only a dead stream's dirty region left: the device is what can be waited for
+    yf_stream_scratch one; one.max_regions = 1;
     hipStream_t d = fake_hip::create(), e = fake_hip::create();
     CHECK(good_launch(one, d) == hipSuccess);
+    d->drain();
     fake_hip::destroy(d);
     CHECK(good_launch(one, e) == hipSuccess && one.count() == 1 && fake_hip::device_syncs() == syncs + 1);
     one.release();
   }
-  {   // 4. live stream, dirty region, owner never launches again: named lazily by the next stream, idle once drained, then it changes hands
-    yf_stream_scratch m; m.max_regions = 2;
-    hipStream_t a = fake_hip::create(), b = fake_hip::create(), c = fake_hip::create();
-    char *pa = nullptr, *pc = nullptr;
-    CHECK(good_launch(m, a, 1024, &pa) == hipSuccess);
-    CHECK(good_launch(m, b) == hipSuccess);                                    // names a's region lazily
-    const long syncs = fake_hip::device_syncs(), mallocs = fake_hip::mallocs();
+  {   // 4. the same handle VALUE comes back for a new stream (the runtime reuses addresses): it finds the old region -- safe, because a stream may only be
+      //    dropped once its launches have completed
+    yf_stream_scratch m;
+    hipStream_t a = fake_hip::create();
+    char *p1 = nullptr, *p2 = nullptr;
+    CHECK(good_launch(m, a, 1024, &p1) == hipSuccess);
     a->drain();
-    CHECK(good_launch(m, c, 1024, &pc) == hipSuccess);
-    CHECK(pc == pa && fake_hip::device_syncs() == syncs && fake_hip::mallocs() == mallocs && m.count() == 2);     // no wait, no allocation
+    fake_hip::destroy(a);
+    fake_hip::live().insert(a);                                                // "a new stream at the same address"
+    CHECK(good_launch(m, a, 1024, &p2) == hipSuccess && p1 == p2 && m.count() == 1);
     m.release();
   }
   {   // 5. 64 short-lived streams, three launches each, dropped after their work completed, never released: bounded footprint

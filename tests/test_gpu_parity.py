@@ -544,6 +544,16 @@ def test_a_failed_launch_does_not_keep_its_scratch_region(torch_cuda):
     assert r.returncode == 0 and "failed-launch rehearsal ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_streams_that_are_destroyed_without_a_release(torch_cuda):
+    """A stream per request, synchronised and destroyed with real hipStreamCreate / hipStreamDestroy and no yf_network_release_stream (INTEGRATION.md allows
+    it): the scratch map holds regions whose stream handle is dead and must never hand one to the runtime -- this runtime segfaults on a destroyed stream
+    (a first form of round 5's map did exactly that).  200 requests, every int8 head equal to the oracle's, footprint within eight regions per kind
+    (tests/dev/destroyed_streams.py, fresh process)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "destroyed_streams.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "destroyed-streams rehearsal ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_baseline_config4_fp16_tolerance(yf, network, golden, torch_cuda):
     """BASELINE.json configs[3]: fp16 weights from the reference's ONNX export, 56x56, MFMA-f16 dense convs.
     Checked against an fp32 numpy evaluation of the same graph (oracle/np_fp32.py; itself cross-checked against torch

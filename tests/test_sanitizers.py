@@ -38,9 +38,10 @@ def test_c_sources_are_clean_under_asan_and_ubsan(tmp_path):
 def test_stream_scratch_map_policy_under_asan(tmp_path):
     """csrc/yf_stream_scratch.h against a fake HIP runtime (tests/csrc/fake_hip: streams that count what was enqueued, events that complete when
     the test drains a stream): a launch that fails between get() and mark() leaves nothing acquired (max_regions failures, then a new stream
-    still gets a region), a stream that is alone records no event and goes back to none once the others' launches have completed, a dirty
-    region is named lazily by the next stream and changes hands without a wait or an allocation, a dead stream's region comes back through a
-    device synchronise, 64 dropped streams stay within 8 regions, a failed allocation leaves the map usable."""
+    still gets a region), a stream that is alone records no event and goes back to none once the others' launches have completed, the handle of
+    a DESTROYED stream is never handed to the runtime (the fake aborts if it is: the real runtime segfaults) and its region comes back through a
+    device synchronise, a reused handle value finds its old region, 64 dropped streams stay within 8 regions, a failed allocation leaves the map
+    usable."""
     exe = str(tmp_path / "scratch_map_test")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-I" + os.path.join(ROOT, "tests", "csrc", "fake_hip"), "-I" + os.path.join(ROOT, "stm32h7-yolo_amd", "csrc"),
