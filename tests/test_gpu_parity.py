@@ -544,6 +544,48 @@ def test_a_failed_launch_does_not_keep_its_scratch_region(torch_cuda):
     assert r.returncode == 0 and "failed-launch rehearsal ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_hip_stream_per_thread_is_keyed_by_thread(network, oracle, torch_cuda):
+    """hipStreamPerThread is ONE handle value (2) for a different stream per host thread: the scratch map keys it by (handle, thread), so two host threads
+    that launch on it -- taking turns, the entry points are serialised by the caller like the reference's -- never share a region.  Two threads, five
+    launches of a 1024-frame batch each on hipStreamPerThread, every head equal to the oracle's, and the library holds (at least) two tail-scratch regions."""
+    import ctypes
+    import threading
+    torch = torch_cuda
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    per_thread = 2                                                 # hipStreamPerThread
+    block = rnd(91, 1024)
+    ref = oracle.run(block, threads=16)
+    d_in = torch.from_numpy(block).cuda()
+    torch.cuda.synchronize()
+    network.configure(2, 8)
+    before = network.scratch_bytes()
+    turn, results, errors = threading.Lock(), {}, []
+
+    def worker(tid):
+        try:
+            outs = []
+            for _ in range(5):
+                o = torch.empty((1024, 7, 7, 18), dtype=torch.int8, device="cuda")
+                with turn:
+                    network.run_device(d_in.data_ptr(), o.data_ptr(), 1024, per_thread)
+                outs.append(o)
+            assert hip.hipStreamSynchronize(per_thread) == 0      # this thread's own stream
+            results[tid] = [np.array_equal(o.cpu().numpy(), ref) for o in outs]
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    network.configure(-1, 0)
+    assert not errors, errors
+    assert all(results[0]) and all(results[1]) and len(results[0]) == 5
+    assert network.scratch_bytes() >= before and network.scratch_bytes() >= 2 * 5 * 2 ** 20      # two regions of 5.5 MB for the two threads' streams
+
+
 def test_streams_that_are_destroyed_without_a_release(torch_cuda):
     """A stream per request, synchronised and destroyed with real hipStreamCreate / hipStreamDestroy and no yf_network_release_stream (INTEGRATION.md allows
     it): the scratch map holds regions whose stream handle is dead and must never hand one to the runtime -- this runtime segfaults on a destroyed stream
