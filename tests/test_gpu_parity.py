@@ -544,6 +544,14 @@ def test_a_failed_launch_does_not_keep_its_scratch_region(torch_cuda):
     assert r.returncode == 0 and "failed-launch rehearsal ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_a_hundred_lifecycles_leak_nothing(torch_cuda):
+    """create -> init (-> init again) -> run on every path (device on a side stream, host zero-copy / one-shot / pipelined, fp16, 160x160) -> destroy, a
+    hundred times in one process (tests/dev/lifecycle_soak.py): device memory comes back, host memory does not grow, every head stays equal to the oracle's."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "lifecycle_soak.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "lifecycle soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_hip_stream_per_thread_is_keyed_by_thread(network, oracle, torch_cuda):
     """hipStreamPerThread is ONE handle value (2) for a different stream per host thread: the scratch map keys it by (handle, thread), so two host threads
     that launch on it -- taking turns, the entry points are serialised by the caller like the reference's -- never share a region.  Two threads, five
