@@ -544,6 +544,15 @@ def test_a_failed_launch_does_not_keep_its_scratch_region(torch_cuda):
     assert r.returncode == 0 and "failed-launch rehearsal ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_batches_whose_byte_offsets_pass_32_bits(torch_cuda):
+    """481 280 int8 frames (4.5 GB) in one fused launch with the decode, 240 640 fp16 frames, 60 160 frames of 160x160: block-periodic inputs, so every copy must
+    give the block's heads (the oracle's for int8) and every detection record its own frame index -- a 32-bit byte offset anywhere would show at the far end
+    (tests/dev/huge_batch.py, fresh process)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "huge_batch.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "huge batches ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_a_hundred_lifecycles_leak_nothing(torch_cuda):
     """create -> init (-> init again) -> run on every path (device on a side stream, host zero-copy / one-shot / pipelined, fp16, 160x160) -> destroy, a
     hundred times in one process (tests/dev/lifecycle_soak.py): device memory comes back, host memory does not grow, every head stays equal to the oracle's."""
