@@ -705,6 +705,25 @@ def test_max_n_batches_65535_through_the_abi(network, oracle):
     assert np.array_equal(out[256 * 100:256 * 101], ref)
 
 
+def test_host_buffers_at_odd_addresses(network, oracle):
+    """ai_network_run takes the caller's arrays as they are (the firmware aligns in_data / out_data to 32 bytes, yoloface.c:10-16; a host application
+    may not): frames and heads at addresses that are 1, 3 and 7 bytes off any alignment, on the zero-copy (n <= 8), one-shot and pipelined paths."""
+    b = importlib.import_module("stm32h7-yolo_amd.binding")
+    lib = network.lib
+    for n in (3, 300, 2500):
+        x = rnd(100 + n, n)
+        ref = oracle.run(x, threads=16)
+        for off in (1, 3, 7):
+            raw_in = np.zeros(n * 9408 + 64, np.int8)
+            raw_out = np.full(n * 882 + 64, 91, np.int8)
+            raw_in[off:off + n * 9408] = x.reshape(-1)
+            bi = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 56, 56, 3, n, raw_in.ctypes.data + off)
+            bo = b.make_buffer(b.AI_BUFFER_FORMAT_S8, 7, 7, 18, n, raw_out.ctypes.data + off)
+            assert lib.ai_network_run(network.handle, ctypes.byref(bi), ctypes.byref(bo)) == n
+            assert np.array_equal(raw_out[off:off + n * 882].reshape(n, 7, 7, 18), ref), (n, off)
+            assert (raw_out[:off] == 91).all() and (raw_out[off + n * 882:] == 91).all()      # nothing written outside the caller's heads
+
+
 def test_run_argument_errors_are_latched(network):
     """Error behaviour of the reference boundary: <= 0 return, first error readable once (network.h:120-132)."""
     lib = network.lib
