@@ -761,6 +761,17 @@ def test_run_argument_errors_are_latched(network):
         assert lib.ai_network_get_error(network.handle).type == 0
     assert lib.yf_network_run_decode_device(network.handle, d.data_ptr(), d.data_ptr(), 0, 0, 1.0, 1.0, d.data_ptr(), d.data_ptr(), 4, None) == 0   # n = 0: nothing to do
     assert lib.ai_network_get_error(network.handle).type == 0
+    # device pointers the kernels cannot take -- frames not 4-byte aligned (dword staging), heads not 2-byte aligned, fp16 frames not 4-byte aligned, 160x160
+    # frames not 4-byte aligned -- are refused before anything is launched, with a latched error
+    h = torch.zeros((2 * 882 + 8,), dtype=torch.int8, device="cuda")
+    for call in (lambda: lib.yf_network_run_device(network.handle, d.data_ptr() + 1, h.data_ptr(), 2, None),
+                 lambda: lib.yf_network_run_device(network.handle, d.data_ptr() + 2, h.data_ptr(), 2, None),
+                 lambda: lib.yf_network_run_device(network.handle, d.data_ptr(), h.data_ptr() + 1, 2, None),
+                 lambda: lib.yf_network_run_device_hw(network.handle, 160, 160, d.data_ptr() + 2, h.data_ptr(), 0 + 1, None)):
+        assert call() <= 0
+        assert lib.ai_network_get_error(network.handle).type != 0
+        assert lib.ai_network_get_error(network.handle).type == 0
+    torch.cuda.synchronize()
 
 
 def test_weights_come_from_the_callers_blob(yf, network, oracle):
