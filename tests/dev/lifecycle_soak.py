@@ -2,7 +2,8 @@
 """create -> init -> run (device path on a side stream, host path, fp16, 160x160) -> destroy, a hundred times in one process: the reference's firmware calls
 aiInit once, a host application may not.  Device memory must come back (free memory after cycle k within 64 MiB of free memory after cycle 3), host memory must not grow (resident set within 64 MiB of
 cycle 10's), every head
-must stay equal to the oracle's, and ai_network_init on a live network (re-initialisation, network.c:3385-3399 allows it) must not leak either.
+must stay equal to the oracle's, ai_network_init on a live network (re-initialisation, network.c:3385-3399 allows it) must not leak either, and ai_network_destroy with a launch still in
+flight on a caller's stream must let that launch finish (its heads are checked).
 Test helper: tests/test_gpu_parity.py runs it in a fresh process."""
 import importlib, os, sys
 import numpy as np, torch
@@ -39,7 +40,14 @@ for cycle in range(100):
     net.fp16_run_device(d_f16.data_ptr(), d_of.data_ptr(), 16)
     net.run_device_hw(160, 160, d_160.data_ptr(), d_o160.data_ptr(), 8)
     torch.cuda.synchronize()
-    net.destroy()
+    if cycle % 7 == 0:                                    # destroy with a launch still in flight: ai_network_destroy waits for the device before it frees anything
+        d_out.zero_()
+        net.run_device(d_in.data_ptr(), d_out.data_ptr(), 700, side.cuda_stream)
+        net.destroy()
+        side.synchronize()
+        bad += not np.array_equal(d_out.cpu().numpy(), ref)
+    else:
+        net.destroy()
     free.append(torch.cuda.mem_get_info()[0])
     rss.append(proc.memory_info().rss)
 drift = (free[3] - min(free[3:])) / 2 ** 20
