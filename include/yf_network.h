@@ -213,7 +213,31 @@ enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anc
        YF_DECODE_FW_HOST = 2 };/* the same loop compiled for an x86-64 host (cvttss2si: out of range -> INT32_MIN, which the
                                  clamps then turn into 0 / 55); equals YF_DECODE_FW whenever every edge fits in int32 */
 
-/* Select GPU (default 0 / $LOCAL_RANK is NOT read here; the caller decides).  Call before ai_network_init. */
+/* Rounding of the requantisation step (TFLite MultiplyByQuantizedMultiplier) behind every conv / add / quantize of the int8 network.
+ * "Bit-exact vs tflite" needs a definition of WHICH TFLite: the reference's script builds tf.lite.Interpreter with default arguments
+ * (yoloface/tflite/tflite_prediction.py:23), i.e. the default op resolver, and TensorFlow 2.10 cannot be run where this library is
+ * built, so the choice is the integrator's (DESIGN.md section 2 has the measured distance between the forms):
+ *   YF_ROUND_TFLITE_REF   (default) the builtin REFERENCE kernels: SRDHM, then RoundingDivideByPOT (ties away from zero) everywhere.
+ *                         SURVEY.md 8(c).3's definition of "the tflite int8 reference" (experimental_op_resolver_type=BUILTIN_REF).
+ *   YF_ROUND_TIES_UP      dense CONV_2D as the default resolver's optimized kernels route it on x86 / ARM (ruy: sqrdmulh + srshl, the right
+ *                         shift breaks ties UPWARD); DEPTHWISE_CONV_2D, LEAKY_RELU, ADD, QUANTIZE keep the reference form.
+ *   YF_ROUND_TIES_UP_ALL  every op ties upward.
+ *   YF_ROUND_SINGLE       dense CONV_2D with ONE rounding, (acc*M + 2^(30-shift)) >> (31-shift) (ruy's portable path); the rest reference.
+ * All four run the SAME kernels at the same speed: the rounding lives in the per-channel constants {C64, ZR}, the LeakyReLU / QUANTIZE
+ * byte tables and the add tables that ai_network_init builds (csrc/yf_host_prep.c).  Call after ai_network_create, before or after
+ * ai_network_init (a ready network waits for its launches, rebuilds its tables from the weights it was initialised with -- which the caller
+ * still owns, as on the MCU -- and uploads them); ai_network_create resets the choice to $YF_REQUANT_ROUNDING ("ref", "ties_up",
+ * "ties_up_all", "single"; unset = ref) so that an unmodified aiInit() can be steered from outside.  Affects the 56x56 and 160x160 int8
+ * paths; the fp16 path has no requantisation.  Returns 0, or -1 with an error latched. */
+#ifndef YF_ROUND_ENUM
+#define YF_ROUND_ENUM
+enum { YF_ROUND_TFLITE_REF = 0, YF_ROUND_TIES_UP = 1, YF_ROUND_TIES_UP_ALL = 2, YF_ROUND_SINGLE = 3, YF_ROUND_COUNT };
+#endif
+YF_API int  yf_network_set_requant_rounding(ai_handle network, int rounding);
+YF_API int  yf_network_get_requant_rounding(ai_handle network);      /* the rounding in force, -1 for an invalid handle */
+/* Select GPU (default 0 / $LOCAL_RANK is NOT read here; the caller decides).  Call before ai_network_init.  ONE DEVICE PER PROCESS: the library keeps
+ * one network instance (like the reference: network.c:2929-2939) and its decode tables live in device symbols of the device the instance was
+ * initialised on; a host that drives several GPUs starts one process per GPU (tools/c_host/yf_ranks.c, bench.py). */
 YF_API int  yf_network_set_device(ai_handle network, int device);
 /* Kernel variant: frames per workgroup (1,2,4) and waves per workgroup (4,8); 0 keeps the current value.  Without a call the choice
  * is automatic -- the throughput shape <2,8>, and batches of up to 512 frames one frame per workgroup (<1,8>: a 1-frame batch takes
@@ -299,6 +323,15 @@ YF_API long yf_network_fp16_run_device(ai_handle network, const void* d_in_f16, 
  * reports the bytes held right now.  (The reference has one context and no streams: network.c:2929-2939.) */
 YF_API int yf_network_release_stream(ai_handle network, void* stream);
 YF_API size_t yf_network_scratch_bytes(ai_handle network);
+/* What the scratch maps did so far (all kinds of region summed; csrc/yf_stream_scratch.h): a launch whose stream has the library to itself skips the
+ * event behind it (events_skipped), in company it records one (events_recorded); a NEW stream that finds every region busy waits for the event of
+ * the region used longest ago (event_waits), for the whole DEVICE when only unnamed (dirty) regions are left (device_syncs: a hipDeviceSynchronize
+ * inside the launch call -- a host that sees this number grow keeps more streams alive than there are regions, or drops streams without
+ * yf_network_release_stream), or for another host thread's launch call to finish (acquire_waits).  Returns 0, -1 for an invalid handle. */
+typedef struct yf_scratch_stats_ {
+  unsigned long long events_recorded, events_skipped, event_waits, device_syncs, acquire_waits, regions;
+} yf_scratch_stats;
+YF_API int yf_network_scratch_stats(ai_handle network, yf_scratch_stats* out);
 YF_API const char* yf_network_last_error_text(ai_handle network);
 YF_API const char* yf_network_kernel_name(ai_handle network);
 /* Name of the kernel shape a batch of n frames runs (see yf_network_configure). */

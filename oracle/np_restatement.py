@@ -68,9 +68,21 @@ def rdivpot(x, e):
     return np.where(x >= 0, (x + half) >> e, -((-x + half) >> e))
 
 
-def mbqm(x, m, shift):
+def mbqm(x, m, shift, mode=0):
+    """mode 0: TFLite reference (ties away from zero); 1: right shift ties upward (ruy vector kernels / ARM srshl);
+    2: single rounding (ruy standard C++).  The variants mirror oracle/yf_oracle.h YFO_RV_*."""
     ls, rs = (shift, 0) if shift > 0 else (0, -shift)
-    return rdivpot(srdhm(x * (1 << ls), m), rs)
+    if mode == 2:
+        total = 31 - shift
+        return (x.astype(np.int64) * np.int64(m) + (np.int64(1) << (total - 1))) >> total
+    s = srdhm(x * (1 << ls), m)
+    if mode == 1:
+        return (s + (np.int64(1) << (rs - 1))) >> rs if rs else s
+    return rdivpot(s, rs)
+
+
+# variant -> (dense conv, depthwise conv, element-wise) form; "f" = float32 requantisation (XNNPACK qs8)
+VARIANT_MODES = {0: (0, 0, 0), 1: (1, 0, 0), 2: (1, 1, 1), 3: ("f", "f", 0), 4: (2, 0, 0)}
 
 
 def clamp8(x):
@@ -88,9 +100,10 @@ class NpModel:
     def __init__(self, path):
         self.m = load_yfm(path)
 
-    def run(self, frame, dump=False):
+    def run(self, frame, dump=False, variant=0):
         """frame int8 [h,w,3] -> head int8 [oh,ow,18] (+ list of every op output)."""
         T, ops = self.m["tensors"], self.m["ops"]
+        m_dense, m_dw, m_elt = VARIANT_MODES[variant]
         f32 = np.float32
         val = {self.m["input"]: np.asarray(frame, np.int8)}
         outs = []
@@ -128,17 +141,22 @@ class NpModel:
                             acc += patch * w[0, fy, fx, :]
                 acc += bias
                 y = np.empty(acc.shape, np.int64)
+                mode = m_dense if o["op"] == CONV else m_dw
                 for c in range(cout):
+                    if mode == "f":
+                        fs = f32(f32(s_in * f32(wt["scale"][c])) / s_out)             # float32 arithmetic
+                        y[..., c] = np.rint(acc[..., c].astype(np.float32) * fs).astype(np.int64)   # ties to even
+                        continue
                     eff = float(s_in) * float(f32(wt["scale"][c])) / float(s_out)
                     m, sh = quantize_multiplier(eff)
-                    y[..., c] = mbqm(acc[..., c], m, sh)
+                    y[..., c] = mbqm(acc[..., c], m, sh, mode)
                 y = clamp8(y + zo)
             elif o["op"] == LEAKY:
                 alpha = f32(o["alpha"])
                 ma, sa = quantize_multiplier(float(f32(s_in * alpha / s_out)))
                 mi, si = quantize_multiplier(float(f32(s_in / s_out)))
                 v = x.astype(np.int64) - zi
-                y = clamp8(zo + np.where(v >= 0, mbqm(v, mi, si), mbqm(v, ma, sa)))
+                y = clamp8(zo + np.where(v >= 0, mbqm(v, mi, si, m_elt), mbqm(v, ma, sa, m_elt)))
             elif o["op"] == MAXPOOL:
                 oh, ph = _same_valid(o["padding"], x.shape[0], o["fh"], o["sh"])
                 ow, pw = _same_valid(o["padding"], x.shape[1], o["fw"], o["sw"])
@@ -157,10 +175,10 @@ class NpModel:
                 mo, ho = quantize_multiplier(twice / float(f32(1 << 20) * s_out))
                 a = (x.astype(np.int64) - zi) << 20
                 b = (x2.astype(np.int64) - t2["zp"]) << 20
-                y = clamp8(mbqm(mbqm(a, m1, h1) + mbqm(b, m2, h2), mo, ho) + zo)
+                y = clamp8(mbqm(mbqm(a, m1, h1, m_elt) + mbqm(b, m2, h2, m_elt), mo, ho, m_elt) + zo)
             elif o["op"] == QUANTIZE:
                 m, sh = quantize_multiplier(float(s_in) / float(s_out))
-                y = clamp8(mbqm(x.astype(np.int64) - zi, m, sh) + zo)
+                y = clamp8(mbqm(x.astype(np.int64) - zi, m, sh, m_elt) + zo)
             elif o["op"] == CONCAT:
                 y = np.concatenate([x, val[o["ins"][1]]], axis=2)
             else:

@@ -13,6 +13,11 @@ _LIB_PATH = os.path.join(_HERE, "libyf_oracle.so")
 MODEL_PATH = os.path.join(_HERE, "model", "yoloface_int8.yfm")
 
 
+# rounding variants of the requantisation step (oracle/yf_oracle.h, YFO_RV_*)
+RV_REF, RV_UP_DENSE, RV_UP_ALL, RV_FP32, RV_SINGLE_DENSE = range(5)
+VARIANTS = {"R": RV_REF, "U": RV_UP_DENSE, "U-all": RV_UP_ALL, "X": RV_FP32, "S": RV_SINGLE_DENSE}
+
+
 class Det(ctypes.Structure):
     _fields_ = [("frame", ctypes.c_int32), ("anchor", ctypes.c_uint8), ("row", ctypes.c_uint8),
                 ("col", ctypes.c_uint8), ("q_conf", ctypes.c_int8), ("conf", ctypes.c_float),
@@ -39,6 +44,10 @@ def _load():
     lib.yfo_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     lib.yfo_leaky_lut.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.yfo_run_variant.argtypes = lib.yfo_run.argtypes + [ctypes.c_int]
+    lib.yfo_leaky_lut_variant.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.yfo_mbqm_mode.restype = ctypes.c_int32
+    lib.yfo_mbqm_mode.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int]
     lib.yfo_decode_py.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.POINTER(Det), ctypes.c_int]
     lib.yfo_decode_c.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -88,23 +97,24 @@ class Oracle:
     def dump_bytes(self, h=56, w=56):
         return self.lib.yfo_dump_bytes(self.h, h, w)
 
-    def run(self, frames, dump=False, threads=1):
-        """frames: int8 [n,h,w,3] -> head int8 [n,oh,ow,18] (and [n,dump_bytes] when dump)."""
+    def run(self, frames, dump=False, threads=1, variant=RV_REF):
+        """frames: int8 [n,h,w,3] -> head int8 [n,oh,ow,18] (and [n,dump_bytes] when dump).
+        variant: RV_* -- another published rounding of the requantisation step (default: TFLite's reference kernels)."""
         x = np.ascontiguousarray(frames, dtype=np.int8)
         assert x.ndim == 4 and x.shape[3] == 3
         n, h, w, _ = x.shape
         oh, ow, oc = self.out_shape(h, w)
         out = np.empty((n, oh, ow, oc), np.int8)
         d = np.empty((n, self.dump_bytes(h, w)), np.int8) if dump else None
-        rc = self.lib.yfo_run(self.h, x.ctypes.data, n, h, w, out.ctypes.data,
-                              d.ctypes.data if dump else None, threads)
+        rc = self.lib.yfo_run_variant(self.h, x.ctypes.data, n, h, w, out.ctypes.data,
+                                      d.ctypes.data if dump else None, threads, int(variant))
         if rc != n:
             raise RuntimeError(f"yfo_run failed rc={rc}")
         return (out, d) if dump else out
 
-    def leaky_lut(self, op_index):
+    def leaky_lut(self, op_index, variant=RV_REF):
         lut = np.empty(256, np.int8)
-        if self.lib.yfo_leaky_lut(self.h, op_index, lut.ctypes.data) != 0:
+        if self.lib.yfo_leaky_lut_variant(self.h, op_index, lut.ctypes.data, int(variant)) != 0:
             raise ValueError("not a LEAKY_RELU op")
         return lut
 

@@ -36,6 +36,7 @@ typedef struct {
 typedef struct {
   int32_t* mult;          /* per output channel (conv) */
   int* shift;
+  float* fscale;          /* per output channel, float32 arithmetic: s_in * s_w / s_out (variant FP32 only) */
   int32_t m_id, m_alpha;  /* leaky */
   int s_id, s_alpha;
   int32_t m1, m2, mo;     /* add */
@@ -86,6 +87,32 @@ int32_t yfo_mbqm(int32_t x, int32_t m, int shift) {
   return yfo_rdivpot(yfo_srdhm(x * (1 << left_shift), m), right_shift);
 }
 
+/* ---- rounding VARIANTS of the requantisation (yf_oracle.h, YFO_RV_*): other published arithmetics of the same step.
+ * The restatement above (RoundingDivideByPOT: ties away from zero) is what TFLite's builtin REFERENCE kernels compute and
+ * what SURVEY.md 8(c).3 fixes as "the tflite int8 reference".  tflite_prediction.py:23 builds tf.lite.Interpreter with
+ * default arguments, i.e. the default (optimized) resolver, whose per-channel int8 CONV_2D GEMMs go through ruy:
+ *   UP     : ruy's vector kernels = ARM sqrdmulh + srshl: the right shift breaks ties UPWARD, (s + 2^(e-1)) >> e;
+ *   SINGLE : ruy's standard C++ path (ruy/apply_multiplier.cc): ONE rounding, (x*M + 2^(30-shift)) >> (31-shift);
+ *   FP32   : XNNPACK's qs8 requantisation: lrintf((float)acc * (float)(s_in*s_w/s_out)).
+ * None of them can be checked against an interpreter here; they exist to MEASURE how much the choice matters
+ * (tests/test_oracle.py::test_rounding_variant_exposure) and as the checker of the library's selectable rounding. */
+enum { MB_REF = 0, MB_UP = 1, MB_SINGLE = 2 };
+int32_t yfo_mbqm_mode(int32_t x, int32_t m, int shift, int mode) {
+  if (mode == MB_REF) return yfo_mbqm(x, m, shift);
+  const int left_shift = shift > 0 ? shift : 0;
+  const int right_shift = shift > 0 ? 0 : -shift;
+  if (mode == MB_UP) {
+    const int32_t s = yfo_srdhm(x * (1 << left_shift), m);
+    return right_shift ? (int32_t)(((int64_t)s + (1LL << (right_shift - 1))) >> right_shift) : s;
+  }
+  const int total = 31 - shift;                            /* MB_SINGLE */
+  return (int32_t)(((int64_t)x * (int64_t)m + (1LL << (total - 1))) >> total);
+}
+/* which form each op family takes under a variant: [dense conv, depthwise conv, element-wise (LEAKY_RELU, ADD, QUANTIZE)] */
+static inline int mode_dense(int v) { return v == YFO_RV_UP_DENSE || v == YFO_RV_UP_ALL ? MB_UP : v == YFO_RV_SINGLE_DENSE ? MB_SINGLE : MB_REF; }
+static inline int mode_dw(int v)    { return v == YFO_RV_UP_ALL ? MB_UP : MB_REF; }
+static inline int mode_elt(int v)   { return v == YFO_RV_UP_ALL ? MB_UP : MB_REF; }
+
 static inline int8_t clamp8(int32_t v) { return (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v)); }
 static inline float bits2f(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline float tscale(const yfo_model* m, int ti, int k) {
@@ -122,9 +149,12 @@ yfo_model* yfo_load(const char* path) {
       const float s_in = tscale(m, o->in[0], 0);
       p->mult = (int32_t*)malloc(sizeof(int32_t) * n);
       p->shift = (int*)malloc(sizeof(int) * n);
+      p->fscale = (float*)malloc(sizeof(float) * n);
       for (int c = 0; c < n; ++c) {
         const double eff = (double)s_in * (double)tscale(m, wt, c) / (double)s_out;
         yfo_quantize_multiplier(eff, &p->mult[c], &p->shift[c]);
+        const volatile float num = s_in * tscale(m, wt, c);                 /* two float32 operations, no contraction */
+        p->fscale[c] = num / s_out;
       }
     } else if (o->opcode == OP_LEAKY) {
       /* activations.cc LeakyReluPrepare: float expressions widened to double */
@@ -154,7 +184,7 @@ yfo_model* yfo_load(const char* path) {
 
 void yfo_free(yfo_model* m) {
   if (!m) return;
-  if (m->prep) for (uint32_t i = 0; i < m->n_ops; ++i) { free(m->prep[i].mult); free(m->prep[i].shift); }
+  if (m->prep) for (uint32_t i = 0; i < m->n_ops; ++i) { free(m->prep[i].mult); free(m->prep[i].shift); free(m->prep[i].fscale); }
   free(m->prep); free(m->t); free(m->op); free(m->data); free(m);
 }
 
@@ -239,10 +269,16 @@ static void k_pad(const int8_t* in, shp a, int8_t* out, shp r, int top, int left
     memcpy(out + ((size_t)(y + top) * r.w + left) * r.c, in + (size_t)y * a.w * a.c, (size_t)a.w * a.c);
 }
 
+/* the requantisation of one conv accumulator under a variant: mode = MB_* or -1 for FP32 */
+static inline int32_t conv_requant(int32_t acc, int c, const op_prep* p, int mode) {
+  if (mode >= 0) return yfo_mbqm_mode(acc, p->mult[c], p->shift[c], mode);
+  return (int32_t)lrintf((float)acc * p->fscale[c]);                        /* round to nearest, ties to even */
+}
+
 /* reference_integer_ops::ConvPerChannel (int8).  ST: forward_conv2d_integer_SSSA_ch, conv2d_1/5/6/... */
 static void k_conv(const int8_t* in, shp a, const int8_t* w, int kh, int kw, const int32_t* bias,
                    int stride, int pad_h, int pad_w, int32_t in_zp, int32_t out_zp,
-                   const int32_t* mult, const int* shift, int8_t* out, shp r) {
+                   const op_prep* p, int mode, int8_t* out, shp r) {
   for (int oy = 0; oy < r.h; ++oy)
     for (int ox = 0; ox < r.w; ++ox)
       for (int oc = 0; oc < r.c; ++oc) {
@@ -259,7 +295,7 @@ static void k_conv(const int8_t* in, shp a, const int8_t* w, int kh, int kw, con
           }
         }
         acc += bias[oc];
-        acc = yfo_mbqm(acc, mult[oc], shift[oc]) + out_zp;
+        acc = conv_requant(acc, oc, p, mode) + out_zp;
         out[((size_t)oy * r.w + ox) * r.c + oc] = clamp8(acc);
       }
 }
@@ -267,7 +303,7 @@ static void k_conv(const int8_t* in, shp a, const int8_t* w, int kh, int kw, con
 /* reference_integer_ops::DepthwiseConvPerChannel (int8, depth_multiplier 1).  ST: same fn with .groups=C. */
 static void k_dwconv(const int8_t* in, shp a, const int8_t* w, int kh, int kw, const int32_t* bias,
                      int stride, int pad_h, int pad_w, int32_t in_zp, int32_t out_zp,
-                     const int32_t* mult, const int* shift, int8_t* out, shp r) {
+                     const op_prep* p, int mode, int8_t* out, shp r) {
   for (int oy = 0; oy < r.h; ++oy)
     for (int ox = 0; ox < r.w; ++ox)
       for (int c = 0; c < r.c; ++c) {
@@ -282,16 +318,16 @@ static void k_dwconv(const int8_t* in, shp a, const int8_t* w, int kh, int kw, c
           }
         }
         acc += bias[c];
-        acc = yfo_mbqm(acc, mult[c], shift[c]) + out_zp;
+        acc = conv_requant(acc, c, p, mode) + out_zp;
         out[((size_t)oy * r.w + ox) * r.c + c] = clamp8(acc);
       }
 }
 
 /* reference_ops::QuantizeLeakyRelu<int8_t>.  ST uses a float-rounded LUT instead (nl_func_array_integer,
  * network.c:2218..2902) and differs in 11-22 entries per layer -- TFLite semantics are the oracle. */
-static inline int8_t leaky1(int8_t q, int32_t in_zp, int32_t out_zp, const op_prep* p) {
+static inline int8_t leaky1(int8_t q, int32_t in_zp, int32_t out_zp, const op_prep* p, int mode) {
   const int32_t v = (int32_t)q - in_zp;
-  const int32_t u = v >= 0 ? yfo_mbqm(v, p->m_id, p->s_id) : yfo_mbqm(v, p->m_alpha, p->s_alpha);
+  const int32_t u = v >= 0 ? yfo_mbqm_mode(v, p->m_id, p->s_id, mode) : yfo_mbqm_mode(v, p->m_alpha, p->s_alpha, mode);
   return clamp8(out_zp + u);
 }
 
@@ -316,30 +352,35 @@ static void k_maxpool(const int8_t* in, shp a, int k_h, int k_w, int stride, int
 }
 
 /* reference_integer_ops::Add (int8).  ST: forward_eltwise_integer_INT8 with float scales (eltwise_18/35/41). */
-static inline int8_t add1(int8_t q1, int8_t q2, int32_t zp1, int32_t zp2, int32_t zpo, const op_prep* p) {
+static inline int8_t add1(int8_t q1, int8_t q2, int32_t zp1, int32_t zp2, int32_t zpo, const op_prep* p, int mode) {
   const int32_t a = ((int32_t)q1 - zp1) * (1 << 20);
   const int32_t b = ((int32_t)q2 - zp2) * (1 << 20);
-  const int32_t sa = yfo_mbqm(a, p->m1, p->s1);
-  const int32_t sb = yfo_mbqm(b, p->m2, p->s2);
-  return clamp8(yfo_mbqm(sa + sb, p->mo, p->so) + zpo);
+  const int32_t sa = yfo_mbqm_mode(a, p->m1, p->s1, mode);
+  const int32_t sb = yfo_mbqm_mode(b, p->m2, p->s2, mode);
+  return clamp8(yfo_mbqm_mode(sa + sb, p->mo, p->so, mode) + zpo);
 }
 
 /* reference_ops::Requantize int8->int8 (QUANTIZE).  ST folds these into concat_22/46 ("conversion_21/44/45"). */
-static inline int8_t requant1(int8_t q, int32_t in_zp, int32_t out_zp, const op_prep* p) {
-  return clamp8(yfo_mbqm((int32_t)q - in_zp, p->mq, p->sq) + out_zp);
+static inline int8_t requant1(int8_t q, int32_t in_zp, int32_t out_zp, const op_prep* p, int mode) {
+  return clamp8(yfo_mbqm_mode((int32_t)q - in_zp, p->mq, p->sq, mode) + out_zp);
 }
 
-int yfo_leaky_lut(const yfo_model* m, int op_index, int8_t lut[256]) {
+int yfo_leaky_lut(const yfo_model* m, int op_index, int8_t lut[256]) { return yfo_leaky_lut_variant(m, op_index, lut, YFO_RV_REF); }
+
+int yfo_leaky_lut_variant(const yfo_model* m, int op_index, int8_t lut[256], int variant) {
+  if (variant < 0 || variant >= YFO_RV_COUNT) return -2;
   if (op_index < 0 || op_index >= (int)m->n_ops || m->op[op_index].opcode != OP_LEAKY) return -1;
   const yfm_op* o = &m->op[op_index];
   for (int q = -128; q < 128; ++q)
-    lut[q + 128] = leaky1((int8_t)q, m->t[o->in[0]].zero_point, m->t[o->out].zero_point, &m->prep[op_index]);
+    lut[q + 128] = leaky1((int8_t)q, m->t[o->in[0]].zero_point, m->t[o->out].zero_point, &m->prep[op_index], mode_elt(variant));
   return 0;
 }
 
 /* ------------------------------------------------------------------ graph runner (one frame) */
 static void run_frame(const yfo_model* m, const shp* s, const int8_t* in, int8_t* out, int8_t* dump,
-                      int8_t** buf) {
+                      int8_t** buf, int variant) {
+  const int fp32 = variant == YFO_RV_FP32;
+  const int md = fp32 ? -1 : mode_dense(variant), mw = fp32 ? -1 : mode_dw(variant), me = mode_elt(variant);
   /* buf[t]: scratch for tensor t (allocated by caller, sized from s) */
   const shp si = s[m->input];
   memcpy(buf[m->input], in, (size_t)si.h * si.w * si.c);
@@ -364,12 +405,12 @@ static void run_frame(const yfo_model* m, const shp* s, const int8_t* in, int8_t
         int oh, ow, ph, pw;
         same_or_valid(o->padding, a.h, kh, o->stride_h, &oh, &ph);
         same_or_valid(o->padding, a.w, kw, o->stride_w, &ow, &pw);
-        if (o->opcode == OP_CONV) k_conv(x, a, w, kh, kw, b, o->stride_h, ph, pw, zi, zo, p->mult, p->shift, y, r);
-        else k_dwconv(x, a, w, kh, kw, b, o->stride_h, ph, pw, zi, zo, p->mult, p->shift, y, r);
+        if (o->opcode == OP_CONV) k_conv(x, a, w, kh, kw, b, o->stride_h, ph, pw, zi, zo, p, md, y, r);
+        else k_dwconv(x, a, w, kh, kw, b, o->stride_h, ph, pw, zi, zo, p, mw, y, r);
       } break;
       case OP_LEAKY: {
         int8_t lut[256];
-        for (int q = -128; q < 128; ++q) lut[q + 128] = leaky1((int8_t)q, zi, zo, p);
+        for (int q = -128; q < 128; ++q) lut[q + 128] = leaky1((int8_t)q, zi, zo, p, me);
         const size_t n = (size_t)r.h * r.w * r.c;
         for (size_t k = 0; k < n; ++k) y[k] = lut[(int)x[k] + 128];
       } break;
@@ -383,11 +424,11 @@ static void run_frame(const yfo_model* m, const shp* s, const int8_t* in, int8_t
         const int8_t* x2 = buf[o->in[1]];
         const int32_t z2 = m->t[o->in[1]].zero_point;
         const size_t n = (size_t)r.h * r.w * r.c;
-        for (size_t k = 0; k < n; ++k) y[k] = add1(x[k], x2[k], zi, z2, zo, p);
+        for (size_t k = 0; k < n; ++k) y[k] = add1(x[k], x2[k], zi, z2, zo, p, me);
       } break;
       case OP_QUANTIZE: {
         const size_t n = (size_t)r.h * r.w * r.c;
-        for (size_t k = 0; k < n; ++k) y[k] = requant1(x[k], zi, zo, p);
+        for (size_t k = 0; k < n; ++k) y[k] = requant1(x[k], zi, zo, p, me);
       } break;
       case OP_CONCAT: {   /* axis 3, equal quantisation on all operands: byte copy.  ST: forward_concat */
         const int8_t* x2 = buf[o->in[1]];
@@ -407,7 +448,7 @@ static void run_frame(const yfo_model* m, const shp* s, const int8_t* in, int8_t
 
 typedef struct {
   const yfo_model* m; const shp* s; const int8_t* in; int8_t* out; int8_t* dump;
-  int n0, n1; size_t in_bytes, out_bytes; long dump_bytes; int rc;
+  int n0, n1; size_t in_bytes, out_bytes; long dump_bytes; int rc, variant;
 } job;
 
 static void* worker(void* arg) {
@@ -420,14 +461,19 @@ static void* worker(void* arg) {
   }
   for (int f = j->n0; f < j->n1; ++f)
     run_frame(m, j->s, j->in + (size_t)f * j->in_bytes, j->out + (size_t)f * j->out_bytes,
-              j->dump ? j->dump + (size_t)f * j->dump_bytes : NULL, buf);
+              j->dump ? j->dump + (size_t)f * j->dump_bytes : NULL, buf, j->variant);
   for (uint32_t t = 0; t < m->n_tensors; ++t) free(buf[t]);
   free(buf);
   return NULL;
 }
 
 int yfo_run(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* out, int8_t* dump, int threads) {
+  return yfo_run_variant(m, in, n, h, w, out, dump, threads, YFO_RV_REF);
+}
+
+int yfo_run_variant(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* out, int8_t* dump, int threads, int variant) {
   if (!m || !in || !out || n < 0) return -1;
+  if (variant < 0 || variant >= YFO_RV_COUNT) return -3;
   shp* s = (shp*)malloc(sizeof(shp) * m->n_tensors);
   infer_shapes(m, h, w, s);
   const shp so = s[m->output];
@@ -439,7 +485,7 @@ int yfo_run(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* o
   const long db = yfo_dump_bytes(m, h, w);
   for (int k = 0; k < threads; ++k) {
     job* j = &jobs[k];
-    j->m = m; j->s = s; j->in = in; j->out = out; j->dump = dump;
+    j->m = m; j->s = s; j->in = in; j->out = out; j->dump = dump; j->variant = variant;
     j->n0 = (int)((long)n * k / threads); j->n1 = (int)((long)n * (k + 1) / threads);
     j->in_bytes = (size_t)h * w * s[m->input].c; j->out_bytes = (size_t)so.h * so.w * so.c; j->dump_bytes = db;
   }

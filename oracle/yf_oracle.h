@@ -46,6 +46,25 @@ int yfo_run(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* o
 /* LeakyReLU table of tflite op `op_index` as TFLite computes it (256 entries, index q+128). */
 int yfo_leaky_lut(const yfo_model* m, int op_index, int8_t lut[256]);
 
+/* ---- rounding variants (round 6): how much does the one unverifiable CHOICE under every parity claim matter? ----
+ * yfo_run above is variant REF = TFLite's builtin REFERENCE kernels (SURVEY.md 8(c).3's definition of "the tflite int8
+ * reference").  tflite_prediction.py:23 constructs tf.lite.Interpreter with default arguments = the default resolver,
+ * whose per-channel int8 CONV_2D goes through ruy; the variants restate the other published roundings of the
+ * requantisation step so that tests can measure the exposure of heads and boxes to that choice, and so that the
+ * library's selectable rounding (yf_network_set_requant_rounding) has a checker.  All equally interpreter-unverified. */
+enum {
+  YFO_RV_REF = 0,           /* RoundingDivideByPOT everywhere: ties away from zero (common.h)                         */
+  YFO_RV_UP_DENSE = 1,      /* dense CONV_2D: right shift breaks ties upward (ruy's vector kernels, ARM srshl);
+                               DEPTHWISE_CONV_2D, LEAKY_RELU, ADD, QUANTIZE keep common.h's form                      */
+  YFO_RV_UP_ALL = 2,        /* every op ties upward                                                                    */
+  YFO_RV_FP32 = 3,          /* CONV_2D and DEPTHWISE_CONV_2D requantise in float32 (XNNPACK qs8): lrintf(acc * scale) */
+  YFO_RV_SINGLE_DENSE = 4,  /* dense CONV_2D: single rounding (x*M + 2^(30-shift)) >> (31-shift) (ruy standard C++)    */
+  YFO_RV_COUNT
+};
+int32_t yfo_mbqm_mode(int32_t x, int32_t m, int shift, int mode);   /* mode: 0 REF, 1 ties upward, 2 single rounding */
+int yfo_run_variant(const yfo_model* m, const int8_t* in, int n, int h, int w, int8_t* out, int8_t* dump, int threads, int variant);
+int yfo_leaky_lut_variant(const yfo_model* m, int op_index, int8_t lut[256], int variant);
+
 typedef struct {
   int32_t frame;
   uint8_t anchor, row, col;

@@ -27,6 +27,8 @@ OUT_H, OUT_W, OUT_C = 7, 7, 18
 IN_BYTES, OUT_BYTES = IN_H * IN_W * IN_C, OUT_H * OUT_W * OUT_C
 WEIGHTS_BYTES, ACTIVATIONS_BYTES = 11304, 29784
 YF_DECODE_PY, YF_DECODE_FW, YF_DECODE_FW_HOST = 0, 1, 2
+# rounding of the requantisation step (include/yf_network.h, yf_network_set_requant_rounding)
+YF_ROUND_TFLITE_REF, YF_ROUND_TIES_UP, YF_ROUND_TIES_UP_ALL, YF_ROUND_SINGLE = 0, 1, 2, 3
 
 
 class AiError(ctypes.Structure):
@@ -72,6 +74,10 @@ class AiNetworkReport(ctypes.Structure):
                 ("p", AiNetworkParams), ("n_nodes", ctypes.c_uint32), ("signature", ctypes.c_uint32)]
 
 
+class YfScratchStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_ulonglong) for n in ("events_recorded", "events_skipped", "event_waits", "device_syncs", "acquire_waits", "regions")]
+
+
 class YfDet(ctypes.Structure):
     _fields_ = [("frame", ctypes.c_int32), ("anchor", ctypes.c_uint8), ("row", ctypes.c_uint8), ("col", ctypes.c_uint8),
                 ("q_conf", ctypes.c_int8), ("conf", ctypes.c_float), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32),
@@ -87,7 +93,7 @@ EXPORTS = ["ai_network_create", "ai_network_init", "ai_network_run", "ai_network
            "ai_network_data_params_get", "ai_platform_bind_network_params", "yf_network_set_device",
            "yf_network_configure", "yf_network_run_device", "yf_network_run_device_dump", "yf_network_dump_bytes", "yf_network_run_device_hw",
            "yf_network_decode_device", "yf_network_run_decode_device", "yf_network_pack_detections_device", "yf_network_unpack_detections_device", "yf_network_prepare_rgb565_device", "yf_network_run_camera_device", "yf_network_time_device",
-           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_release_stream", "yf_network_scratch_bytes", "yf_network_last_error_text",
+           "yf_network_time_stages", "yf_network_format_uart", "yf_network_shard_range", "yf_network_table_plan", "yf_network_all_gather_device", "yf_network_fp16_init", "yf_network_fp16_run_device", "yf_network_release_stream", "yf_network_scratch_bytes", "yf_network_scratch_stats", "yf_network_set_requant_rounding", "yf_network_get_requant_rounding", "yf_network_last_error_text",
            "yf_network_kernel_name", "yf_network_kernel_name_for", "yf_network_build_id", "yf_network_host_id",
            "ai_platform_observer_node_info", "ai_platform_observer_register", "ai_platform_observer_register_s",
            "ai_platform_observer_unregister", "ai_platform_observer_unregister_s",
@@ -146,6 +152,28 @@ def build(force=False):
     return LIB_PATH
 
 
+def library_is_current():
+    """True when the in-tree library can be loaded WITHOUT running make: it exists, the ids make stamped beside it (lib/build_id.stamp,
+    lib/host_id.stamp) are the ids of the sources as they stand, and it is newer than every one of them.  load() then starts no child process --
+    under rocprofv3 every child of a GPU-holding process is instrumented by the profiler's preloaded tool (round 5: make, sh, cut and sha256sum
+    in the middle of a counter pass).  The ids baked into the library are still checked after it is loaded."""
+    import re
+    csrc, lib = os.path.join(_PKG, "csrc"), os.path.join(_PKG, "lib")
+    try:
+        if open(os.path.join(lib, "build_id.stamp")).read().strip() != expected_build_id():
+            return False
+        if open(os.path.join(lib, "host_id.stamp")).read().strip() != expected_host_id():
+            return False
+        built = os.path.getmtime(LIB_PATH)
+        flags = open(os.path.join(csrc, "flags.mk")).read()
+        srcs = ["Makefile", "flags.mk"]
+        for var in ("DEVICE_SRCS", "HOST_SRCS"):
+            srcs += re.search(r"^%s\s*=\s*(.*)$" % var, flags, re.M).group(1).split()
+        return all(os.path.getmtime(os.path.join(csrc, f)) <= built for f in srcs)
+    except (OSError, AttributeError):
+        return False
+
+
 _lib = None
 
 
@@ -178,9 +206,16 @@ def load():
     if _lib is not None:
         return _lib
     check_id = False
-    if not os.environ.get("YF_LIB_PATH"):
+    if os.environ.get("YF_LIB_PATH"):
+        pass
+    elif os.environ.get("YF_NO_BUILD") == "1" or library_is_current():
+        # no child process at all (profiler runs set YF_NO_BUILD=1: tools/profile_*.sh); a library built from other sources is refused below
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"YF_NO_BUILD=1 and {LIB_PATH} does not exist: build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        check_id = True
+    else:
         try:
-            build()              # `make`: a no-op when the library is current, so a stale .so is never loaded under fresh sources
+            build()              # `make`: a stale .so is never loaded under fresh sources
         except (OSError, subprocess.CalledProcessError) as e:
             # no make / no hipcc on this box (or the build failed): an existing library is used if -- and only if -- it was built from these
             # sources with these flags (its baked-in id against the id computed here)
@@ -195,11 +230,11 @@ def load():
         lib.yf_network_build_id.restype = ctypes.c_char_p
         have, want = (lib.yf_network_build_id() or b"").decode(), expected_build_id()
         if have != want:
-            raise RuntimeError(f"{LIB_PATH} was built from other sources or flags (build id {have}, expected {want}) and cannot be rebuilt here")
+            raise RuntimeError(f"{LIB_PATH} was built from other sources or flags (build id {have}, expected {want}) and is not being rebuilt here (no make / YF_NO_BUILD=1)")
         lib.yf_network_host_id.restype = ctypes.c_char_p
         have, want = (lib.yf_network_host_id() or b"").decode(), expected_host_id()
         if have != want:
-            raise RuntimeError(f"{LIB_PATH}: its C host layer was built from other sources (host id {have}, expected {want}) and cannot be rebuilt here")
+            raise RuntimeError(f"{LIB_PATH}: its C host layer was built from other sources (host id {have}, expected {want}) and is not being rebuilt here (no make / YF_NO_BUILD=1)")
     vp, cl = ctypes.c_void_p, ctypes.c_long
     lib.ai_network_create.restype = AiError
     lib.ai_network_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(AiBuffer)]
@@ -262,6 +297,10 @@ def load():
         lib.yf_network_release_stream.argtypes = [vp, vp]
         lib.yf_network_scratch_bytes.restype = ctypes.c_size_t
         lib.yf_network_scratch_bytes.argtypes = [vp]
+    if hasattr(lib, "yf_network_set_requant_rounding"):
+        lib.yf_network_set_requant_rounding.argtypes = [vp, ctypes.c_int]
+        lib.yf_network_get_requant_rounding.argtypes = [vp]
+        lib.yf_network_scratch_stats.argtypes = [vp, ctypes.POINTER(YfScratchStats)]
     lib.yf_network_last_error_text.restype = ctypes.c_char_p
     lib.yf_network_last_error_text.argtypes = [vp]
     lib.yf_network_kernel_name.restype = ctypes.c_char_p
@@ -408,6 +447,24 @@ class Network:
 
     def scratch_bytes(self):
         return int(self.lib.yf_network_scratch_bytes(self.handle))
+
+    def scratch_stats(self):
+        """events recorded / skipped and the waits of the all-busy path, as a dict (include/yf_network.h, yf_scratch_stats)"""
+        st = YfScratchStats()
+        if self.lib.yf_network_scratch_stats(self.handle, ctypes.byref(st)) != 0:
+            self._raise("yf_network_scratch_stats")
+        return {n: int(getattr(st, n)) for n, _ in YfScratchStats._fields_}
+
+    def set_requant_rounding(self, rounding):
+        """Which published rounding of TFLite's requantisation the network computes (YF_ROUND_*; default: the builtin reference kernels).
+        Same kernels, other constants; before or after init()."""
+        if self.lib.yf_network_set_requant_rounding(self.handle, int(rounding)) != 0:
+            self._raise("yf_network_set_requant_rounding")
+        return self
+
+    @property
+    def requant_rounding(self):
+        return int(self.lib.yf_network_get_requant_rounding(self.handle))
 
     def fp16_run_device(self, d_in_f16, d_out_f32, n, stream=None):
         if self.lib.yf_network_fp16_run_device(self.handle, d_in_f16, d_out_f32, n, stream) != n:

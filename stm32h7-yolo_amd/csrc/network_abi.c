@@ -33,6 +33,8 @@ typedef struct {
   yf_fp16* fp16;
   int device;
   int cfg_frames, cfg_waves;
+  int rounding;                           /* YF_ROUND_*: which published rounding the requantisation constants are built for */
+  size_t bound_weights_bytes;
   ai_platform_version tools_api;          /* what the network was created with (network.c:3376: AI_TOOLS_API_VERSION_*); reports return it */
   const void* bound_weights;              /* what ai_network_init was handed: the reports describe these buffers */
   ai_handle bound_activations;
@@ -56,6 +58,16 @@ void yf_impl_fail_init(ai_handle network, unsigned code, const char* text) {
 static ai_platform_version version3(unsigned a, unsigned b, unsigned c);
 static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = type; e.code = code; return e; }
 
+/* $YF_REQUANT_ROUNDING: lets an unmodified aiInit() (yoloface.c:188-211: create + init back to back) be steered from outside */
+static int rounding_from_env(void) {
+  const char* v = getenv("YF_REQUANT_ROUNDING");
+  if (!v || !*v || !strcmp(v, "ref")) return YF_ROUND_TFLITE_REF;
+  if (!strcmp(v, "ties_up")) return YF_ROUND_TIES_UP;
+  if (!strcmp(v, "ties_up_all")) return YF_ROUND_TIES_UP_ALL;
+  if (!strcmp(v, "single")) return YF_ROUND_SINGLE;
+  return -1;                               /* unknown word: ai_network_init fails loudly instead of guessing */
+}
+
 /* ------------------------------------------------------------------------------------------------ create / destroy */
 ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
   if (!network) return mk_error(AI_ERROR_CREATE_FAILED, AI_ERROR_CODE_INVALID_PTR);
@@ -68,6 +80,7 @@ ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
   g_network.state = ST_CREATED;
   g_network.device = dev; g_network.cfg_frames = cf; g_network.cfg_waves = cw;
   g_network.tools_api = version3(YF_REPORT_TOOLS_API_VERSION);
+  g_network.rounding = rounding_from_env();
   *network = (ai_handle)&g_network;
   return mk_error(AI_ERROR_NONE, AI_ERROR_CODE_NONE);
 }
@@ -130,10 +143,13 @@ ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
     latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_ACTIVATIONS, "activations buffer smaller than 29784 bytes"); return false;
   }
   if (c->engine) { yf_engine_destroy(c->engine); c->engine = NULL; c->state = ST_CREATED; }
+  if (c->rounding < 0 || c->rounding >= YF_ROUND_COUNT) {
+    latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, "YF_REQUANT_ROUNDING is none of ref, ties_up, ties_up_all, single"); return false;
+  }
 
   uint8_t* tables = NULL;
   yf_table_index ix;
-  const int prc = yf_prepare_tables(blob, wbytes, &tables, &ix);
+  const int prc = yf_prepare_tables_rounding(blob, wbytes, c->rounding, &tables, &ix);
   if (prc != YF_PREP_OK) {
     char t[96]; snprintf(t, sizeof t, "table preparation failed (code %d)", prc);
     latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, t); return false;
@@ -150,6 +166,7 @@ ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
   }
   c->state = ST_READY;
   c->bound_weights = blob;
+  c->bound_weights_bytes = wbytes;
   c->bound_activations = act ? act->data : NULL;
   return true;
 }
@@ -329,6 +346,28 @@ YF_API int yf_network_set_device(ai_handle network, int device) {
   if (c->state == ST_READY) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_IN_USE, "set the device before ai_network_init"); return -1; }
   c->device = device;
   return 0;
+}
+
+YF_API int yf_network_set_requant_rounding(ai_handle network, int rounding) {
+  yf_context* c = acquire(network);
+  if (!c) return -1;
+  if (rounding < 0 || rounding >= YF_ROUND_COUNT) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_OUT_OF_RANGE, "no such requantisation rounding"); return -1; }
+  if (c->state == ST_READY && c->engine && rounding != c->rounding) {
+    /* same weights (still the caller's, as on the MCU: network.c:3108-3267 keeps pointers into the blob), other constants, same layout */
+    uint8_t* tables = NULL;
+    yf_table_index ix;
+    const int prc = yf_prepare_tables_rounding((const uint8_t*)c->bound_weights, c->bound_weights_bytes, rounding, &tables, &ix);
+    if (prc != YF_PREP_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK_WEIGHTS, "table preparation failed"); return -1; }
+    const int erc = yf_engine_set_tables(c->engine, tables, &ix);
+    free(tables);
+    if (erc != YF_ENG_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_engine_error(c->engine)); return -1; }
+  }
+  c->rounding = rounding;
+  return 0;
+}
+YF_API int yf_network_get_requant_rounding(ai_handle network) {
+  yf_context* c = acquire(network);
+  return c ? c->rounding : -1;
 }
 
 YF_API int yf_network_configure(ai_handle network, int frames_per_wg, int waves_per_wg) {
@@ -540,6 +579,16 @@ YF_API size_t yf_network_scratch_bytes(ai_handle network) {
   yf_context* c = acquire(network);
   if (!c || !c->engine) return 0;
   return yf_engine_scratch_bytes(c->engine) + (c->fp16 ? yf_fp16_scratch_bytes(c->fp16) : 0);
+}
+
+YF_API int yf_network_scratch_stats(ai_handle network, yf_scratch_stats* out) {
+  yf_context* c = acquire(network);
+  if (!c || !out) return -1;
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+  if (c->engine) yf_engine_scratch_stats(c->engine, v);
+  if (c->fp16) yf_fp16_scratch_stats(c->fp16, v);
+  out->events_recorded = v[0]; out->events_skipped = v[1]; out->event_waits = v[2]; out->device_syncs = v[3]; out->acquire_waits = v[4]; out->regions = v[5];
+  return 0;
 }
 
 YF_API const char* yf_network_last_error_text(ai_handle network) {

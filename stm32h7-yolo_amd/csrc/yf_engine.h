@@ -15,6 +15,8 @@ enum { YF_ENG_OK = 0, YF_ENG_ERR_HIP = -1, YF_ENG_ERR_ARG = -2, YF_ENG_ERR_NO_DE
 
 int  yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen);
 void yf_engine_destroy(yf_engine* e);
+/* replace the table blob of a live engine (same layout, other constants: yf_network_set_requant_rounding); waits for the device first */
+int  yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix);
 /* 1 if a production kernel of that shape is compiled in (frames_per_wg may carry the +200 experimental-build tag) */
 int  yf_engine_variant_exists(int frames_per_wg, int waves_per_wg);
 int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);
@@ -49,6 +51,7 @@ int  yf_engine_run_device_160(yf_engine* e, const void* d_in, void* d_out, long 
 /* scratch regions are owned by launch streams (yf_stream_scratch.h): give a stream's regions back before destroying it; bytes held right now */
 int  yf_engine_release_stream(yf_engine* e, void* stream);
 size_t yf_engine_scratch_bytes(yf_engine* e);
+void yf_engine_scratch_stats(yf_engine* e, unsigned long long out[6]);
 long yf_engine_dump_bytes(void);
 /* debug: dump build on n host frames; heads and the per-stage dump records come back to host memory (per-node observer) */
 int  yf_engine_run_host_dump(yf_engine* e, const void* h_in, void* h_out, void* h_dump, long n);

@@ -130,6 +130,7 @@ struct yf_engine {
   int device = 0;
   int cus = 0;
   size_t lds_per_cu = 0;                         // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
+  int band_wgs_per_cu[3] = {1, 1, 1};            // resident workgroups per CU of the three banded 160x160 kernels on this device (occupancy query at creation)
 #ifdef YF_LAB
   int grid_div = 1;                              // laboratory (YF_LAB_GRID_DIV): a launch takes 1 / grid_div of the resident grid (launch-policy what-ifs: several launches side by side)
   int fail_next_launch = 0;                      // laboratory: the next k fused launches get an invalid grid (tests the scratch lease on the failure path)
@@ -235,27 +236,37 @@ static int launch160_from(yf_engine* e, const yf160::GenParams& prm, unsigned gr
 #endif
 
 // 160x160, banded form: three kernels, each fusing a group of stages over row bands staged through LDS
-struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; int wgs_per_cu; };
+struct BandKernel { const void* fn; const char* name; unsigned threads; size_t lds; int jobs_per_frame; };   // (workgroups per CU: per ENGINE, yf_engine::band_wgs_per_cu)
 #ifndef YF_K1_NW
 #define YF_K1_NW 8
 #endif
 #define YF_K1_NW_ YF_K1_NW
-static BandKernel k_band_fused[3] = {            // round 3: K2 and K3 fused (three tensors cross HBM instead of five)
-  {(const void*)yf160::band::band_k1<YF_K1_NW_>, "band_k1", YF_K1_NW_ * 64, (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS, 1},
-  {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS, 1},
-  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1, 1},
+static const BandKernel k_band_fused[3] = {      // round 3: K2 and K3 fused (three tensors cross HBM instead of five)
+  {(const void*)yf160::band::band_k1<YF_K1_NW_>, "band_k1", YF_K1_NW_ * 64, (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS},
+  {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS},
+  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1},
 };
 static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
   for (int i = 0; i < 3; ++i) {
     const BandKernel& k = k_band_fused[i];
     const long jobs = prm.n * k.jobs_per_frame;
-    const long full = (long)e->cus * k.wgs_per_cu;           // persistent grid: every workgroup resident, jobs grid-strided
+    const long full = (long)e->cus * e->band_wgs_per_cu[i];  // persistent grid: every workgroup resident, jobs grid-strided
     const unsigned grid = (unsigned)(jobs < full ? jobs : full);
     void* args[] = {(void*)&prm};
     const hipError_t rc = hipLaunchKernel(k.fn, dim3(grid), dim3(k.threads), args, k.lds, s);
     if (rc != hipSuccess) { e->err = std::string(k.name) + " launch: " + hipGetErrorString(rc); return YF_ENG_ERR_HIP; }
   }
   return YF_ENG_OK;
+}
+
+// the kernels address the tables at compiled-in offsets (yf_kernels.hip.h, TablePlan): the blob must be laid out that way
+static bool layout_is_the_compiled_plan(const yf_table_index* ix) {
+  bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
+  for (int i = 0; i < YF_N_DENSE; ++i) same = same && (int)ix->dense[i].w_off == yf::PLAN.w_off[i] && (int)ix->dense[i].c_off == yf::PLAN.c_off[i];
+  for (int i = 0; i < YF_N_DW; ++i) same = same && (int)ix->dw[i].g_off == yf::PLAN.g_off[i];
+  for (int i = 0; i < YF_N_CS; ++i)
+    same = same && (int)ix->cs_v_off[i] == yf::PLAN.vb_off[i] && (int)ix->cs_v_bytes[i] == yf::PLAN.vb_bytes[i] && (int)ix->cs_s_off[i] == yf::PLAN.sb_off[i];
+  return same;
 }
 
 extern "C" {
@@ -282,14 +293,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   e->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;      // 160 KB on gfx950: how many workgroups of a shape a CU holds (grid size, scratch slots)
   for (const Variant& v : k_variants)
     if (e->lds_per_cu < v.lds) return quit("the device reports " + std::to_string(e->lds_per_cu) + " bytes of LDS per CU, " + v.name + " needs " + std::to_string(v.lds), YF_ENG_ERR_NO_DEVICE);
-  {   // the kernels address the tables at compiled-in offsets (yf_kernels.hip.h, TablePlan): the blob must be laid out that way
-    bool same = (int)ix->lut_off == yf::PLAN.lut_off && (int)ix->total_bytes == yf::PLAN.total;
-    for (int i = 0; i < YF_N_DENSE; ++i) same = same && (int)ix->dense[i].w_off == yf::PLAN.w_off[i] && (int)ix->dense[i].c_off == yf::PLAN.c_off[i];
-    for (int i = 0; i < YF_N_DW; ++i) same = same && (int)ix->dw[i].g_off == yf::PLAN.g_off[i];
-    for (int i = 0; i < YF_N_CS; ++i)
-      same = same && (int)ix->cs_v_off[i] == yf::PLAN.vb_off[i] && (int)ix->cs_v_bytes[i] == yf::PLAN.vb_bytes[i] && (int)ix->cs_s_off[i] == yf::PLAN.sb_off[i];
-    if (!same) return quit("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG);
-  }
+  if (!layout_is_the_compiled_plan(ix)) return quit("table blob layout differs from the layout compiled into the kernels", YF_ENG_ERR_ARG);
   if ((rc = hipMalloc((void**)&e->d_tab, ix->total_bytes)) != hipSuccess) return bail(rc, "hipMalloc(tables)");
   if ((rc = hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(rc, "hipMemcpy(tables)");
   for (int i = 1; i < 256; ++i) {           // the fused decode compares quantised confidences (yf_decode_q_threshold): the table must not decrease
@@ -315,7 +319,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   }
   { const char* lw = getenv("YF_160_LAYERWISE"); e->layerwise160 = lw && lw[0] == '1'; }     // the lab library's layer-by-layer form (debugging)
 #endif
-  auto prepare_band = [&](BandKernel& k) -> int {
+  auto prepare_band = [&](const BandKernel& k, int* wgs_per_cu) -> int {
     hipFuncAttributes at;
     if ((rc = hipFuncGetAttributes(&at, k.fn)) != hipSuccess) return bail(rc, "hipFuncGetAttributes");
     if (at.sharedSizeBytes != 0) return quit(std::string(k.name) + ": kernel has static LDS, absolute LUT addressing is invalid", YF_ENG_ERR_HIP);
@@ -323,10 +327,10 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
       return bail(rc, "hipFuncSetAttribute(max dynamic LDS)");
     int occ = 0;
     if ((rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, (int)k.threads, k.lds)) != hipSuccess) return bail(rc, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-    k.wgs_per_cu = occ > 0 ? occ : 1;
+    *wgs_per_cu = occ > 0 ? occ : 1;                          // a property of THIS engine's device (round 5 wrote it into the process-wide kernel table)
     return YF_ENG_OK;
   };
-  for (BandKernel& k : k_band_fused) { const int r = prepare_band(k); if (r != YF_ENG_OK) return r; }
+  for (int i = 0; i < 3; ++i) { const int r = prepare_band(k_band_fused[i], &e->band_wgs_per_cu[i]); if (r != YF_ENG_OK) return r; }
   { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
 #ifdef YF_LAB
   { const char* fl = getenv("YF_LAB_FAIL_LAUNCHES"); if (fl) e->fail_next_launch = atoi(fl); }
@@ -354,9 +358,20 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   return YF_ENG_OK;
 }
 
+int yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix) {
+  if (!e || !table_blob || !ix) return YF_ENG_ERR_ARG;
+  if (!layout_is_the_compiled_plan(ix)) { e->err = "table blob layout differs from the layout compiled into the kernels"; return YF_ENG_ERR_ARG; }
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipDeviceSynchronize());             // launches in flight read the old constants to their end
+  HIPCHK(e, hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice));
+  e->ix = *ix;
+  return YF_ENG_OK;
+}
+
 void yf_engine_destroy(yf_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();                  // a launch still in flight finishes before its tables and scratch are freed (no reliance on hipFree's implicit wait)
   if (e->d_tab) (void)hipFree(e->d_tab);
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_out) (void)hipFree(e->d_out);
@@ -679,6 +694,16 @@ int yf_engine_release_stream(yf_engine* e, void* stream) {
 }
 
 size_t yf_engine_scratch_bytes(yf_engine* e) { return e ? e->park.bytes_held() + e->arena160.bytes_held() : 0; }
+// counters of the two scratch maps, summed: out[0..5] = events recorded, events skipped, event waits, device synchronisations, waits for another
+// thread's mark (the last three on the all-busy path of yf_stream_scratch::get), regions in existence
+void yf_engine_scratch_stats(yf_engine* e, unsigned long long out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (!e) return;
+  for (yf_stream_scratch* m : {&e->park, &e->arena160}) {
+    const yf_stream_scratch::Stats s = m->stats();
+    out[0] += s.events_recorded; out[1] += s.events_skipped; out[2] += s.event_waits; out[3] += s.device_syncs; out[4] += s.acquire_waits; out[5] += s.regions;
+  }
+}
 
 int yf_engine_time_stages(yf_engine* e, const void* d_in, void* d_out, long n, int iters, int stop_stage, void* stream, float* ms_per_launch) {
   if (!e || !d_in || !d_out || n <= 0 || iters <= 0 || !ms_per_launch) return YF_ENG_ERR_ARG;

@@ -1061,6 +1061,7 @@ const char* yf_fp16_error(const yf_fp16* c) { return c ? c->err.c_str() : "null 
 void yf_fp16_destroy(yf_fp16* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();                  // a launch still in flight finishes before its tables and park slots are freed
   if (c->d_tab) (void)hipFree(c->d_tab);
   c->park.release();
   delete c;
@@ -1155,6 +1156,11 @@ int yf_fp16_release_stream(yf_fp16* c, void* stream) {
   return 0;
 }
 size_t yf_fp16_scratch_bytes(yf_fp16* c) { return c ? c->park.bytes_held() : 0; }
+void yf_fp16_scratch_stats(yf_fp16* c, unsigned long long out[6]) {          // added to out (yf_engine_scratch_stats has the order)
+  if (!c) return;
+  const yf_stream_scratch::Stats s = c->park.stats();
+  out[0] += s.events_recorded; out[1] += s.events_skipped; out[2] += s.event_waits; out[3] += s.device_syncs; out[4] += s.acquire_waits; out[5] += s.regions;
+}
 
 // d_in: fp16 [n][56][56][3] (pixel / 255), d_out: fp32 logits [n][7][7][18]
 int yf_fp16_run_device(yf_fp16* c, const void* d_in, void* d_out, long n, void* stream) {

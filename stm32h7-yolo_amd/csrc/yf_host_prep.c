@@ -10,6 +10,12 @@
  *   LEAKY_RELU       : QuantizeMultiplier((double)(float)(s_in*alpha/s_out)), ...(s_in/s_out)
  *   ADD              : left_shift 20, QuantizeMultiplierSmallerThanOneExp x3
  *   QUANTIZE         : QuantizeMultiplier((double)s_in / (double)s_out)
+ *
+ * Which ROUNDING the requantisation's right shift takes is selectable (include/yf_network.h, yf_network_set_requant_rounding):
+ * the default is TFLite's builtin REFERENCE kernels (RoundingDivideByPOT: ties away from zero) = SURVEY.md 8(c).3's definition
+ * of "the tflite int8 reference"; the reference's script builds its interpreter with the default resolver
+ * (yoloface/tflite/tflite_prediction.py:23), whose per-channel int8 CONV_2D goes through ruy -- ties upward, or one single
+ * rounding on ruy's portable path.  Every form is a different set of CONSTANTS for the same kernels (yf_tables.h, yf_pass).
  */
 #include "yf_host_prep.h"
 #include "gen/yf_model_gen.h"
@@ -51,11 +57,29 @@ int32_t yf_mbqm(int32_t x, int32_t mult, int shift) {
   return rounding_div_pot(sat_rounding_doubling_high_mul(x * (1 << ls), mult), rs);
 }
 
+/* The three published forms of MultiplyByQuantizedMultiplier's rounding (own statement; the oracle has an independent one):
+ * RQ_REF the above; RQ_UP the right shift breaks ties upward (ARM srshl, ruy's vector kernels); RQ_SINGLE one rounding of
+ * the 64-bit product (ruy/apply_multiplier.cc). */
+enum { RQ_REF = 0, RQ_UP = 1, RQ_SINGLE = 2 };
+int32_t yf_mbqm_form(int32_t x, int32_t mult, int shift, int form) {
+  if (form == RQ_REF) return yf_mbqm(x, mult, shift);
+  const int ls = shift > 0 ? shift : 0, rs = shift > 0 ? 0 : -shift;
+  if (form == RQ_UP) {
+    const long long s = sat_rounding_doubling_high_mul(x * (1 << ls), mult);
+    return rs ? (int32_t)((s + (1LL << (rs - 1))) >> rs) : (int32_t)s;
+  }
+  const int total = 31 - shift;
+  return (int32_t)(((long long)x * mult + (1LL << (total - 1))) >> total);
+}
+/* the form each op family takes under a rounding mode of the public interface */
+static int form_dense(int rounding) { return rounding == YF_ROUND_TIES_UP || rounding == YF_ROUND_TIES_UP_ALL ? RQ_UP : rounding == YF_ROUND_SINGLE ? RQ_SINGLE : RQ_REF; }
+static int form_other(int rounding) { return rounding == YF_ROUND_TIES_UP_ALL ? RQ_UP : RQ_REF; }
+
 static int8_t sat8(int32_t v) { return (int8_t)(v < -128 ? -128 : v > 127 ? 127 : v); }
 
 /* ---- LUT builders ------------------------------------------------------------------------------------------ */
 /* TFLite int8 LEAKY_RELU as a table over q in [-128,127] (index q+128). */
-static void build_leaky_lut(int t_in, int t_out, uint8_t* lut) {
+static void build_leaky_lut(int t_in, int t_out, uint8_t* lut, int form) {
   const float s_in = t_scale(t_in), s_out = t_scale(t_out);
   const float alpha = 0.1f;                              /* LeakyReluOptions.alpha of all 17 ops (0x3dcccccd) */
   int32_t m_a, m_i; int sh_a, sh_i;
@@ -63,29 +87,38 @@ static void build_leaky_lut(int t_in, int t_out, uint8_t* lut) {
   yf_quantize_multiplier((double)(float)(s_in / s_out), &m_i, &sh_i);
   for (int q = -128; q < 128; ++q) {
     const int32_t v = q - t_zp(t_in);
-    const int32_t u = v >= 0 ? yf_mbqm(v, m_i, sh_i) : yf_mbqm(v, m_a, sh_a);
+    const int32_t u = v >= 0 ? yf_mbqm_form(v, m_i, sh_i, form) : yf_mbqm_form(v, m_a, sh_a, form);
     lut[q + 128] = (uint8_t)sat8(t_zp(t_out) + u);
   }
 }
 
 /* TFLite int8->int8 QUANTIZE (requantize) as a table. */
-static void build_requant_lut(int t_in, int t_out, uint8_t* lut) {
+static void build_requant_lut(int t_in, int t_out, uint8_t* lut, int form) {
   int32_t m; int sh;
   yf_quantize_multiplier((double)t_scale(t_in) / (double)t_scale(t_out), &m, &sh);
   for (int q = -128; q < 128; ++q)
-    lut[q + 128] = (uint8_t)sat8(yf_mbqm(q - t_zp(t_in), m, sh) + t_zp(t_out));
+    lut[q + 128] = (uint8_t)sat8(yf_mbqm_form(q - t_zp(t_in), m, sh, form) + t_zp(t_out));
 }
 
 /* ---- per-channel requantisation constants (device form: yf_tables.h, yf_pass) -------------------------------- */
-/* 64-bit constant of the fused requantisation: (off)*2M + 2^31 + (2^(rs-1) - 1)*2^32 (mod 2^64), off = bias' - O. */
-static void build_c64(long long off, int32_t m, int rs, uint32_t out[2]) {
-  const unsigned long long c = (unsigned long long)off * (2ull * (unsigned long long)(uint32_t)m)   /* wraps mod 2^64 as intended */
-                             + (1ull << 31) + ((((unsigned long long)1 << (rs - 1)) - 1ull) << 32);
+/* 64-bit constant of the fused requantisation and the matching ZR (yf_tables.h, yf_pass), off = bias' - O, Z = zp_out + 128:
+ *   RQ_REF    C64 = off*2M + 2^31 + (2^(rs-1) - 1)*2^32 (mod 2^64),   ZR = Z << rs         carry-out = TFLite's sign term
+ *   RQ_UP     C64 = off*2M + 2^31 + 2^(rs-1)*2^32 + 2^63,             ZR = (Z << rs) - 2^31
+ *   RQ_SINGLE C64 = off*2M + 2^(31+rs) + 2^63,                        ZR = (Z << rs) - 2^31
+ * The last two have no sign term: the 2^63 keeps acc_p*2M + C64 inside [2^61, 2^64) for every accumulator the host admits
+ * (|acc| < 2^29), so the multiply-add never carries out, and its 2^31 in the high word is taken back by ZR (32-bit wrap).  The
+ * kernels' instruction sequence -- v_mad_u64_u32, v_addc_co_u32, v_ashrrev, v_med3 -- is the same for all three. */
+static void build_c64(long long off, int32_t m, int rs, int form, int z, uint32_t out[2], uint32_t* zr) {
+  unsigned long long c = (unsigned long long)off * (2ull * (unsigned long long)(uint32_t)m);   /* wraps mod 2^64 as intended */
+  if (form == RQ_REF) c += (1ull << 31) + ((((unsigned long long)1 << (rs - 1)) - 1ull) << 32);
+  else if (form == RQ_UP) c += (1ull << 31) + (((unsigned long long)1 << (rs - 1)) << 32) + (1ull << 63);
+  else c += ((unsigned long long)1 << (31 + rs)) + (1ull << 63);
   out[0] = (uint32_t)c; out[1] = (uint32_t)(c >> 32);
+  *zr = ((uint32_t)z << rs) - (form == RQ_REF ? 0u : 0x80000000u);
 }
 
 /* Channel j of pass p.  abs_w = sum |w| (bounds the accumulator).  Returns 0 or an error code. */
-static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int32_t abs_w, yf_pass* p, int j) {
+static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int32_t abs_w, yf_pass* p, int j, int form) {
   const float s_in = t_scale(d->t_in), s_out = t_scale(d->t_out);
   const float s_w = f32_from_bits(d->wscale_bits[ch]);
   int32_t m; int sh;
@@ -99,15 +132,14 @@ static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_
   /* O + sum w*x_raw must stay a positive 32-bit multiplicand and the true accumulator below 2^29 in magnitude */
   if ((bias2 < 0 ? -bias2 : bias2) + 255ll * abs_w >= (1ll << 29)) return YF_PREP_ERR_SHIFT_RANGE;
   p->mult2[j] = (uint32_t)m << 1;
-  p->zr[j] = (uint32_t)(t_zp(d->t_out) + 128) << rs;
-  build_c64(bias2 - (long long)YF_ACC_OFFSET, m, rs, p->c64[j]);
+  build_c64(bias2 - (long long)YF_ACC_OFFSET, m, rs, form, t_zp(d->t_out) + 128, p->c64[j], &p->zr[j]);
   p->rshift[j] = rs;
   return 0;
 }
 /* padding channel of a pass (cout not a multiple of 4): harmless constants, the byte it produces is never read */
 static void pad_chan(yf_pass* p, int j) {
-  p->mult2[j] = ((1u << 30) + 1u) << 1; p->zr[j] = 128u << 1; p->rshift[j] = 1;
-  build_c64(-(long long)YF_ACC_OFFSET, (1 << 30) + 1, 1, p->c64[j]);
+  p->mult2[j] = ((1u << 30) + 1u) << 1; p->rshift[j] = 1;
+  build_c64(-(long long)YF_ACC_OFFSET, (1 << 30) + 1, 1, RQ_REF, 128, p->c64[j], &p->zr[j]);
 }
 
 static const yf_conv_desc* find_conv(int tfl_op) {
@@ -145,7 +177,13 @@ static void conv1_slot(int ky, int kx, int c, int* step, int* slot) {
 }
 
 int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** out_blob, yf_table_index* ix) {
+  return yf_prepare_tables_rounding(weights_blob, blob_bytes, YF_ROUND_TFLITE_REF, out_blob, ix);
+}
+
+int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, int rounding, uint8_t** out_blob, yf_table_index* ix) {
   if (!weights_blob || blob_bytes < YF_WEIGHTS_BLOB_BYTES || !out_blob || !ix) return YF_PREP_ERR_ARGS;
+  if (rounding < 0 || rounding >= YF_ROUND_COUNT) return YF_PREP_ERR_ARGS;
+  const int fd = form_dense(rounding), fo = form_other(rounding);      /* dense CONV_2D | DEPTHWISE_CONV_2D, LEAKY_RELU, ADD, QUANTIZE */
   memset(ix, 0, sizeof *ix);
   blob_t b = {0, 0, 0};
   int rc = 0;
@@ -184,7 +222,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
       } else {
         memcpy(row, w + (size_t)ch * kk, (size_t)kk);
       }
-      rc = build_chan(d, weights_blob, ch, sum_w, abs_w, (yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3);
+      rc = build_chan(d, weights_blob, ch, sum_w, abs_w, (yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3, fd);
       if (rc) break;
     }
   }
@@ -214,7 +252,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
           sum_w += wv; abs_w += wv < 0 ? -wv : wv;
           wd[t * 4 + j] = ((uint32_t)(uint8_t)wv) << (8 * j);      /* byte j of the tap's dword carries channel j */
         }
-        rc = build_chan(d, weights_blob, ch, sum_w, abs_w, cc, j);
+        rc = build_chan(d, weights_blob, ch, sum_w, abs_w, cc, j, fo);
         if (rc) break;
       }
       if (rc) break;
@@ -237,8 +275,7 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     a->kco = ((int32_t)1 << (a->rso - 1)) + a->zpo * ((int32_t)1 << a->rso);
     if (!rc && a->rso > 20) rc = YF_PREP_ERR_SHIFT_RANGE;
     a->mo2 = (uint32_t)a->mo << 1;
-    a->zro = (uint32_t)(a->zpo + 128) << a->rso;
-    if (!rc) build_c64(-(long long)YF_ACC_OFFSET, a->mo, a->rso, a->c64o);
+    if (!rc) build_c64(-(long long)YF_ACC_OFFSET, a->mo, a->rso, fo, a->zpo + 128, a->c64o, &a->zro);
   }
 
   /* ---------------- LUTs ---------------- */
@@ -249,8 +286,8 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
     for (int s = 0; s < YF_N_ADD; ++s) {
       const yf_add* a = &ix->add[s];
       for (int q = -128; q < 128; ++q) {
-        AL[(s * 2 + 0) * 256 + q + 128] = yf_mbqm((q - a->zp1) * (1 << 20), a->m1, a->s1);
-        AL[(s * 2 + 1) * 256 + q + 128] = yf_mbqm((q - a->zp2) * (1 << 20), a->m2, a->s2) + YF_ACC_OFFSET;   /* |sa + sb| < 2^29 */
+        AL[(s * 2 + 0) * 256 + q + 128] = yf_mbqm_form((q - a->zp1) * (1 << 20), a->m1, a->s1, fo);
+        AL[(s * 2 + 1) * 256 + q + 128] = yf_mbqm_form((q - a->zp2) * (1 << 20), a->m2, a->s2, fo) + YF_ACC_OFFSET;   /* |sa + sb| < 2^29 */
       }
     }
     static const int leaky[][3] = {       /* lut id, tensor in, tensor out (tflite LEAKY_RELU ops) */
@@ -260,16 +297,16 @@ int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** 
       {YF_L_LEAKY39, 87, 88}, {YF_L_LEAKY48, 94, 95}, {YF_L_LEAKY50, 96, 97}, {YF_L_LEAKY52, 98, 99},
     };
     for (unsigned i = 0; i < sizeof leaky / sizeof leaky[0]; ++i)
-      build_leaky_lut(leaky[i][1], leaky[i][2], L + 256 * leaky[i][0]);
+      build_leaky_lut(leaky[i][1], leaky[i][2], L + 256 * leaky[i][0], fo);
     /* the two pool LUTs are RAW-indexed (index = the int8 bit pattern, not q + 128): the pooling code extracts bytes
      * straight out of its packed maxima */
     uint8_t q21[256], q45[256];
-    build_requant_lut(58, 103, q21);                         /* QUANTIZE #21: pool_8 branch of concat_22 */
-    build_requant_lut(74, 101, q45);                         /* QUANTIZE #45: pool_25 branch of concat_46 */
+    build_requant_lut(58, 103, q21, fo);                         /* QUANTIZE #21: pool_8 branch of concat_22 */
+    build_requant_lut(74, 101, q45, fo);                         /* QUANTIZE #45: pool_25 branch of concat_46 */
     for (int i = 0; i < 256; ++i) { L[256 * YF_L_Q21 + i] = q21[i ^ 128]; L[256 * YF_L_Q45 + i] = q45[i ^ 128]; }
     uint8_t l43[256], q44[256];
-    build_leaky_lut(91, 92, l43);                            /* LEAKY_RELU #43 */
-    build_requant_lut(92, 102, q44);                         /* QUANTIZE #44 */
+    build_leaky_lut(91, 92, l43, fo);                            /* LEAKY_RELU #43 */
+    build_requant_lut(92, 102, q44, fo);                         /* QUANTIZE #44 */
     for (int i = 0; i < 256; ++i) L[256 * YF_L_L43Q44 + i] = q44[(int)(int8_t)l43[i] + 128];
     memcpy(L + YF_N_LUT * 256 + YF_ADDLUT_BYTES, l43, 256);   /* LEAKY_RELU #43 alone: the debug builds' per-node dump (tensor 92 is never materialised otherwise) */
   }

@@ -18,7 +18,10 @@
 //     handles -- hipStreamQuery / hipEventRecord on a destroyed stream is a segmentation fault (tools/probe/dead_stream_probe.py).  Every HIP call here
 //     takes the CALLER's stream, or an event.  A dirty region whose stream never launches again therefore stays dirty (nothing can name its launches)
 //     until release_stream(), or until every other region is busy and the device is synchronised (the all-busy path);
-//   - at most max_regions regions exist; when all are busy on other streams the caller waits for the one marked longest ago;
+//   - at most max_regions regions exist; when all are busy on other streams the caller waits for the one marked longest ago -- or, when
+//     only dirty regions are left, for the DEVICE (counted: stats().device_syncs, so a host can see when it pays that), or, when every region
+//     is between another thread's get() and mark(), for one of those marks (a condition variable; round 5 failed that launch with
+//     hipErrorNotReady, reachable with more host threads than regions);
 //   - release_stream() gives a stream's region back at once (yf_network_release_stream);
 //   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread), and such a region always
 //     records its event.
@@ -29,6 +32,7 @@
 #ifndef YF_STREAM_SCRATCH_H
 #define YF_STREAM_SCRATCH_H
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -39,9 +43,14 @@ struct yf_stream_scratch {
   // dirty: launched on without an event; acquired: handed out by get(), its launch not yet marked
   struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired; };
   std::mutex mu;
+  std::condition_variable cv_marked;               // a mark() or release: somebody waiting in get() for a region that is not acquired may look again
   std::vector<Region> regions;
   unsigned long long clock = 0;
-  unsigned long long events_recorded = 0, events_skipped = 0;     // diagnostics (tests)
+  // diagnostics (yf_network_scratch_stats; tests): events recorded / skipped by mark(); on the all-busy path of get(): waits for the oldest
+  // region's event, device synchronisations (only dirty regions left), waits for another thread's mark() (every region acquired)
+  unsigned long long events_recorded = 0, events_skipped = 0, event_waits = 0, device_syncs = 0, acquire_waits = 0;
+  struct Stats { unsigned long long events_recorded, events_skipped, event_waits, device_syncs, acquire_waits, regions; };
+  Stats stats() { std::lock_guard<std::mutex> lock(mu); return Stats{events_recorded, events_skipped, event_waits, device_syncs, acquire_waits, regions.size()}; }
 
   // What get() hands out: the region's bytes, and the duty to mark it.  Movable, not copyable.
   struct Lease {
@@ -62,10 +71,14 @@ struct yf_stream_scratch {
   static bool idle(const Region& r) { return !r.acquired && !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
   // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls lease.mark().
   hipError_t get(hipStream_t s, size_t bytes, Lease* lease) {
-    std::lock_guard<std::mutex> lock(mu);
+    if (!lease || lease->owner) return hipErrorInvalidValue;                          // a lease that is still live is marked by its holder, not overwritten here (its settle() takes mu)
+    std::unique_lock<std::mutex> lock(mu);
     const size_t tk = thread_key(s);
     Region* r = find(s, tk);
-    if (!r) {
+    while (r && r->acquired) {                                                        // another thread is between get() and mark() on this very stream: its turn first
+      ++acquire_waits; cv_marked.wait(lock); r = find(s, tk);
+    }
+    while (!r) {
       for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
       if (!r && regions.size() < max_regions) {
         Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false};
@@ -77,11 +90,11 @@ struct yf_stream_scratch {
       if (!r) {                                                                       // all busy on other streams: wait for the one marked longest ago
         for (Region& c : regions) if (!c.dirty && !c.acquired && (!r || c.stamp < r->stamp)) r = &c;
         hipError_t rc;
-        if (r) rc = hipEventSynchronize(r->done);
+        if (r) { ++event_waits; rc = hipEventSynchronize(r->done); }
         else {                                                                        // only dirty regions left (nothing names their launches): wait for the device
           for (Region& c : regions) if (!c.acquired) { r = &c; break; }
-          if (!r) return hipErrorNotReady;                                            // every region is between get() and mark() on another thread
-          rc = hipDeviceSynchronize();
+          if (!r) { ++acquire_waits; cv_marked.wait(lock); continue; }                // every region is between get() and mark() on another thread: wait for a mark, look again
+          ++device_syncs; rc = hipDeviceSynchronize();
         }
         if (rc != hipSuccess) return rc;
       }
@@ -96,7 +109,6 @@ struct yf_stream_scratch {
     }
     r->stamp = ++clock;
     r->acquired = true;                                                               // not idle between get() and mark(), whoever asks
-    *lease = Lease();
     lease->owner = this; lease->stream = s; lease->ptr = r->ptr;
     return hipSuccess;
   }
@@ -107,6 +119,7 @@ struct yf_stream_scratch {
     Region* r = find(s, tk);
     if (!r) return hipSuccess;
     r->acquired = false;
+    cv_marked.notify_all();
     bool alone = tk == 0;                                                             // nobody else in sight: no event between this stream's kernels
     for (const Region& c : regions) if (&c != r && !idle(c)) { alone = false; break; }
     if (alone) { r->marked = false; r->dirty = true; ++events_skipped; return hipSuccess; }      // dirty outranks whatever an older event says: never idle until named
@@ -124,6 +137,7 @@ struct yf_stream_scratch {
       if (r.ptr) (void)hipFree(r.ptr);                                                // (hipFree waits for the device: a dirty region's launches are through)
       (void)hipEventDestroy(r.done);
       regions.erase(regions.begin() + (long)i);
+      cv_marked.notify_all();
       return hipSuccess;
     }
     return hipSuccess;

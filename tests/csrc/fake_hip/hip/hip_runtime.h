@@ -5,14 +5,15 @@
  * (tools/probe/dead_stream_probe.py) -- so the map under test must never do it. */
 #ifndef FAKE_HIP_RUNTIME_H
 #define FAKE_HIP_RUNTIME_H
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
 #include <vector>
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorInvalidHandle = 400, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorInvalidHandle = 400, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 enum { hipEventDisableTiming = 2 };
-struct fake_stream { long enqueued = 0, completed = 0; void enqueue() { ++enqueued; } void drain() { completed = enqueued; } };
+struct fake_stream { std::atomic<long> enqueued{0}, completed{0}; void enqueue() { ++enqueued; } void drain() { completed = enqueued.load(); } };   /* atomic: the threaded cases drain their own streams while the map drains all */
 struct fake_event { fake_stream* on = nullptr; long at = 0; };
 typedef fake_stream* hipStream_t;
 typedef fake_event* hipEvent_t;
@@ -36,7 +37,7 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   e->on = s; e->at = s->enqueued; return hipSuccess;
 }
 inline hipError_t hipEventQuery(hipEvent_t e) { return (!e->on || e->on->completed >= e->at) ? hipSuccess : hipErrorNotReady; }
-inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e->on && e->on->completed < e->at) e->on->completed = e->at; return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e->on && e->on->completed < e->at) e->on->completed = (long)e->at; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { ++fake_hip::device_syncs(); fake_hip::drain_all(); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { if (fake_hip::fail_mallocs() > 0) { --fake_hip::fail_mallocs(); return hipErrorOutOfMemory; } *p = std::malloc(n); ++fake_hip::mallocs(); return hipSuccess; }

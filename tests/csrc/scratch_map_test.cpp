@@ -2,9 +2,13 @@
 // the paths a GPU test cannot reach deterministically -- a launch that fails between get() and mark(), events skipped while a stream is alone
 // and recorded again when another stream turns up, destroyed streams whose handles must never reach the runtime.  Built and run by tests/test_sanitizers.py.
 #include "yf_stream_scratch.h"
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+#include <thread>
+#include <vector>
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::fflush(stdout); std::exit(1); } } while (0)
 
 static hipError_t good_launch(yf_stream_scratch& m, hipStream_t s, size_t bytes = 1024, char** ptr = nullptr) {
   yf_stream_scratch::Lease l;
@@ -103,6 +107,66 @@ int main() {
     yf_stream_scratch::Lease l;
     CHECK(m.get(a, 4096, &l) == hipErrorOutOfMemory && m.acquired_count() == 0);
     CHECK(good_launch(m, a, 4096) == hipSuccess);
+    m.release();
+  }
+  {   // 7. (round 6, ADVICE) get() into a lease that is still LIVE is refused before the lock is taken: overwriting it would settle() it under
+      //    the map's own mutex -- a self-deadlock on a non-recursive std::mutex.  The live lease stays valid and marks normally.
+    yf_stream_scratch m;
+    hipStream_t a = fake_hip::create(), b = fake_hip::create();
+    yf_stream_scratch::Lease l;
+    CHECK(m.get(a, 1024, &l) == hipSuccess && m.acquired_count() == 1);
+    CHECK(m.get(b, 1024, &l) == hipErrorInvalidValue);                         // round 5: never returned
+    CHECK(m.get(a, 1024, nullptr) == hipErrorInvalidValue);
+    CHECK(m.acquired_count() == 1 && l.ptr != nullptr);
+    a->enqueue();
+    CHECK(l.mark() == hipSuccess && m.acquired_count() == 0);
+    CHECK(m.get(b, 1024, &l) == hipSuccess);                                   // a marked lease may be filled again
+    CHECK(l.mark() == hipSuccess);
+    m.release();
+  }
+  {   // 8. (round 6, ADVICE) more host threads than regions, every region between another thread's get() and mark(): the extra thread WAITS for a
+      //    mark and then launches (round 5: hipErrorNotReady, a failed launch).  Reachable on the 160x160 path: arena160 has four regions and holds
+      //    its lease across the whole chunk loop.
+    yf_stream_scratch m; m.max_regions = 2;
+    hipStream_t s[3];
+    for (auto& x : s) x = fake_hip::create();
+    yf_stream_scratch::Lease l0, l1;
+    CHECK(m.get(s[0], 1024, &l0) == hipSuccess && m.get(s[1], 1024, &l1) == hipSuccess && m.acquired_count() == 2);
+    std::atomic<int> state{0};
+    hipError_t rc_third = hipErrorUnknown;
+    std::thread third([&] { state = 1; rc_third = good_launch(m, s[2]); state = 2; });
+    while (state.load() == 0) std::this_thread::yield();
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    CHECK(state.load() == 1);                                                  // still waiting: nothing has been marked
+    s[0]->enqueue();
+    CHECK(l0.mark() == hipSuccess);                                            // wakes the waiter; s[0]'s region is dirty (it was alone), so the waiter...
+    s[1]->enqueue();
+    CHECK(l1.mark() == hipSuccess);                                            // ...gets a region through an event wait or the device
+    third.join();                                                              // (nothing is drained before: the waiter has to wait for an event, the fake completes it)
+    s[0]->drain(); s[1]->drain();
+    CHECK(rc_third == hipSuccess && m.count() == 2 && m.acquired_count() == 0);
+    const yf_stream_scratch::Stats st = m.stats();
+    CHECK(st.acquire_waits >= 1 && st.regions == 2);
+    CHECK(st.event_waits + st.device_syncs >= 1);                              // what the third stream paid is visible to the host
+    // six threads, four launches each, on two regions: everybody gets through
+    std::vector<std::thread> pool;
+    std::atomic<int> failures{0};
+    hipStream_t t[6];
+    for (auto& x : t) x = fake_hip::create();
+    for (int i = 0; i < 6; ++i) pool.emplace_back([&, i] { for (int k = 0; k < 4; ++k) { if (good_launch(m, t[i]) != hipSuccess) ++failures; t[i]->drain(); } });
+    for (auto& th : pool) th.join();
+    CHECK(failures.load() == 0 && m.count() == 2 && m.acquired_count() == 0);
+    m.release();
+  }
+  {   // 9. the counters a host reads through yf_network_scratch_stats: a lone stream skips its events, company makes both record
+    yf_stream_scratch m;
+    hipStream_t a = fake_hip::create(), b = fake_hip::create();
+    for (int i = 0; i < 5; ++i) CHECK(good_launch(m, a) == hipSuccess);
+    yf_stream_scratch::Stats st = m.stats();
+    CHECK(st.events_skipped == 5 && st.events_recorded == 0 && st.device_syncs == 0 && st.event_waits == 0 && st.acquire_waits == 0 && st.regions == 1);
+    CHECK(good_launch(m, b) == hipSuccess);
+    st = m.stats();
+    CHECK(st.events_recorded == 1 && st.regions == 2);
     m.release();
   }
   fake_hip::free_all();

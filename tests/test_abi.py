@@ -161,28 +161,47 @@ def test_repeated_init_without_gpu_does_not_grow(yf):
 
 
 def test_load_without_a_build_tool_checks_the_build_id():
-    """binding.load() on a box without make / hipcc: an existing library is loaded if its baked-in build id equals the id computed
-    from the sources and flags (binding.expected_build_id), and refused otherwise."""
+    """binding.load() decides without a child process whether the in-tree library is current (stamped ids == the ids of the sources as they stand,
+    library newer than every source) and then loads it without running make -- under rocprofv3 every child of the process would be instrumented;
+    YF_NO_BUILD=1 forces that path.  When it does have to build and the box has no make / hipcc, an existing library is loaded with a warning.
+    In every case the ids baked into the library are compared with the ids computed from the sources, and another build is refused."""
     import subprocess
     import sys
     code = (
-        "import importlib, os, sys, warnings\n"
+        "import importlib, os, sys, warnings, subprocess\n"
         "os.environ['PATH'] = '/nonexistent'\n"
         "b = importlib.import_module('stm32h7-yolo_amd.binding')\n"
-        "if sys.argv[1] == 'bad': b.expected_build_id = lambda *a: '0' * 16\n"
+        "mode = sys.argv[1]\n"
+        "if 'bad' in mode: b.expected_build_id = lambda *a: '0' * 16\n"
+        "if 'stale' in mode: b.library_is_current = lambda: False\n"
+        "calls = []\n"
+        "real = subprocess.check_call\n"
+        "def spy(*a, **k): calls.append(a); return real(*a, **k)\n"
+        "subprocess.check_call = spy\n"
         "with warnings.catch_warnings(record=True) as w:\n"
         "    warnings.simplefilter('always')\n"
         "    try:\n"
         "        lib = b.load()\n"
-        "        print('LOADED', sum('could not run the build' in str(x.message) for x in w), lib.yf_network_build_id().decode() == b.expected_build_id())\n"
+        "        print('LOADED', len(calls), sum('could not run the build' in str(x.message) for x in w), lib.yf_network_build_id().decode() == b.expected_build_id())\n"
         "    except RuntimeError as e:\n"
-        "        print('REFUSED', 'build id' in str(e))\n")
+        "        print('REFUSED', len(calls), 'build id' in str(e))\n")
     env = dict(os.environ)
     env.pop("YF_LIB_PATH", None)
-    ok = subprocess.run([sys.executable, "-c", code, "good"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert ok.stdout.strip() == "LOADED 1 True", ok.stdout + ok.stderr
-    bad = subprocess.run([sys.executable, "-c", code, "bad"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert bad.stdout.strip() == "REFUSED True", bad.stdout + bad.stderr
+    env.pop("YF_NO_BUILD", None)
+
+    def run(mode, **extra):
+        r = subprocess.run([sys.executable, "-c", code, mode], cwd=ROOT, env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        return r.stdout.strip(), r.stdout + r.stderr
+    out, log = run("good")
+    assert out == "LOADED 0 0 True", log                    # current library: no make, no child process at all
+    out, log = run("stale")
+    assert out == "LOADED 1 1 True", log                    # has to build, cannot (no make on PATH): warns, checks the ids, loads
+    out, log = run("stale-bad")
+    assert out == "REFUSED 1 True", log
+    out, log = run("stale", YF_NO_BUILD="1")
+    assert out == "LOADED 0 0 True", log                    # YF_NO_BUILD=1: never starts make ...
+    out, log = run("stale-bad", YF_NO_BUILD="1")
+    assert out == "REFUSED 0 True", log                     # ... and refuses a library built from other sources
 
 
 def test_handle_and_param_validation(yf):

@@ -255,6 +255,94 @@ def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), a[perm])                # frames are independent
 
 
+# library rounding -> the oracle variant that states it (oracle/yf_oracle.h YFO_RV_*)
+ROUNDING_TO_VARIANT = {0: 0, 1: 1, 2: 2, 3: 4}
+
+
+@pytest.mark.parametrize("rounding", [1, 2, 3])
+def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, oracle, golden, torch_cuda, rounding):
+    """yf_network_set_requant_rounding (round 6): the SAME kernels with the constants of another published rounding of TFLite's requantisation
+    -- ties upward on the dense convs (ruy, what tflite_prediction.py:23's default resolver most likely runs), ties upward everywhere, single
+    rounding on the dense convs -- bit-exact against the oracle's statement of that variant: the six golden frames, the reference's 27 sample
+    images, 4096 seeded frames (BASELINE configs[1]'s input) with the fused decode, every fused stage through the dump build, a 160x160 block,
+    ai_network_run on host arrays.  Switching back restores the reference rounding bit for bit."""
+    torch = torch_cuda
+    variant = ROUNDING_TO_VARIANT[rounding]
+    real = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    x = rnd(1, 4096)
+    x[:6] = golden["inputs"]
+    x[6:33] = real
+    ref0 = oracle.run(x, threads=16)
+    want, want_dump = oracle.run(x, threads=16, variant=variant), None
+    assert not np.array_equal(want, ref0)
+    assert network.requant_rounding == 0
+    try:
+        network.set_requant_rounding(rounding)
+        assert network.requant_rounding == rounding
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros((4096, 7, 7, 18), dtype=torch.int8, device="cuda")
+        cap = 4
+        d_d = torch.zeros((4096, cap, 28), dtype=torch.uint8, device="cuda")
+        d_c = torch.zeros((4096,), dtype=torch.int32, device="cuda")
+        network.run_decode_device(d_in.data_ptr(), d_out.data_ptr(), 4096, d_d.data_ptr(), d_c.data_ptr(), cap, 0)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got, want)
+        counts, buf = d_c.cpu().numpy(), d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(4096, cap)
+        for f in list(range(40)) + list(np.nonzero(counts)[0][:200]):
+            py = oracle.decode_py(want[f], f)
+            assert counts[f] == len(py)
+            assert [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in buf[f, :min(cap, counts[f])]] == \
+                   [(d[1], d[2], d[3], d[6], d[7], d[8], d[9]) for d in py][:cap]
+        # small batches (one frame per workgroup), the host path, and every fused stage through the dump build
+        assert np.array_equal(network.run(x[:33]), want[:33])
+        from oracle.np_restatement import load_yfm
+        m = load_yfm(os.path.join(ROOT, "oracle", "model", "yoloface_int8.yfm"))
+        sizes = [int(np.prod(m["tensors"][o["out"]]["shape"][1:])) for o in m["ops"]]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        _, dump_ref = oracle.run(x[4:9], dump=True, variant=variant)
+        d_dump = torch.zeros((5, network.dump_bytes()), dtype=torch.int8, device="cuda")
+        network.run_device(d_in[4:9].data_ptr(), d_out.data_ptr(), 5, None, d_dump.data_ptr())
+        torch.cuda.synchronize()
+        dump, off = d_dump.cpu().numpy(), 0
+        for name, op in STAGES:
+            assert np.array_equal(dump[:, off:off + sizes[op]], dump_ref[:, offs[op]:offs[op] + sizes[op]]), f"stage {name} (tflite op {op})"
+            off += sizes[op]
+        # 160x160: the banded kernels read the same tables
+        block = np.random.default_rng(4).integers(-128, 128, (3, 160, 160, 3), dtype=np.int8)
+        d_b = torch.from_numpy(block).cuda()
+        d_o = torch.zeros((3, 20, 20, 18), dtype=torch.int8, device="cuda")
+        network.run_device_hw(160, 160, d_b.data_ptr(), d_o.data_ptr(), 3)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), oracle.run(block, threads=3, variant=variant))
+        with pytest.raises(Exception):
+            network.set_requant_rounding(7)
+        assert network.get_error()[0] == 0x14 and network.requant_rounding == rounding      # AI_ERROR_INVALID_PARAM, nothing changed
+    finally:
+        network.set_requant_rounding(0)
+    network.run_device(d_in.data_ptr(), d_out.data_ptr(), 4096)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), ref0)
+
+
+def test_requant_rounding_from_the_environment_steers_an_unmodified_caller(oracle, golden):
+    """YF_REQUANT_ROUNDING is read by ai_network_create: a caller that cannot be modified (the reference's aiInit: create + init back to back,
+    yoloface.c:188-211) runs with another rounding; an unknown word fails ai_network_init loudly.  Fresh processes (the variable is read at create)."""
+    import sys
+    code = ("import sys, importlib, numpy as np\nsys.path.insert(0, %r)\nyf = importlib.import_module('stm32h7-yolo_amd')\n"
+            "x = np.fromfile(%r, np.int8).reshape(-1, 56, 56, 3)\n"
+            "try:\n    net = yf.Network(device=0).init()\nexcept Exception as e:\n    print('INIT FAILED', e); sys.exit(3)\n"
+            "print(net.requant_rounding); sys.stdout.flush(); sys.stdout.buffer.write(net.run(x).tobytes())\n") % (ROOT, os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"))
+    for word, variant in (("ties_up", 1), ("ref", 0)):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=dict(os.environ, YF_REQUANT_ROUNDING=word))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        head, _, raw = r.stdout.partition(b"\n")
+        assert int(head) == {"ties_up": 1, "ref": 0}[word]
+        assert np.array_equal(np.frombuffer(raw, np.int8).reshape(-1, 7, 7, 18), oracle.run(golden["inputs"], variant=variant))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=dict(os.environ, YF_REQUANT_ROUNDING="nearest"))
+    assert r.returncode == 3 and b"YF_REQUANT_ROUNDING" in r.stdout
+
+
 @pytest.mark.parametrize("shape", [(2, 8), (1, 8)])
 def test_tail_pairing_patterns(network, oracle, torch_cuda, shape):
     """Tail batching runs the 7x7 stages once per PAIR of a workgroup's frame groups.  Batch sizes around the multiples of the

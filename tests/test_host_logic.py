@@ -309,12 +309,129 @@ def test_add_tables(prep, oracle, pack):
             assert _device_requant(sa + sb, a.mo, a.rso, a.zro, a.c64o[0] | (a.c64o[1] << 32)) == ref + 128
 
 
+# ---- selectable rounding (round 6): library rounding -> (oracle variant, oracle mbqm mode of dense convs, of everything else)
+ROUNDINGS = {1: ("ties_up", 1, 1, 0), 2: ("ties_up_all", 2, 1, 1), 3: ("single", 4, 2, 0)}
+
+
+def _prep_rounding(prep, rounding):
+    lib = prep["lib"]
+    lib.yf_prepare_tables_rounding.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Index)]
+    blob = (ctypes.c_uint8 * 11304).in_dll(lib, "yf_weights_blob")
+    out, ix = ctypes.c_void_p(), Index()
+    assert lib.yf_prepare_tables_rounding(blob, 11304, rounding, ctypes.byref(out), ctypes.byref(ix)) == 0
+    return ix, bytes((ctypes.c_uint8 * ix.total_bytes).from_address(out.value))
+
+
+def _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, zp_out, abs_w, rng, mode):
+    """the kernel's four instructions with a non-reference rounding's constants == the oracle's statement of that rounding + zp_out + 128, on
+    random accumulators and on both signs of every kind of tie; the multiply-add must never carry out (its carry is TFLite's sign term in the
+    reference form and has to stay 0 in the others)"""
+    lim = 255 * abs_w
+    dots = np.concatenate([rng.integers(-lim, lim + 1, 200), [0, 1, -1, lim, -lim, -bias2, -bias2 - 1, -bias2 + 1]])
+    half = 1 << (rs - 1)
+    for k in (-40, -3, -2, -1, 0, 1, 2, 40):
+        target = k * (1 << rs) + half
+        a = int(round(target * 2.0**31 / mult))
+        dots = np.concatenate([dots, [a - bias2 + d for d in (-2, -1, 0, 1, 2)], [-a - bias2 + d for d in (-2, -1, 0, 1, 2)]])
+    assert zr == (((zp_out + 128) << rs) - (1 << 31)) % (1 << 32)
+    for dot in dots:
+        dot = int(dot)
+        acc_p = O + dot
+        n = acc_p * (2 * mult) + c64
+        assert 0 < acc_p < (1 << 32) and (1 << 61) <= n < (1 << 64), "no carry-out"
+        assert _device_requant(dot, mult, rs, zr, c64) == oracle.lib.yfo_mbqm_mode(dot + bias2, mult, -rs, mode) + zp_out + 128, (dot, bias2, mult, rs, mode)
+
+
+@pytest.mark.parametrize("rounding", sorted(ROUNDINGS))
+def test_rounding_modes_are_other_constants_in_the_same_layout(prep, oracle, pack, rounding):
+    """yf_network_set_requant_rounding: every rounding is a table blob of the SAME layout (the kernels address it at compiled-in offsets) whose
+    weights are the reference blob's, and whose {C64, ZR} per channel, byte LUTs and add tables state the rounding the oracle's variant states:
+    dense convs by the variant's dense form, depthwise convs / LEAKY_RELU / QUANTIZE / ADD by its form for everything else."""
+    name, variant, m_dense, m_other = ROUNDINGS[rounding]
+    ix, tab = _prep_rounding(prep, rounding)
+    ix0, tab0 = prep["ix"], prep["tab"]
+    skip = Index.add.offset, Index.add.offset + Index.add.size                     # the add records carry rounding-dependent constants (checked below)
+    assert bytes(ix)[:skip[0]] == bytes(ix0)[:skip[0]] and bytes(ix)[skip[1]:] == bytes(ix0)[skip[1]:] and len(tab) == len(tab0)
+    T, ops = pack["tensors"], pack["ops"]
+    rng = np.random.default_rng(60 + rounding)
+    n_changed = 0
+    for s, op in enumerate(DENSE_OPS):
+        o, d = ops[op], ix.dense[s]
+        t_in = o["ins"][0] if op != 1 else 0
+        wt, bt, to = T[o["ins"][1]], T[o["ins"][2]], T[o["out"]]
+        w = wt["data"].reshape(wt["shape"]).astype(np.int64)
+        assert tab[d.w_off:d.w_off + d.cout_pad4 * d.krow] == tab0[d.w_off:d.w_off + d.cout_pad4 * d.krow]
+        for ch in range(wt["shape"][0]):
+            mult, rs, zr, c64 = _chan(tab, d.c_off, ch)
+            assert (mult, rs) == _chan(tab0, d.c_off, ch)[:2]
+            wf = w[ch].reshape(-1)
+            bias2 = int(bt["data"][ch]) - T[t_in]["zp"] * int(wf.sum())
+            if m_dense == 1:
+                assert c64 == ((bias2 - O) * 2 * mult + (1 << 31) + ((1 << (rs - 1)) << 32) + (1 << 63)) % (1 << 64)
+            else:
+                assert c64 == ((bias2 - O) * 2 * mult + (1 << (31 + rs)) + (1 << 63)) % (1 << 64)
+            _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(wf).sum()), rng, m_dense)
+            n_changed += 1
+    for s, op in enumerate(DW_OPS):
+        o, d = ops[op], ix.dw[s]
+        t_in = ops[op - 1]["ins"][0] if ops[op - 1]["op"] == 34 else o["ins"][0]
+        wt, bt, to = T[o["ins"][1]], T[o["ins"][2]], T[o["out"]]
+        w = wt["data"].reshape(wt["shape"]).astype(np.int64)
+        c = wt["shape"][3]
+        for g in range(d.ngroups):
+            base = d.g_off + g * (36 * 4 + 80)
+            assert tab[base:base + 144] == tab0[base:base + 144]
+            for j in range(4):
+                ch = g * 4 + j
+                if ch >= c:
+                    continue
+                mult, rs, zr, c64 = _chan(tab, base + 144, j)
+                taps = w[0].reshape(9, c)[:, ch]
+                bias2 = int(bt["data"][ch]) - T[t_in]["zp"] * int(taps.sum())
+                if m_other == 0:
+                    assert (mult, rs, zr, c64) == _chan(tab0, base + 144, j)            # untouched by a dense-only rounding
+                else:
+                    _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(taps).sum()), rng, m_other)
+    assert n_changed == 338                                                        # dense output channels (206 depthwise: 544 in all)
+    # byte LUTs: the oracle's tables for the variant; a dense-only rounding leaves all 19 and the add tables as they were
+    lut = np.frombuffer(tab, np.int8, N_LUT * 256, ix.lut_off).reshape(N_LUT, 256)
+    for op, lid in LEAKY_LUT_IDS.items():
+        assert np.array_equal(lut[lid], oracle.leaky_lut(op, variant)), f"LEAKY_RELU #{op}"
+    a0 = ix.lut_off + N_LUT * 256
+    if m_other == 0:
+        assert tab[ix.lut_off:a0 + 3 * 2048 + 256] == tab0[ix.lut_off:a0 + 3 * 2048 + 256]
+        assert bytes(ix.add) == bytes(ix0.add)
+        return
+    assert not np.array_equal(lut, np.frombuffer(tab0, np.int8, N_LUT * 256, ix.lut_off).reshape(N_LUT, 256))
+
+    def requant(t_in, t_out):
+        m, sh = ctypes.c_int32(), ctypes.c_int()
+        oracle.lib.yfo_quantize_multiplier(float(np.float32(T[t_in]["scale"][0])) / float(np.float32(T[t_out]["scale"][0])), ctypes.byref(m), ctypes.byref(sh))
+        return np.array([np.clip(oracle.lib.yfo_mbqm_mode(q - T[t_in]["zp"], m.value, sh.value, m_other) + T[t_out]["zp"], -128, 127) for q in range(-128, 128)], np.int8)
+    assert np.array_equal(np.roll(lut[3], 128), requant(58, 103)) and np.array_equal(np.roll(lut[9], 128), requant(74, 101))
+    assert np.array_equal(lut[15], requant(92, 102)[oracle.leaky_lut(43, variant).astype(int) + 128])
+    al = np.frombuffer(tab, "<i4", 3 * 512, a0).reshape(3, 2, 256)
+    for s in range(3):
+        a = ix.add[s]
+        for q1, q2 in np.concatenate([np.random.default_rng(70 + s).integers(-128, 128, (300, 2)), [[-128, -128], [127, 127], [-128, 127]]]):
+            q1, q2 = int(q1), int(q2)
+            sa = oracle.lib.yfo_mbqm_mode((q1 - a.zp1) * (1 << 20), a.m1, a.s1, m_other)
+            sb = oracle.lib.yfo_mbqm_mode((q2 - a.zp2) * (1 << 20), a.m2, a.s2, m_other)
+            assert (al[s, 0, q1 + 128], al[s, 1, q2 + 128]) == (sa, sb + O)
+            ref = oracle.lib.yfo_mbqm_mode(sa + sb, a.mo, a.so, m_other) + a.zpo
+            assert _device_requant(sa + sb, a.mo, a.rso, a.zro, a.c64o[0] | (a.c64o[1] << 32)) == ref + 128
+
+
 def test_prepare_rejects_bad_arguments(prep):
     lib = prep["lib"]
     out, ix = ctypes.c_void_p(), Index()
     small = (ctypes.c_uint8 * 100)()
     assert lib.yf_prepare_tables(small, 100, ctypes.byref(out), ctypes.byref(ix)) == 1
     assert lib.yf_prepare_tables(None, 11304, ctypes.byref(out), ctypes.byref(ix)) == 1
+    lib.yf_prepare_tables_rounding.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Index)]
+    blob = (ctypes.c_uint8 * 11304).in_dll(lib, "yf_weights_blob")
+    for bad in (-1, 4, 99):
+        assert lib.yf_prepare_tables_rounding(blob, 11304, bad, ctypes.byref(out), ctypes.byref(ix)) == 1
 
 
 def test_fp16_prefetch_wait_count_matches_the_isa(tmp_path):

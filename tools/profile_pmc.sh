@@ -7,6 +7,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export YF_NO_BUILD=1     # binding.load() starts no child process under the profiler (no make / sh / sha256sum instrumented by the tool); a library that is not current is refused
 TRACE_ARGS="--no-secondary $*"        # kernel trace: the default bench command (400 steps after 100 warm-up), headline kernel only
 ARGS="--steps 20 --warmup 5 --no-secondary $*"   # counter passes: per-launch counts do not depend on the clock state
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $TRACE_ARGS > $OUT/bench_line.json 2> $OUT/trace.err

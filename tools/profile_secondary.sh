@@ -9,6 +9,7 @@ SEC=${1:?section}; TAG=${2:-run}
 OUT=$PWD/gpurun_out/prof_sec/$SEC/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+export YF_NO_BUILD=1     # binding.load() starts no child process under the profiler (no make / sh / sha256sum instrumented by the tool); a library that is not current is refused
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --only-secondary $SEC > $OUT/bench_line.json 2> $OUT/trace.err
 echo "trace rc=$?"
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
