@@ -98,29 +98,38 @@ def cpu_model():
 
 
 def cpu_baseline(x, got_heads):
-    """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames, 3 repetitions (~20 s of CPU work);
-    also the in-bench parity check of the GPU result.  `value` is the MEDIAN of the repetitions; the best is reported beside
-    it, with what the box has: the cores this process may run on, the CPU model, the threads actually used."""
+    """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames -- about 2 s of CPU work in all;
+    also the in-bench parity check of the GPU result.  Three figures, each the MEDIAN of 3 repetitions ("(i) single thread and
+    (ii) all cores"), each with its thread count:
+      value / cores                 16 threads: the CPU share of a ONE-GPU box of this pool (gpurun: "16 for one GPU"), what rounds 1-5 reported
+      all_cores_images_per_s        one thread per core this process may run on (affinity_cores: 256 on the driver's box) -- north_star's "the GPU
+                                    box's own cores (core count stated)"
+      single_thread_images_per_s    one thread, on 512 of the frames
+    with the CPU model and the box's core count beside them.  Returns (dict, mismatching head bytes, the oracle's heads)."""
     from oracle.oracle import Oracle
     orc = Oracle()
     affinity = len(os.sched_getaffinity(0))
-    cores = min(affinity, 16)                 # a 1-GPU box's CPU share is 16 cores
-    reps, times = 3, []
-    ref = None
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        ref = orc.run(x, threads=cores)
-        times.append(time.perf_counter() - t0)
-    median, best = sorted(times)[reps // 2], min(times)
-    t0 = time.perf_counter()
-    orc.run(x[:512], threads=1)
-    one = 512 / (time.perf_counter() - t0)
+    cores = min(affinity, 16)
+    reps = 3
+
+    def median_rate(frames, threads):
+        times, out = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = orc.run(frames, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return frames.shape[0] / sorted(times)[reps // 2], frames.shape[0] / min(times), out
+    rate, best, ref = median_rate(x, cores)
+    all_rate, all_best, _ = median_rate(x, affinity) if affinity != cores else (rate, best, None)
+    one, _, _ = median_rate(x[:512], 1)
     mism = int((ref != got_heads).sum())
-    return dict(value=round(x.shape[0] / median, 1), unit="images/s", cores=cores, kind="port",
-                sample=f"{reps} x {x.shape[0]} frames (the bench batch), median of {reps}, {cores} threads of {affinity} usable "
-                       f"({os.cpu_count()} in the box, {cpu_model()}); best {x.shape[0] / best:.0f} images/s; single thread: {one:.0f} images/s",
-                best_images_per_s=round(x.shape[0] / best, 1), affinity_cores=affinity, box_cores=os.cpu_count(), cpu_model=cpu_model(),
-                single_thread_images_per_s=round(one, 1)), mism
+    return dict(value=round(rate, 1), unit="images/s", cores=cores, kind="port",
+                sample=f"{reps} x {x.shape[0]} frames (the bench batch), median of {reps}, {cores} threads (a one-GPU box's CPU share) of {affinity} usable "
+                       f"({os.cpu_count()} in the box, {cpu_model()}); best {best:.0f} images/s; all {affinity} usable cores: {all_rate:.0f} images/s; "
+                       f"single thread: {one:.0f} images/s",
+                best_images_per_s=round(best, 1), all_cores_images_per_s=round(all_rate, 1), all_cores_threads=affinity,
+                all_cores_best_images_per_s=round(all_best, 1), affinity_cores=affinity, box_cores=os.cpu_count(), cpu_model=cpu_model(),
+                single_thread_images_per_s=round(one, 1)), mism, ref
 
 
 def event_time_ms(stream, fn, iters):
@@ -288,6 +297,9 @@ def main():
     ap.add_argument("--rccl-one-rank", action="store_true",
                     help="N = 1 only: run the N > 1 code path -- process group (backend nccl = RCCL), per-step all-gather, gathered-record checks -- in a "
                          "ONE-rank group: the only way to execute the torch.distributed / RCCL calls of this file on a one-GPU box (RCCL refuses two ranks on one device)")
+    ap.add_argument("--input-batches", type=int, default=N_INPUT_BATCHES, metavar="B",
+                    help=f"distinct input batches the steps rotate through (default {N_INPUT_BATCHES}: 308 MB per rank, more than the 256 MB Infinity Cache, so a "
+                         "launch reads its frames from HBM); a rehearsal with several ranks on ONE GPU lowers it so that the ranks do not generate 2.5 GB")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
@@ -335,7 +347,8 @@ def main():
     assert b - a == n
     golden_in = np.fromfile(os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"), np.int8).reshape(-1, 56, 56, 3)
     xs = []
-    for k in range(N_INPUT_BATCHES):
+    NB = max(1, args.input_batches)
+    for k in range(NB):
         xk = np.random.default_rng([1, rank, k]).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
         if rank == 0 and k == 0:    # golden frames inside the timed batch
             xk[:6] = golden_in
@@ -365,17 +378,20 @@ def main():
 
     step_no = 0
 
-    def step():
+    def step(batch=None, stream_no=None):
+        """one step; `batch` / `stream_no` override the rotation (the check steps behind the timed region, the one-stream steps)"""
         nonlocal step_no
-        k, s = step_no % N_INPUT_BATCHES, streams[step_no % S]
+        k, s = (step_no % NB if batch is None else batch), streams[(step_no if stream_no is None else stream_no) % S]
         step_no += 1
         if not dist_on:                     # nothing to order against: no collective reads the buffers
-            launch(ex.acquire(), k, s)
-            return
+            slot = ex.acquire()
+            launch(slot, k, s)
+            return slot
         with torch.cuda.stream(s):          # the exchange orders itself against the CURRENT stream: make it the step's launch stream
             slot = ex.acquire()             # waits for the gather that last read the slot's buffer
             launch(slot, k, s)
             ex.exchange(slot)               # every rank ends up with every rank's detection records and counts (RCCL over xGMI); one collective per K steps
+        return slot
 
     drain = ex.drain
 
@@ -389,7 +405,7 @@ def main():
 
     def settle_launch():
         nonlocal settle_no
-        launch(Slot0, settle_no % N_INPUT_BATCHES)
+        launch(Slot0, settle_no % NB)
         settle_no += 1
 
     while settled_ms < args.clock_settle_ms:
@@ -423,10 +439,24 @@ def main():
     if dist_on or S > 1:  # the timed region above also holds the collectives / overlaps consecutive launches: time the kernel ALONE -- one stream, same
         kernel_ms = event_time_ms(stream, settle_launch, 100)      # inputs, back to back; with one stream and one rank the timed region is that already
 
-    # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames), then compare
+    # ---- the same K steps on ONE stream, between the same kind of brackets (N = 1 line only): what rounds 1-4 reported as `value`, so that a reader of
+    # the line can separate launch policy (two streams) from kernel progress without profiles/
+    one_stream = None
+    if S > 1 and not dist_on:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(stream_no=0)
+        torch.cuda.synchronize()
+        one_stream = (time.perf_counter() - t1) / args.steps
+
+    # ---- correctness of what was just timed: one more step on batch 0 (the one holding the golden frames) PER LAUNCH STREAM AND EXCHANGE BUFFER -- the
+    # timed region ran on all of them (round 5 checked stream 0 / buffer 0 only) --, every one compared with the oracle below
+    drain()
     step_no = 0
     ex.step_no = 0
-    step()
+    n_check_steps = max(S, ex.n_buf) * ex.K
+    check_slots = [step(batch=0) for _ in range(n_check_steps)]
     drain()
     torch.cuda.synchronize()
     d_dets, d_counts = ex.views(ex.local[0])
@@ -437,6 +467,11 @@ def main():
     orc = Oracle()
     n_chk = n if not dist_on else 256            # at N > 1 every rank checks a slice of ITS shard (the full check is the N = 1 run's)
     problems = []
+    for j, sl in enumerate(check_slots[1:], 1):  # every other (stream, buffer, slot) pair produced what (stream 0, buffer 0, slot 0) produced, bit for bit: heads, records, counts
+        r_j, c_j = ex.views(ex.local[sl.i], 0, sl.k)
+        kept_j = torch.arange(cap, device=dev)[None, :] < d_counts.clamp(max=cap)[:, None]     # (record slots beyond a frame's count are never written: stale bytes)
+        if not (torch.equal(ex.heads(sl), ex.heads(Slot0)) and torch.equal(c_j, d_counts) and torch.equal(r_j[kept_j], d_dets[kept_j])):
+            problems.append(f"rank {rank}: check step {j} (stream {j % S}, buffer {sl.i}, slot {sl.k}) differs from check step 0")
     ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if dist_on else None
     if dist_on and not np.array_equal(heads[:n_chk], ref_heads):
         problems.append(f"rank {rank}: heads differ from the oracle on its first {n_chk} frames")
@@ -455,12 +490,8 @@ def main():
             got = [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in dets[f, :min(cap, counts[f])]]
             if counts[f] != len(want) or got != want[:cap]:
                 problems.append(f"golden frame {f}: detections differ from tests/golden/golden_meta.json")
-    ok_gather = True
+    ok_gather, ranks_sampled = True, []
     if dist_on:   # every rank must hold every rank's records, in rank = frame order
-        ok_gather = ex.check_gathered(Slot0, rank)
-        g_counts = ex.gathered_counts(Slot0)                                          # [n_total]
-        ok_gather = ok_gather and tuple(g_counts.shape) == (n_total,) and bool(torch.equal(g_counts[a:b], d_counts))
-        first_rec = np.nonzero(g_counts.cpu().numpy() > 0)[0]
         if args.compact_records:    # the wire carries cells + logits: decode the sparse heads they stand for with the library's own decode -> the sender's records
             sparse = ex.gathered_sparse_heads(Slot0).contiguous()
             r_dets = torch.zeros((n_total, cap, 28), dtype=torch.uint8, device=dev)
@@ -471,11 +502,14 @@ def main():
             ok_gather = ok_gather and bool(torch.equal(r_counts[a:b], d_counts.clamp(max=cap)))
             ok_gather = ok_gather and bool(torch.equal(r_dets[a:b][kept][:, 4:], d_dets[kept][:, 4:]))        # every field but the (positional) frame index
             g_frames = r_dets[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
-            ok_gather = ok_gather and all(int(g_frames[i]) == int(i) for i in first_rec[:512])                  # rank-major = global frame order
+            frame_of = lambda g: g_frames[g] % n                                       # noqa: E731  (decoded over n_total frames: the index is the global position)
+            ok_gather = ok_gather and all(int(g_frames[g]) == g for g in ex.rank_major_samples(Slot0))
         else:
             g_frames = ex.gathered_records(Slot0)[:, 0, :4].contiguous().view(torch.int32).view(-1).cpu().numpy()
-            # record k of rank r carries its LOCAL frame index: the global order is rank-major
-            ok_gather = ok_gather and all(int(g_frames[i]) == int(i % n) for i in first_rec[:512])
+            frame_of = lambda g: g_frames[g]                                           # noqa: E731  (record k of rank r carries its LOCAL frame index)
+        # this rank's block at its place, all ranks' counts as one array, and the first firing frames of EVERY rank's shard in rank-major order
+        ok_rm, ranks_sampled = ex.gathered_is_rank_major(Slot0, rank, d_counts, frame_of)
+        ok_gather = ok_gather and ok_rm and len(ranks_sampled) == world
         flag = torch.tensor([int(ok_gather and not problems)], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         all_ok = bool(flag.item())
@@ -494,7 +528,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch=4096 int8 YOLO-face 56x56x3 frames per GPU, fused LDS-resident "
                                    "forward + GPU box decode" + exch,
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
-                       "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": N_INPUT_BATCHES, "input_bytes_resident": N_INPUT_BATCHES * n * 9408,
+                       "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": NB, "input_bytes_resident": NB * n * 9408,
+                       "check_steps": n_check_steps,
                        "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
                        "parallelism": f"batch-shard x{world}, all-gather of detections" if dist_on else "single GPU",
                        "exchange_bytes_per_rank_per_step": rec_bytes if dist_on else 0, "gather_every": args.gather_every,
@@ -514,6 +549,10 @@ def main():
         if S > 1:   # the JOB's rate against the KERNEL's duration: consecutive steps overlap, so a step takes less than a kernel lasts -- by design, not by mistake
             line["pipelining"] = {"launch_streams": S, "timed_region_ms_per_step": round(region_ms, 4), "kernel_ms_alone": round(kernel_ms, 4),
                                   "hidden_per_step_us": round((kernel_ms - region_ms) * 1e3, 2),
+                                  **({"one_stream_ms_per_step": round(one_stream * 1e3, 4), "one_stream_images_per_s": round(n_total / one_stream, 1),
+                                      "one_stream_is": f"the same {args.steps} steps issued to ONE stream right after the timed region (wall clock between two device "
+                                                       "synchronisations): the figure rounds 1-4 reported as `value`; value / this = what the second launch stream adds"}
+                                     if one_stream else {}),
                                   "note": "steps alternate between two HIP streams: the workgroups of step k+1 start on CUs step k has drained, so a launch's ramp, drain and "
                                           "dispatch gap (6.6 us of fixed cost per launch on one stream, tools/probe/batch_rate.py) overlap the neighbour step.  "
                                           "ms_per_step < roofline.kernel_ms follows from that; `roofline` prices the kernel alone (--streams 1 reproduces rounds 1-4)"}
@@ -539,7 +578,7 @@ def main():
                                     "frac": round(prof["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4), "bank_conflict_cycles": prof.get("SQ_LDS_BANK_CONFLICT"),
                                     "lds_instructions_per_launch": prof.get("SQ_INSTS_LDS"), "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
         if not dist_on:
-            cb, mism = cpu_baseline(x, heads)
+            cb, mism, _ = cpu_baseline(x, heads)
             line["cpu_baseline"] = cb
             line["parity"] = ("bit-exact vs oracle on %d/%d frames; decoded boxes of the golden frames equal tests/golden" % (n, n)) if mism == 0 and not problems \
                 else f"MISMATCH: {mism} head bytes differ; {problems}"
@@ -582,6 +621,7 @@ def main():
                 line["secondary"] = secondary_configs(net, dev, stream, args.clock_settle_ms, args.secondary_iters)
         else:
             line["all_gather_ok"] = ok_gather
+            line["rank_major_check"] = {"ranks_sampled": ranks_sampled, "note": "rank 0's view: firing frames sampled from every rank's shard carry that rank's local frame indices"}
             line["parity"] = "every rank: heads of its first 256 frames and decoded records of its first 64 frames equal the oracle; golden detections equal tests/golden" \
                 if all_ok else f"FAILED on at least one rank (rank 0: {problems})"
             if not all_ok:

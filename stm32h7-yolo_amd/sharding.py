@@ -231,6 +231,10 @@ class DetectionExchange:
                 self.pending[i].wait()
                 self.pending[i] = None
             self.filled[i] = 0 if self.active else self.filled[i]
+        # a run that ended inside a buffer: the next acquire() starts a FRESH buffer (slot 0).  Round 5 left step_no in the middle of the sent buffer, so a
+        # caller that kept stepping was handed slot k != 0 of it, and the buffer's next send packed range(filled) = the stale slots 0..k-1 in front of the
+        # fresh one -- retransmitted, and indistinguishable from fresh blocks on the receiver.
+        self.step_no = -(-self.step_no // self.K) * self.K
 
     # ---- what every rank must hold after exchange(slot) + drain(): every rank's blocks, in rank (= frame) order
     def check_gathered(self, slot, rank):
@@ -248,6 +252,30 @@ class DetectionExchange:
         """every rank's wire records of the slot, rank-major: [world * n, cap, 28] (or [.., 12] in the compact form)"""
         i, k = self._ik(slot)
         return torch.cat([self.wire_views(self.gathered[i], r, k)[0] for r in range(self.world)])
+
+    def rank_major_samples(self, slot, per_rank=64):
+        """Global frame indices to spot-check the rank = frame order of a gathered slot with: the first `per_rank` FIRING frames of EVERY rank's shard
+        (round 5 looked at the first 512 firing frames of the whole gathered array -- all of them inside rank 0's shard at N = 8, so a block of rank >= 1
+        landing at the wrong place would have passed)."""
+        counts = self.gathered_counts(slot).cpu().numpy()
+        out = []
+        for r in range(self.world):
+            firing = (counts[r * self.n:(r + 1) * self.n] > 0).nonzero()[0][:per_rank]
+            out += [int(r * self.n + f) for f in firing]
+        return out
+
+    def gathered_is_rank_major(self, slot, rank, local_counts, frame_of_record, per_rank=64):
+        """What every rank must hold after the exchange of `slot`: its own block at ITS place, the counts of all ranks as one [world * n] array with this rank's
+        counts in [rank * n, (rank + 1) * n), and -- for firing frames sampled from every rank's shard -- `frame_of_record(g)` (the frame index carried by the
+        first gathered record of global frame g) == g mod n: a rank's records carry LOCAL frame indices, the global order is rank-major.
+        Returns (ok, ranks whose shard contributed a sample)."""
+        ok = self.check_gathered(slot, rank)
+        g_counts = self.gathered_counts(slot)
+        a, b = rank * self.n, (rank + 1) * self.n
+        ok = ok and tuple(g_counts.shape) == (self.world * self.n,) and bool(torch.equal(g_counts[a:b].cpu(), local_counts.cpu()))
+        samples = self.rank_major_samples(slot, per_rank)
+        ok = ok and all(int(frame_of_record(g)) == g % self.n for g in samples)
+        return bool(ok), sorted({g // self.n for g in samples})
 
     def gathered_sparse_heads(self, slot):
         """compact form: the sparse int8 heads [world * n, 7, 7, 18] the gathered records of the slot stand for (decode them to get yf_det records)"""

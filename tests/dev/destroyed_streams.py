@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """A host that creates a HIP stream per request, synchronises it, DESTROYS it and never calls yf_network_release_stream (allowed: INTEGRATION.md, "Dropping a
 stream") -- with real hipStreamCreate / hipStreamDestroy through the runtime's C API, not PyTorch's pooled streams, whose handles are never destroyed.  The
-scratch map then holds regions whose stream handle is dead: a region left "dirty" (launched on without an event) is named lazily by the next stream that
-needs one, i.e. hipEventRecord is called on the dead handle -- which must fail cleanly, not crash -- and the region must come back (device synchronise at the
-cap).  200 requests (int8 batches of 512 frames on the batched shape, every fourth also fp16 and 160x160), at most three streams alive at a time; every int8
+scratch map then holds regions whose stream handle is dead.  The map never hands a STORED stream handle to the runtime (this runtime does not validate
+handles: hipStreamQuery / hipEventRecord on a destroyed stream is a segmentation fault, tools/probe/dead_stream_probe.py -- a first form of round 5 did
+exactly that and died here): a region left "dirty" (launched on without an event) stays dirty until its stream launches again, is released, or -- at the
+cap, when only dirty regions are left -- the DEVICE is synchronised (counted: scratch_stats()["device_syncs"]), and then changes hands.  200 requests (int8 batches of 512 frames on the batched shape, every fourth also fp16 and 160x160), at most three streams alive at a time; every int8
 head is compared with the oracle, the footprint must stay within eight regions per kind.  Test helper: tests/test_gpu_parity.py runs it in a fresh process."""
 import ctypes, importlib, os, sys
 import numpy as np, torch
@@ -48,7 +49,9 @@ for st, o in alive:
     bad += not np.array_equal(o.cpu().numpy(), ref)
     assert hip.hipStreamDestroy(st) == 0
 torch.cuda.synchronize()
-ok = bad == 0 and 0 < peak <= 8 * 48 * 2 ** 20
+st = net.scratch_stats()                    # what the maps did (yf_network_scratch_stats): a host can SEE that dropping streams without a release costs device synchronisations
+ok = bad == 0 and 0 < peak <= 8 * 48 * 2 ** 20 and 0 < st["regions"] <= 8 + 4 + 8 and st["events_recorded"] + st["events_skipped"] >= 200
 print(f"200 requests on {len(handles)} distinct stream handle values: {bad} mismatches, peak scratch {peak / 2**20:.1f} MiB")
+print("scratch stats:", st)
 print("destroyed-streams rehearsal ok" if ok else "destroyed-streams rehearsal FAILED")
 sys.exit(0 if ok else 1)

@@ -108,6 +108,44 @@ def _worker(rank, world, port, n_local, steps, gather_heads, gather_every, compa
     for step in range(max(0, (steps - 1) // K * K - K), steps):           # the steps of the last two buffers
         ok = ok and gathered_is(slots[step], step)
     ok = ok and ex.check_gathered(slots[-1], rank)
+    # bench.py's rank = frame order check (sharding.gathered_is_rank_major): this rank's block at its place, every rank's counts as one array, and the first
+    # firing frames of EVERY rank's shard carrying that rank's LOCAL frame indices -- the sample must reach into every shard (at N = 8 the first 512 firing
+    # frames of the whole array, round 5's sample, all lie in rank 0's)
+    last = slots[-1]
+    if compact:
+        sparse = ex.gathered_sparse_heads(last).numpy()
+        frame_of = lambda g: orc.decode_py(sparse[g], g % n_local, 1.0, 1.0)[0][0]      # noqa: E731
+    else:
+        g_frames = ex.gathered_records(last)[:, 0, :4].contiguous().view(torch.int32).view(-1).numpy()
+        frame_of = lambda g: g_frames[g]                                                # noqa: E731
+    ok_rm, ranks_sampled = ex.gathered_is_rank_major(last, rank, ex.views(ex.local[last.i], 0, last.k)[1], frame_of, per_rank=2)
+    ok = ok and ok_rm and ranks_sampled == list(range(world))
+    if not compact:                            # a block at the wrong place IS caught: swap the blocks of the last two ranks in the gathered buffer
+        g = ex.gathered[last.i]
+        rb = ex.K * ex.wire_rec_bytes
+        tmp = g[(world - 1) * rb:world * rb].clone()
+        g[(world - 1) * rb:world * rb] = g[(world - 2) * rb:(world - 1) * rb]
+        g[(world - 2) * rb:(world - 1) * rb] = tmp
+        g_frames = ex.gathered_records(last)[:, 0, :4].contiguous().view(torch.int32).view(-1).numpy()
+        caught = not ex.gathered_is_rank_major(last, rank, ex.views(ex.local[last.i], 0, last.k)[1], lambda gi: g_frames[gi], per_rank=2)[0]
+        ok = ok and (caught or rank < world - 2)     # the two ranks whose own block moved see it; the others cannot (records carry LOCAL frame indices, a foreign
+                                                     # shard looks the same wherever it lies) -- which is why EVERY rank checks its own block's place and bench.py
+                                                     # MIN-reduces the verdicts
+    #  a run that ended INSIDE a buffer and keeps stepping: drain() sent the partly filled buffer, the next acquire() must start a fresh
+    # buffer at slot 0 -- not hand out slot k != 0 of the sent one, whose next send would retransmit the stale slots in front of it
+    if K > 1 and steps % K:
+        slot = ex.acquire()
+        ok = ok and slot.k == 0 and ex.step_no % K == 1
+        a, b = sh.shard_range(world * n_local, rank, world)
+        heads = orc.run(frames[pick_of(steps)[a:b]])
+        recs, counts = _records(orc, heads, cap)
+        r_view, c_view = ex.views(ex.local[slot.i], 0, 0)
+        r_view.copy_(torch.from_numpy(recs.view(np.uint8).reshape(n_local, cap, 28)))
+        c_view.copy_(torch.from_numpy(counts))
+        ex.heads(slot).copy_(torch.from_numpy(heads.reshape(-1).view(np.uint8)))
+        ex.exchange(slot)
+        ex.drain()
+        ok = ok and gathered_is(slot, steps) and ex.filled == [0] * ex.n_buf
     if rank == 0:
         q.put((bool(ok), int(ex.gathered_counts(slots[-1]).sum()), ex.wire_rec_bytes))
     dist.barrier()
@@ -122,19 +160,36 @@ def test_two_rank_gloo_detection_exchange(n_local, steps, gather_heads, gather_e
     every rank's records, counts (and heads) on every rank in rank = frame order, step after step; also with ONE collective per
     K steps (--gather-every: a run that ends inside a buffer sends it from drain()) and with the 12-byte wire records
     (--compact-records: decoding the sparse heads they stand for gives the senders' records)."""
+    port = 29500 + (os.getpid() + 17 * n_local + 131 * gather_every + 977 * compact) % 2000
+    _run_ranks(2, port, n_local, steps, gather_heads, gather_every, compact)
+
+
+def _run_ranks(world, port, n_local, steps, gather_heads, gather_every, compact):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 17 * n_local + 131 * gather_every + 977 * compact) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_local, steps, gather_heads, gather_every, compact, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, steps, gather_heads, gather_every, compact, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, n_dets, rec_bytes = q.get(timeout=240)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        ok, n_dets, rec_bytes = q.get(timeout=300)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ok
     assert n_dets > 0, "no frame fired: the record comparison would be vacuous"
     assert rec_bytes >= n_local * (4 * (12 if compact else 28) + 4)
+
+
+@pytest.mark.parametrize("n_local,steps,gather_heads,gather_every,compact", [(3, 5, False, 1, False), (3, 5, True, 2, True)])
+def test_eight_rank_gloo_detection_exchange(n_local, steps, gather_heads, gather_every, compact):
+    """World size EIGHT on CPU (gloo) -- BASELINE configs[2]'s rank count; no round before this one ran anything above world size 2.  The same worker as the
+    two-rank test: every rank's records / counts / heads on every rank in rank = frame order step after step (`gathered_is` walks all eight shards), the
+    gathered-buffer indexing r * K + k at r up to 7, and bench.py's own rank-major check with its sample drawn from every rank's shard."""
+    port = 31600 + (os.getpid() + 17 * n_local + 131 * gather_every + 977 * compact) % 2000
+    _run_ranks(8, port, n_local, steps, gather_heads, gather_every, compact)
 
 
 def test_compact_wire_records_round_trip():
