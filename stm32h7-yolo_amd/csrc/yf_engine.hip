@@ -25,6 +25,16 @@
 #undef YF_NS
 #undef YF_H0
 #undef YF_GENERIC
+#ifdef YF_LAB
+// laboratory: the 56x56 kernel once more, as a dump build that keeps the PRODUCTION stage order (yf_fused56.hip.h, YF_PDUMP) -- per-stage parity of what ships
+#undef YF_STAGE_FN
+#define YF_NS yfpd
+#define YF_DUMP_PROD_ORDER 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_DUMP_PROD_ORDER
+#undef YF_H0
+#endif
 #include "gen/yf_decode_tables_gen.h"
 
 namespace {
@@ -121,6 +131,10 @@ const Variant k_variants[] = {
   YF_VARIANT(2, 8, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 8, true), YF_VARIANT_CAM(2, 8),
 #ifdef YF_LAB
   YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 8, false), YF_VARIANT(2, 4, true),
+  // the dump build in the production stage order (same NetParams layout; selected by YF_LAB_DUMP_PROD_ORDER=1 as the engine's dump variant): f = 1002 keeps it
+  // out of every lookup by shape
+  { 1002, 8, true, false, (fused_fn)yfpd::yoloface56_fused<2, 8, true>, yfpd::lds_bytes<2, 8, true>(), yfpd::scratch_bytes_per_frame_slot<true>(),
+    "yoloface56_fused<F=2,NW=8,dump in production order>" },
 #endif
 };
 
@@ -134,6 +148,7 @@ struct yf_engine {
 #ifdef YF_LAB
   int grid_div = 1;                              // laboratory (YF_LAB_GRID_DIV): a launch takes 1 / grid_div of the resident grid (launch-policy what-ifs: several launches side by side)
   int fail_next_launch = 0;                      // laboratory: the next k fused launches get an invalid grid (tests the scratch lease on the failure path)
+  bool dump_prod_order = false;                  // laboratory (YF_LAB_DUMP_PROD_ORDER=1): the dump entry points run the dump build that keeps the production stage order
 #endif
   uint8_t* d_tab = nullptr;
   yf_table_index ix;
@@ -335,6 +350,7 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
 #ifdef YF_LAB
   { const char* fl = getenv("YF_LAB_FAIL_LAUNCHES"); if (fl) e->fail_next_launch = atoi(fl); }
   { const char* gd = getenv("YF_LAB_GRID_DIV"); if (gd && atoi(gd) > 1) e->grid_div = atoi(gd); }
+  { const char* pd = getenv("YF_LAB_DUMP_PROD_ORDER"); e->dump_prod_order = pd && pd[0] == '1'; }
 #endif
   {   // every shape keeps at most 4 frames in flight per CU (grid x frames per group)
     size_t park = 0;
@@ -354,6 +370,9 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   e->var = find_variant(2, 8, false);
   e->var_dump = find_variant(2, 8, true);
   e->var_small = find_variant(1, 8, false);
+#ifdef YF_LAB
+  if (e->dump_prod_order) e->var_dump = find_variant(1002, 8, true);
+#endif
   *out = e;
   return YF_ENG_OK;
 }

@@ -17,6 +17,19 @@ __device__ __forceinline__ void dump_buf(const char* frames, int8_t* dump, long 
   }
 }
 
+// the tail sets of a batched tail (tail batching: set f belongs to frame id_of(f), -1 = none) -- laboratory dump build in the PRODUCTION stage order only
+template <class B, int C, int FT, int NT, class IdOf>
+__device__ __forceinline__ void dump_sets(const char* frames, int8_t* dump, long stride, long off, const IdOf& id_of, int tid, int ch0 = 0, int split = 1 << 30, int gap = 0) {
+  for (int i = tid; i < FT * B::P * C; i += NT) {
+    const int ch = i % C; const int t = i / C;
+    const int p = t % B::P; const int f = t / B::P;
+    const long id = id_of(f);
+    if (id < 0) continue;
+    const int phys = ch0 + ch + (ch >= split ? gap : 0);
+    dump[id * stride + off + (long)p * C + ch] = (int8_t)frames[f * B::FS + B::at_p(p) + phys];
+  }
+}
+
 struct DumpOffsets {   // byte offsets of each fused stage's tensor inside one frame's dump record
   enum { T1 = 0, T2 = T1 + 6272, T3 = T2 + 6272, T4 = T3 + 3136, Q21 = T4 + 14112, T6 = Q21 + 3528, T7 = T6 + 3528,
          T8 = T7 + 1176, T9 = T8 + 7056, T11 = T9 + 7056, T14 = T11 + 1176, T15 = T14 + 7056, Q45 = T15 + 4704,
@@ -67,7 +80,15 @@ constexpr int STAGE_PRIO[27] = {YF_PRIO_LIST};
 template <int K> __device__ __forceinline__ void stage_prio() {
   if constexpr (K == 0 || STAGE_PRIO[K] != STAGE_PRIO[K - 1]) __builtin_amdgcn_s_setprio(STAGE_PRIO[K]);
 }
-template <bool DUMP> constexpr bool tail_batch() { return !DUMP; }
+// Laboratory (namespace yfpd of a -DYF_LAB build, yf_engine.hip): a dump build that KEEPS the production stage order -- pools beside the branch on 3 + 5 waves,
+// conv2d_10's output on concat_22's bytes, the 7x7 tail once per pair of groups on four frames through the HBM park -- so that per-stage parity is evidenced on
+// the order that ships, not only on the staged order of the observer's debug build.  The six observer-only tensors are not dumped.
+#if defined(YF_LAB) && defined(YF_DUMP_PROD_ORDER)
+#define YF_PDUMP 1
+#else
+#define YF_PDUMP 0
+#endif
+template <bool DUMP> constexpr bool tail_batch() { return !DUMP || YF_PDUMP; }
 
 // CAM: prm.in holds 112x112 RGB565 camera frames (25 088 B each) instead of int8 56x56x3 frames: the firmware's frame
 // preparation runs inside the input staging (stage_input_cam).
@@ -90,7 +111,8 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   constexpr bool BATCH = tail_batch<DUMP>();             // tail on two groups at a time (production builds)
-  constexpr bool POOL_MERGE = YF_POOL_MERGE != 0 && !DUMP && NW >= 8;      // (debug builds keep the staged order: their dumps and stop-stage numbers follow it)
+  constexpr bool POOL_MERGE = YF_POOL_MERGE != 0 && (!DUMP || YF_PDUMP) && NW >= 8;      // (debug builds keep the staged order: their dumps and stop-stage numbers follow it)
+  constexpr bool XDUMP = DUMP && !YF_PDUMP;               // the observer's extra tensors (raw pools, convolutions in front of the adds, LEAKY_RELU #43): staged-order debug build only
   typedef Buf<B_T14::OFF, 14, 14, 32, 14, 0, 0> B_T6X;                     // conv2d_10's output on concat_22's (still unwritten) bytes
   typedef typename std::conditional<POOL_MERGE, B_T6X, B_T6>::type B_T6M;
   constexpr int FT = BATCH ? 2 * F : F;                  // frames per tail run
@@ -248,17 +270,17 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
       YF_FETCH(5, W_m, L_m);
       if (W_m < PH) pool8_h<F, PH * 64>(frames, tid_m);                                               // pool_8 (h): T4 -> HB ...
       else v2::dw2_stage<F, NW - PH, 2, B_T4, B_T6M, 18, YF_L_LEAKY11, 4, v2::JobTabs<F, BATCH>::JT_DW10>(frames, tab, W_m - PH, L_m);   // ... beside conv2d_10: T4 -> T6
-      YF_SYNC();
+      YF_SYNC(); YF_DUMP(B_T6M, 18, T6)
       YF_PRIO(8);
       YF_FETCH(6, W_m, L_m);
       YF_DENSE(F, 1, 2, 16, B_T6M, B_T7, 0, 6, EPI_RAW, 0, B_T7, YF_D_C12, no_add, W_m, L_m, 5);          // conv2d_12
-      YF_SYNC();
+      YF_SYNC(); YF_DUMP(B_T7, 6, T7)
       YF_PRIO(9);
       YF_HALO(B_T8, true, F, G8, H_T8, YF_W_DW15, tid_m);
       YF_FETCH(7, W_m, L_m);
       if (W_m < PV) pool8_v<F, PV * 64, false>(frames, tid_m);                                        // pool_8 (v) + QUANTIZE#21: HB -> concat_22 ...
       else v2::dense2_stage<F, NW - PV, YF_TPJ13, 1, 8, B_T7, B_T8, 0, 36, EPI_LUT, YF_L_LEAKY14, B_T8, 6>(frames, out_all, tab, no_add, W_m - PV, L_m);   // ... beside conv2d_13: T7 -> T8
-      YF_SYNC();
+      YF_SYNC(); YF_DUMP(B_T14, 18, Q21) YF_DUMP(B_T8, 36, T8)
     } else {
   YF_PRIO(5);
 #if !(defined(YF_LAB) && defined(YF_WHATIF_NO_POOL8H))   // what-if (WRONG results): the horizontal pass and its barrier gone -- the bound for folding it into conv2d_6's epilogue
@@ -267,7 +289,7 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
 #endif
       YF_STAGE_END()
       YF_PRIO(6);
-      pool8_v<F, NT, DUMP>(frames, tid_m);                                                       // pool_8 (v) + QUANTIZE#21
+      pool8_v<F, NT, XDUMP>(frames, tid_m);                                                      // pool_8 (v) + QUANTIZE#21
       YF_SYNC();                                    // T6 (written next) aliases HB (read by pool_8 v)
       YF_PRIO(7);
       YF_FETCH(5, W_m, L_m);
@@ -293,11 +315,11 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     YF_STAGE_END()
     YF_PRIO(11);
     YF_FETCH(9, W_m, L_m);
-    if constexpr (DUMP)   // debug builds: conv2d_17's own output is parked in the (still unwritten) conv half of concat_22 for the dump
+    if constexpr (XDUMP)   // debug builds: conv2d_17's own output is parked in the (still unwritten) conv half of concat_22 for the dump
       v2::dense2_stage<F, NW, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, 8, B_T14::OFF + YF_T14_CONV_BASE, B_T14::S>(frames, out_all, tab, addctx(YF_A_ADD18), W_m, L_m);
     else
     YF_DENSE(F, 1, 3, 16, B_T9, B_T11, 0, 6, EPI_ADD, YF_A_ADD18, B_T7, YF_D_C17, addctx(YF_A_ADD18), W_m, L_m, 8);   // conv2d_17 + eltwise_18
-    YF_SYNC(); YF_DUMP(B_T11, 6, T11) YF_DUMP(B_T14, 6, C17, YF_T14_CONV_BASE)
+    YF_SYNC(); YF_DUMP(B_T11, 6, T11) if constexpr (XDUMP) { YF_DUMP(B_T14, 6, C17, YF_T14_CONV_BASE) }
     YF_STAGE_END()
     YF_PRIO(12);
     YF_FETCH(10, W_m, L_m);
@@ -358,16 +380,18 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
       return id < prm.n ? id : -1;
     };
 #define YF_DUMP_T(BUF, C, OFF, ...) \
-  if constexpr (DUMP) { if (prm.dump) { dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); YF_SYNC(); } }
+  if constexpr (DUMP) { if (prm.dump) { if constexpr (BATCH) dump_sets<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, frame_of, tid, ##__VA_ARGS__); \
+                                        else dump_buf<BUF, C, FT, NT>(frames, prm.dump, DS, DumpOffsets::OFF, first, prm.n, tid, ##__VA_ARGS__); \
+                                        YF_SYNC(); } }
     YF_PRIO(14);
     YF_FETCH(12, W_t, L_t);
     {   // pool_25 + QUANTIZE#45 on the first waves (by columns), conv2d_27 on the others: both only read T15
       constexpr int PW = v2::pool25_waves<FT>();
       static_assert(PW < NW, "waves left for conv2d_27");
-      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30, DUMP>(frames, W_t * 64 + L_t);
+      if (W_t < PW) v2::pool25_cols<FT, typename U::T15, typename U::T30, XDUMP>(frames, W_t * 64 + L_t);
       else v2::dw2_stage<FT, NW - PW, 2, typename U::T15, typename U::T17, 24, YF_L_LEAKY28, 11, v2::JobTabs<F, BATCH>::JT_DW27>(frames, tab, W_t - PW, L_t);
     }
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) YF_DUMP_T(typename U::T30, 24, P25, 24) YF_DUMP_T(typename U::T17, 24, T17)
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 24, Q45) if constexpr (XDUMP) { YF_DUMP_T(typename U::T30, 24, P25, 24) } YF_DUMP_T(typename U::T17, 24, T17)
     YF_STAGE_END()
     YF_PRIO(15);
     YF_FETCH(13, W_t, L_t);
@@ -388,11 +412,11 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     YF_STAGE_END()
     YF_PRIO(18);
     YF_FETCH(16, W_t, L_t);
-    if constexpr (DUMP)   // debug builds: conv2d_34's own output -> the conv half of concat_46 (written by conv2d_42 only)
+    if constexpr (XDUMP)   // debug builds: conv2d_34's own output -> the conv half of concat_46 (written by conv2d_42 only)
       v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, 15, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD35), W_t, L_t);
     else
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T22, 0, 8, EPI_ADD, YF_A_ADD35, typename U::T18, YF_D_C34, addctx(YF_A_ADD35), W_t, L_t, 15);   // conv2d_34 + eltwise_35
-    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22) YF_DUMP_T(typename U::T30, 8, C34, 24)
+    YF_SYNC(); YF_DUMP_T(typename U::T22, 8, T22) if constexpr (XDUMP) { YF_DUMP_T(typename U::T30, 8, C34, 24) }
     YF_STAGE_END()
     YF_PRIO(19);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW38, tid_t);
@@ -407,19 +431,19 @@ __global__ void __launch_bounds__(NW * 64, YF_WPE(NW)) yoloface56_fused(const Ne
     YF_STAGE_END()
     YF_PRIO(21);
     YF_FETCH(19, W_t, L_t);
-    if constexpr (DUMP)
+    if constexpr (XDUMP)
       v2::dense2_stage<FT, NW, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, 18, U::T30::OFF + 24, U::T30::S>(frames, out_all, tab, addctx(YF_A_ADD41), W_t, L_t);
     else
     YF_DENSE(FT, 1, 3, 16, typename U::T20, typename U::T26, 0, 8, EPI_ADD, YF_A_ADD41, typename U::T22, YF_D_C40, addctx(YF_A_ADD41), W_t, L_t, 18);   // conv2d_40 + eltwise_41
-    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26) YF_DUMP_T(typename U::T30, 8, C40, 24)
+    YF_SYNC(); YF_DUMP_T(typename U::T26, 8, T26) if constexpr (XDUMP) { YF_DUMP_T(typename U::T30, 8, C40, 24) }
     YF_STAGE_END()
     YF_PRIO(22);
     YF_FETCH(20, W_t, L_t);
-    if constexpr (DUMP)   // debug builds: LEAKY_RELU #43's output (through the debug LUT) -> T20's slot, dead since conv2d_40
+    if constexpr (XDUMP)   // debug builds: LEAKY_RELU #43's output (through the debug LUT) -> T20's slot, dead since conv2d_40
       v2::dense2_stage<FT, NW, 2, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, 19, U::T20::OFF, U::T20::S, DBG_LUT>(frames, out_all, tab, no_add, W_t, L_t);
     else
     YF_DENSE(FT, 3, 1, 8, typename U::T26, typename U::T30, 24, 24, EPI_LUT, YF_L_L43Q44, typename U::T30, YF_D_C42, no_add, W_t, L_t, 19);  // conv2d_42 -> concat_46
-    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) YF_DUMP_T(typename U::T20, 24, L43)
+    YF_SYNC(); YF_DUMP_T(typename U::T30, 48, T30) if constexpr (XDUMP) { YF_DUMP_T(typename U::T20, 24, L43) }
     YF_STAGE_END()
     YF_PRIO(23);
     YF_HALO(typename U::T19, true, FT, G19, H_T19, YF_W_DW49, tid_t);
@@ -505,4 +529,4 @@ template <int F, int NW, bool DUMP>
 constexpr size_t lds_bytes() { return (size_t)v2::pre_bytes<F, tail_batch<DUMP>()>() + (tail_batch<DUMP>() ? 0 : (F * OUT_FRAME_BYTES + 15) & ~15) + (size_t)FRAME_BYTES + (size_t)(F - 1) * FRAME_STRIDE + (DUMP ? YF_DBG_LUT_BYTES : 0); }
 template <bool DUMP>
 constexpr size_t scratch_bytes_per_frame_slot() { return tail_batch<DUMP>() ? (size_t)TailBufs<FRAME_BYTES>::T15_BYTES : 0; }
-
+#undef YF_PDUMP

@@ -2,14 +2,27 @@
 """Per-stage parity of the fused kernel against the CPU oracle (debug tool; runs on the GPU box).
 
 Uses the library's dump entry point (yf_network_run_device_dump) and compares every fused stage's tensor with the
-matching tflite op output of the oracle.  Prints the first failing stage."""
+matching tflite op output of the oracle.  Prints the first failing stage.
+
+    stage_parity.py [n]                       the product library's debug build (staged order: what the per-node observer runs)
+    stage_parity.py --prod-order n [n ...]    the laboratory library's dump build that KEEPS THE PRODUCTION STAGE ORDER (yf_fused56.hip.h, YF_PDUMP:
+                                              pools beside the branch on 3 + 5 waves, conv2d_10's output on concat_22's bytes, the 7x7 tail once per pair of
+                                              groups on four frames through the HBM park), on a grid of ONE workgroup so that consecutive groups pair up:
+                                              n = 5 -> a pair and an unpaired last group holding one frame; n = 8 -> two pairs; then once more on the full
+                                              grid.  The 25 fused-stage tensors of every frame must equal the oracle's ops."""
 import importlib
 import os
 import sys
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PROD_ORDER = "--prod-order" in sys.argv
+if PROD_ORDER:                                  # before the library is loaded: the laboratory build and its switches (yf_engine.hip, YF_LAB)
+    sys.argv.remove("--prod-order")
+    os.environ["YF_LIB_PATH"] = os.path.join(ROOT, "stm32h7-yolo_amd", "lib_lab", "libyf_network.so")
+    os.environ["YF_LAB_DUMP_PROD_ORDER"] = "1"
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle  # noqa: E402
 from oracle.np_restatement import load_yfm  # noqa: E402
@@ -31,7 +44,39 @@ def op_offsets():
     return offs, sizes
 
 
+def prod_order(sizes_n):
+    """the laboratory's production-order dump build; one fresh engine per grid size (YF_LAB_GRID_DIV is read at ai_network_init)"""
+    offs, sizes = op_offsets()
+    orc = Oracle()
+    ok = True
+    for grid_div, label in ((1 << 20, "one workgroup (groups pair up)"), (1, "full grid")):
+        os.environ["YF_LAB_GRID_DIV"] = str(grid_div)
+        net = yf.Network().init()
+        for n in sizes_n:
+            x = np.random.default_rng(100 + n).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
+            head_ref, dump_ref = orc.run(x, dump=True, threads=8)
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.full((n + 1, 7, 7, 18), 77, dtype=torch.int8, device="cuda")
+            d_dump = torch.full((n + 1, net.dump_bytes()), 77, dtype=torch.int8, device="cuda")
+            net.run_device(d_in.data_ptr(), d_out.data_ptr(), n, None, d_dump.data_ptr())
+            torch.cuda.synchronize()
+            dump, head = d_dump.cpu().numpy(), d_out.cpu().numpy()
+            off, bad_stages = 0, []
+            for name, op in STAGES:
+                if not np.array_equal(dump[:n, off:off + sizes[op]], dump_ref[:, offs[op]:offs[op] + sizes[op]]):
+                    bad_stages.append(name)
+                off += sizes[op]
+            good = not bad_stages and np.array_equal(head[:n], head_ref) and (head[n] == 77).all() and (dump[n] == 77).all()
+            print(f"production order, {label}, n = {n}: {'25 stage tensors + head ok' if good else 'MISMATCH ' + str(bad_stages)}")
+            ok &= bool(good)
+        net.destroy()
+    print("stage parity (production order) ok" if ok else "stage parity (production order) FAILED")
+    sys.exit(0 if ok else 1)
+
+
 def main():
+    if PROD_ORDER:
+        prod_order([int(a) for a in sys.argv[1:]] or [5, 3, 8])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     rng = np.random.default_rng(0)
     x = rng.integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
