@@ -204,6 +204,22 @@ def test_load_without_a_build_tool_checks_the_build_id():
     assert out == "REFUSED 0 True", log                     # ... and refuses a library built from other sources
 
 
+@pytest.mark.skipif(not _no_gpu(), reason="checks the behaviour WITHOUT a GPU")
+def test_c_rank_host_fails_cleanly_without_a_gpu():
+    """tools/c_host/yf_ranks.c on a box without a GPU: every rank fails at its first HIP call, the parent neither hangs on its pipes nor dies of SIGPIPE
+    (a first form read a dead rank's report as the ncclUniqueId), prints its one line with status 2 and exits 2."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "stm32h7-yolo_amd", "lib", "yf_c_ranks")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "stm32h7-yolo_amd", "csrc"), "chost"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for args in (["2", "1", "0", "1"], ["3", "1", "0", "1", "--no-exchange"]):
+        r = subprocess.run([exe, ROOT] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2, (r.returncode, r.stdout, r.stderr)
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["status"] == 2 and line["n_gpus"] == int(args[0]) and line["value"] == 0.0
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
 def test_handle_and_param_validation(yf):
     lib = yf.load()
     b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")

@@ -1299,6 +1299,31 @@ def test_the_bench_step_from_a_pure_c_host():
         assert line["value"] > 20e6 and 0.10 < line["kernel_ms_alone"] < 0.20
 
 
+def test_the_n_rank_flow_from_a_pure_c_host():
+    """tools/c_host/yf_ranks.c: one PROCESS per GPU forked before any HIP call, rank 0's ncclUniqueId handed round by pipe, ncclCommInitRank, the bench step +
+    yf_network_all_gather_device with four alternating record buffers on two streams, golden heads on rank 0, every rank's block at its own place and the
+    gathered counts in rank order on every rank; one JSON line, non-zero exit if any rank fails -- no Python, no torch.distributed (north_star: "host code in C";
+    INTEGRATION.md "Multi-GPU" has the N = 8 command).  Here: (1) N = 1 through RCCL (a one-rank communicator: RCCL refuses two ranks on one device);
+    (2) three ranks sharing the GPU without the collective (--no-exchange): fork / pipes / barrier / MAX over ranks with rank >= 1."""
+    import json
+    exe = os.path.join(ROOT, "stm32h7-yolo_amd", "lib", "yf_c_ranks")
+    if not os.path.exists(exe):
+        pytest.skip("stm32h7-yolo_amd/lib/yf_c_ranks was not built (make -C stm32h7-yolo_amd/csrc chost)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, ROOT, "1", "40", "10", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["global_batch"] == 4096 and line["status"] == 0 and line["exchange"].startswith("RCCL all-gather")
+    assert line["golden_heads_equal"] is True and line["own_block_at_own_place"] is True and line["gathered_counts_in_rank_order_on_every_rank"] is True
+    assert line["detections_on_the_real_frame"] > 0 and line["value"] > 0 and line["exchange_bytes_per_rank_per_step"] == 4096 * (4 * 28 + 4)
+    print(f"C host, one rank through RCCL: {line['value'] / 1e6:.2f} M images/s ({line['ms_per_step'] * 1e3:.1f} us per step, kernel alone {line['kernel_ms_alone_max_over_ranks'] * 1e3:.1f} us)")
+    r = subprocess.run([exe, ROOT, "3", "10", "2", "2", "--no-exchange"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 3 and line["global_batch"] == 3 * 4096 and line["status"] == 0 and line["golden_heads_equal"] is True
+    assert line["gathered_counts_in_rank_order_on_every_rank"] is None and line["value"] > 0
+
+
 def test_compact_wire_records_on_the_gpu(yf, network, oracle, torch_cuda):
     """yf_network_pack_detections_device / _unpack_ (the 12-byte wire form of the multi-GPU exchange, one launch each): the packed bytes equal the tensor-op
     statement of the format (sharding.pack_compact) also where the record buffer holds stale bytes beyond a frame's count; the sparse heads equal
