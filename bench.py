@@ -97,7 +97,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(x, got_heads):
+# --requant-rounding: library rounding (include/yf_network.h YF_ROUND_*) and the oracle variant that states it (oracle/yf_oracle.h YFO_RV_*)
+ROUNDINGS = {"ref": (0, 0), "ties_up": (1, 1), "ties_up_all": (2, 2), "single": (3, 4)}
+
+
+def cpu_baseline(x, got_heads, variant=0):
     """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames -- about 2 s of CPU work in all;
     also the in-bench parity check of the GPU result.  Three figures, each the MEDIAN of 3 repetitions ("(i) single thread and
     (ii) all cores"), each with its thread count:
@@ -116,7 +120,7 @@ def cpu_baseline(x, got_heads):
         times, out = [], None
         for _ in range(reps):
             t0 = time.perf_counter()
-            out = orc.run(frames, threads=threads)
+            out = orc.run(frames, threads=threads, variant=variant)
             times.append(time.perf_counter() - t0)
         return frames.shape[0] / sorted(times)[reps // 2], frames.shape[0] / min(times), out
     rate, best, ref = median_rate(x, cores)
@@ -300,6 +304,10 @@ def main():
     ap.add_argument("--input-batches", type=int, default=N_INPUT_BATCHES, metavar="B",
                     help=f"distinct input batches the steps rotate through (default {N_INPUT_BATCHES}: 308 MB per rank, more than the 256 MB Infinity Cache, so a "
                          "launch reads its frames from HBM); a rehearsal with several ranks on ONE GPU lowers it so that the ranks do not generate 2.5 GB")
+    ap.add_argument("--requant-rounding", choices=sorted(ROUNDINGS), default="ref",
+                    help="which published rounding of TFLite's requantisation the network computes (yf_network_set_requant_rounding): ref = the builtin reference "
+                         "kernels, the metric's definition (default); ties_up = dense convs as ruy rounds them (the default resolver of tflite_prediction.py:23); "
+                         "same kernels, other constants -- every check of this run then compares with the oracle's statement of THAT variant")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 code path: ranks may share one GPU, collectives go through host copies)")
     args = ap.parse_args()
 
@@ -333,6 +341,9 @@ def main():
     yf = importlib.import_module("stm32h7-yolo_amd")
     sharding = importlib.import_module("stm32h7-yolo_amd.sharding")
     net = yf.Network(device=dev_index, frames_per_wg=args.frames_per_wg, waves_per_wg=args.waves_per_wg).init()
+    rounding, variant = ROUNDINGS[args.requant_rounding]
+    if rounding:
+        net.set_requant_rounding(rounding)
 
     if args.only_secondary:
         if world != 1:
@@ -472,7 +483,7 @@ def main():
         kept_j = torch.arange(cap, device=dev)[None, :] < d_counts.clamp(max=cap)[:, None]     # (record slots beyond a frame's count are never written: stale bytes)
         if not (torch.equal(ex.heads(sl), ex.heads(Slot0)) and torch.equal(c_j, d_counts) and torch.equal(r_j[kept_j], d_dets[kept_j])):
             problems.append(f"rank {rank}: check step {j} (stream {j % S}, buffer {sl.i}, slot {sl.k}) differs from check step 0")
-    ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16)) if dist_on else None
+    ref_heads = orc.run(x[:n_chk], threads=min(len(os.sched_getaffinity(0)), 16), variant=variant) if dist_on else None
     if dist_on and not np.array_equal(heads[:n_chk], ref_heads):
         problems.append(f"rank {rank}: heads differ from the oracle on its first {n_chk} frames")
     if dist_on and os.environ.get("YF_BENCH_TEST_FAIL_RANK") == str(rank):         # read by ONE test only: rehearses "a rank's check fails -> every
@@ -483,7 +494,7 @@ def main():
         if counts[f] != len(want) or got != [(w[1], w[2], w[3], w[4], w[6], w[7], w[8], w[9]) for w in want][:cap]:
             problems.append(f"rank {rank}: detection records of frame {f} differ from the oracle's decode")
             break
-    if rank == 0:                               # the golden frames' detections are committed (tests/golden/golden_meta.json)
+    if rank == 0 and variant == 0:              # the golden frames' detections are committed (tests/golden/golden_meta.json; reference rounding)
         meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_meta.json")))
         for f, fr in enumerate(meta["frames"]):
             want = [(g["anchor"], g["row"], g["col"], g["x1"], g["y1"], g["x2"], g["y2"]) for g in fr["detections_py"]]
@@ -530,7 +541,7 @@ def main():
                        "frames_per_gpu": n, "global_batch": n_total, "frame_bytes_in": 9408, "frame_bytes_out": 882,
                        "clock_settle_ms": round(settled_ms, 1), "input_batches_rotated": NB, "input_bytes_resident": NB * n * 9408,
                        "check_steps": n_check_steps,
-                       "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(),
+                       "kernel": net.kernel_name, "kernel_source_hash": kernel_source_hash(), "requant_rounding": args.requant_rounding,
                        "parallelism": f"batch-shard x{world}, all-gather of detections" if dist_on else "single GPU",
                        "exchange_bytes_per_rank_per_step": rec_bytes if dist_on else 0, "gather_every": args.gather_every,
                        "collectives_issued": ex.collectives, "launch_streams": S,
@@ -578,9 +589,10 @@ def main():
                                     "frac": round(prof["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4), "bank_conflict_cycles": prof.get("SQ_LDS_BANK_CONFLICT"),
                                     "lds_instructions_per_launch": prof.get("SQ_INSTS_LDS"), "source": f"{prof['profile']} (kernel sources {prof['source_hash']})"}
         if not dist_on:
-            cb, mism, _ = cpu_baseline(x, heads)
+            cb, mism, _ = cpu_baseline(x, heads, variant)
             line["cpu_baseline"] = cb
-            line["parity"] = ("bit-exact vs oracle on %d/%d frames; decoded boxes of the golden frames equal tests/golden" % (n, n)) if mism == 0 and not problems \
+            line["parity"] = (("bit-exact vs oracle on %d/%d frames" % (n, n)) + ("; decoded boxes of the golden frames equal tests/golden" if variant == 0 else
+                              f" (oracle variant of --requant-rounding {args.requant_rounding})")) if mism == 0 and not problems \
                 else f"MISMATCH: {mism} head bytes differ; {problems}"
             # PCIe-inclusive rate through the reference ABI (host buffers): reported, never `value`
             # (the first call sizes the engine's device staging and starts its download thread: untimed; best of five after it)

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 }
 
 typedef void (*fused_fn)(const yf::NetParams);
-struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; };   // park: scratch bytes per frame slot of a workgroup
+struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; bool prod_order; };   // park: scratch bytes per frame slot of a workgroup; prod_order: the laboratory's dump build in the production stage order
 
 #define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
@@ -131,10 +131,9 @@ const Variant k_variants[] = {
   YF_VARIANT(2, 8, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 8, true), YF_VARIANT_CAM(2, 8),
 #ifdef YF_LAB
   YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 8, false), YF_VARIANT(2, 4, true),
-  // the dump build in the production stage order (same NetParams layout; selected by YF_LAB_DUMP_PROD_ORDER=1 as the engine's dump variant): f = 1002 keeps it
-  // out of every lookup by shape
-  { 1002, 8, true, false, (fused_fn)yfpd::yoloface56_fused<2, 8, true>, yfpd::lds_bytes<2, 8, true>(), yfpd::scratch_bytes_per_frame_slot<true>(),
-    "yoloface56_fused<F=2,NW=8,dump in production order>" },
+  // the dump build in the production stage order (same NetParams layout; selected by YF_LAB_DUMP_PROD_ORDER=1 as the engine's dump variant)
+  { 2, 8, true, false, (fused_fn)yfpd::yoloface56_fused<2, 8, true>, yfpd::lds_bytes<2, 8, true>(), yfpd::scratch_bytes_per_frame_slot<true>(),
+    "yoloface56_fused<F=2,NW=8,dump in production order>", true },
 #endif
 };
 
@@ -230,9 +229,20 @@ struct Downloader {
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
 static const Variant* shape_for(const yf_engine* e, long n);
-static const Variant* find_variant(int f, int nw, bool dump, bool cam = false) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.cam == cam) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool cam = false, bool prod_order = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.cam == cam && v.prod_order == prod_order) return &v;
   return nullptr;
+}
+
+// the debug (dump) build of a shape: the staged-order build the per-node observer runs; a laboratory engine started with YF_LAB_DUMP_PROD_ORDER=1 takes the
+// dump build that keeps the production stage order instead (shape <2,8> only)
+static const Variant* dump_variant_for(const yf_engine* e, int f, int nw) {
+#ifdef YF_LAB
+  if (e->dump_prod_order) { const Variant* v = find_variant(f, nw, true, false, true); if (v) return v; }
+#else
+  (void)e;
+#endif
+  return find_variant(f, nw, true);
 }
 
 #ifdef YF_LAB
@@ -368,11 +378,8 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   if ((rc = hipHostMalloc(&e->h_small_in, (size_t)ZERO_COPY_N * 9408, hipHostMallocMapped)) != hipSuccess ||
       (rc = hipHostMalloc(&e->h_small_out, (size_t)ZERO_COPY_N * 882, hipHostMallocMapped)) != hipSuccess) return bail(rc, "hipHostMalloc(pinned staging)");
   e->var = find_variant(2, 8, false);
-  e->var_dump = find_variant(2, 8, true);
+  e->var_dump = dump_variant_for(e, 2, 8);
   e->var_small = find_variant(1, 8, false);
-#ifdef YF_LAB
-  if (e->dump_prod_order) e->var_dump = find_variant(1002, 8, true);
-#endif
   *out = e;
   return YF_ENG_OK;
 }
@@ -428,7 +435,7 @@ int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) { return find_
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
   if (frames_per_wg < 0) {                       /* back to the automatic choice: throughput shape, small batches one frame per workgroup */
-    e->var = find_variant(2, 8, false); e->var_dump = find_variant(2, 8, true); e->var_small = find_variant(1, 8, false);
+    e->var = find_variant(2, 8, false); e->var_dump = dump_variant_for(e, 2, 8); e->var_small = find_variant(1, 8, false);
     return YF_ENG_OK;
   }
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
@@ -436,7 +443,7 @@ int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
   e->var = v;
   e->var_small = nullptr;                        /* an explicitly configured shape runs every batch size */
-  e->var_dump = find_variant(f, nw, true);       /* debug build of the SAME shape, or none: the dump / stage-timing entry points refuse instead of running another shape */
+  e->var_dump = dump_variant_for(e, f, nw);      /* debug build of the SAME shape, or none: the dump / stage-timing entry points refuse instead of running another shape */
   return YF_ENG_OK;
 }
 
