@@ -220,6 +220,19 @@ def test_c_rank_host_fails_cleanly_without_a_gpu():
     assert subprocess.run([exe], capture_output=True).returncode == 2
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler"), reason="needs the ROCm LLVM tools")
+def test_frozen_kernels_are_instruction_identical(yf):
+    """The int8 kernels (rounds 4-5), the fp16 kernel and the 160x160 band kernels are FROZEN.  Round 6 edits device SOURCE files for host-side
+    reasons only -- the engine's table upload, scratch statistics, the laboratory's production-order dump build inside yf_fused56.hip.h, the selectable rounding
+    (other CONSTANTS for the same kernels) -- so the build id moves, but every kernel of the product library must disassemble to the instruction stream of the
+    round-5 library (profiles/isa_hashes_frozen.txt; tools/isa_hashes.py).  A kernel change is a decision: regenerate the list and say so."""
+    import subprocess
+    import sys
+    yf.load()                                     # builds the library if it is stale
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hashes.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "12 kernels: instruction streams identical" in r.stdout, r.stdout + r.stderr
+
+
 def test_handle_and_param_validation(yf):
     lib = yf.load()
     b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")

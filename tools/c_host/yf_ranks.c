@@ -225,7 +225,9 @@ int main(int argc, char** argv) {
     pid[r] = fork();
     if (pid[r] < 0) { perror("fork"); return 2; }
     if (pid[r] == 0) {
-      for (int q = 0; q <= r; ++q) { close(up[q][0]); close(down[q][1]); if (q < r) { close(up[q][1]); close(down[q][0]); } }
+      /* the parent's ends of every pipe made so far are open in this child too: close them.  (The CHILD ends of earlier ranks were closed by the parent right
+       * after their fork -- their descriptor numbers may have been handed out again by this rank's pipe(): a first form closed them here and with them its own pipe.) */
+      for (int q = 0; q <= r; ++q) { close(up[q][0]); close(down[q][1]); }
       report rep;
       memset(&rep, 0, sizeof rep);
       rep.status = child(argv[1], r, world, steps, warmup, nb, exchange, up[r][1], down[r][0], &rep);
