@@ -200,6 +200,14 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
   else asm(YF_RQ4_MADS YF_RQ4_OPS);
 #undef YF_RQ4_MADS
 #undef YF_RQ4_OPS
+#if defined(YF_LAB) && defined(YF_WHATIF_RQ3)
+  // Timing-only what-if (laboratory, WRONG results with the shipped tables; profiles/r06_ties_up_epilogue_ab.txt): the epilogue WITHOUT its v_addc_co_u32.  A rounding
+  // with no sign term (ties upward, single rounding: yf_host_prep.c) needs neither the carry nor a separate ZR -- ZR folds into C64's high word -- so a kernel built
+  // for those roundings alone would requantise in three VALU instructions per output.  The product serves every rounding with the four-instruction form.
+  (void)zr; (void)cy0; (void)cy1; (void)cy2; (void)cy3;
+  t[0] = (int)d0[1]; t[1] = (int)d1[1]; t[2] = (int)d2[1]; t[3] = (int)d3[1];
+  return;
+#endif
   asm("v_addc_co_u32_e64 %0, vcc, %4, %8, %12\n\tv_addc_co_u32_e64 %1, vcc, %5, %9, %13\n\t"
       "v_addc_co_u32_e64 %2, vcc, %6, %10, %14\n\tv_addc_co_u32_e64 %3, vcc, %7, %11, %15"
       : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
@@ -228,6 +236,12 @@ __device__ __forceinline__ void requant2(const v4i acc, const v4u m2, const v4u 
   else
     asm("v_mad_u64_u32 %0, %2, %4, %6, %8\n\tv_mad_u64_u32 %1, %3, %5, %7, %9"
         : "=&v"(d0), "=&v"(d1), "=&s"(cy0), "=&s"(cy1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]));
+#if defined(YF_LAB) && defined(YF_WHATIF_RQ3)
+  (void)zr; (void)cy0; (void)cy1;
+  idx[0] = min(max((int)d0[1] >> rs[0], 0), 255);
+  idx[1] = min(max((int)d1[1] >> rs[1], 0), 255);
+  return;
+#endif
   asm("v_addc_co_u32_e64 %0, vcc, %2, %4, %6\n\tv_addc_co_u32_e64 %1, vcc, %3, %5, %7"
       : "=&v"(t0), "=&v"(t1) : "v"(zr[0]), "v"(zr[1]), "v"(d0[1]), "v"(d1[1]), "s"(cy0), "s"(cy1) : "vcc");
   idx[0] = min(max(t0 >> rs[0], 0), 255);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved timing of the SHIPPED kernel of several library builds (one process per library and round; network + fused decode, HBM-resident
-   rotating inputs).  usage: ab_libs.py <libdir> <libdir> [...] [rounds]      (directories under stm32h7-yolo_amd/).  DEV TOOL."""
+   rotating inputs).  usage: ab_libs.py <libdir>[@rounding] <libdir>[@rounding] [...] [rounds]      (directories under stm32h7-yolo_amd/; @ties_up etc. sets
+   YF_REQUANT_ROUNDING for that library's runs).  DEV TOOL."""
 import subprocess, sys, os, re, statistics
 args = sys.argv[1:]
 rounds = int(args.pop()) if args and args[-1].isdigit() else 4
@@ -10,11 +11,12 @@ res = {l: [] for l in libs}
 notes = {l: "" for l in libs}
 for r in range(rounds):
     for l in libs:
-        path = os.path.join(root, "stm32h7-yolo_amd", l, "libyf_network.so")
+        ldir, _, rounding = l.partition("@")         # "lib@ties_up": that library with YF_REQUANT_ROUNDING=ties_up (same kernels, other constants)
+        path = os.path.join(root, "stm32h7-yolo_amd", ldir, "libyf_network.so")
         if not os.path.exists(path):
             notes[l] = f"FAILED: {path} does not exist"
             continue
-        env = dict(os.environ, YF_LIB_PATH=path)
+        env = dict(os.environ, YF_LIB_PATH=path, **({"YF_REQUANT_ROUNDING": rounding} if rounding else {}))
         p = subprocess.run([sys.executable, os.path.join(root, "tools", "probe", "decode_cost.py")], env=env, capture_output=True, text=True, timeout=300)
         m = re.search(r"network only ([\d.]+) us per launch, network \+ fused decode ([\d.]+) us", p.stdout)
         if p.returncode != 0 or not m:       # a missing library, a child that died on the GPU, a changed output line: say which, with the child's last words
