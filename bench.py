@@ -98,7 +98,7 @@ def cpu_model():
 
 
 # --requant-rounding: library rounding (include/yf_network.h YF_ROUND_*) and the oracle variant that states it (oracle/yf_oracle.h YFO_RV_*)
-ROUNDINGS = {"ref": (0, 0), "ties_up": (1, 1), "ties_up_all": (2, 2), "single": (3, 4)}
+ROUNDINGS = {"ref": (0, 0), "ties_up": (1, 1), "ties_up_all": (2, 2), "single": (3, 4), "ties_up+generic": (0x101, 1)}   # +generic: that rounding on the reference rounding's kernels
 
 
 def cpu_baseline(x, got_heads, variant=0):

@@ -223,15 +223,18 @@ enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anc
  *                         shift breaks ties UPWARD); DEPTHWISE_CONV_2D, LEAKY_RELU, ADD, QUANTIZE keep the reference form.
  *   YF_ROUND_TIES_UP_ALL  every op ties upward.
  *   YF_ROUND_SINGLE       dense CONV_2D with ONE rounding, (acc*M + 2^(30-shift)) >> (31-shift) (ruy's portable path); the rest reference.
- * All four run the SAME kernels at the same speed: the rounding lives in the per-channel constants {C64, ZR}, the LeakyReLU / QUANTIZE
- * byte tables and the add tables that ai_network_init builds (csrc/yf_host_prep.c).  Call after ai_network_create, before or after
+ * The rounding lives in the per-channel constants {C64, ZR}, the LeakyReLU / QUANTIZE byte tables and the add tables that ai_network_init builds
+ * (csrc/yf_host_prep.c); the four-instruction requantisation of the reference rounding's kernels serves every one of them.  The three roundings whose
+ * dense convolutions have NO sign term (ties upward, single rounding) by default run a second set of the same kernels whose dense convolutions
+ * requantise in THREE instructions (no carry, ZR folded into C64: 7 % less kernel time, profiles/r06_ties_up_epilogue_ab.txt); or-ing
+ * YF_ROUND_GENERIC_KERNELS into the rounding keeps them on the reference rounding's kernels (same results; for A/B).  Call after ai_network_create, before or after
  * ai_network_init (a ready network waits for its launches, rebuilds its tables from the weights it was initialised with -- which the caller
  * still owns, as on the MCU -- and uploads them); ai_network_create resets the choice to $YF_REQUANT_ROUNDING ("ref", "ties_up",
- * "ties_up_all", "single"; unset = ref) so that an unmodified aiInit() can be steered from outside.  Affects the 56x56 and 160x160 int8
+ * "ties_up_all", "single", each optionally followed by "+generic"; unset = ref) so that an unmodified aiInit() can be steered from outside.  Affects the 56x56 and 160x160 int8
  * paths; the fp16 path has no requantisation.  Returns 0, or -1 with an error latched. */
 #ifndef YF_ROUND_ENUM
 #define YF_ROUND_ENUM
-enum { YF_ROUND_TFLITE_REF = 0, YF_ROUND_TIES_UP = 1, YF_ROUND_TIES_UP_ALL = 2, YF_ROUND_SINGLE = 3, YF_ROUND_COUNT };
+enum { YF_ROUND_TFLITE_REF = 0, YF_ROUND_TIES_UP = 1, YF_ROUND_TIES_UP_ALL = 2, YF_ROUND_SINGLE = 3, YF_ROUND_COUNT, YF_ROUND_GENERIC_KERNELS = 0x100 };
 #endif
 YF_API int  yf_network_set_requant_rounding(ai_handle network, int rounding);
 YF_API int  yf_network_get_requant_rounding(ai_handle network);      /* the rounding in force, -1 for an invalid handle */

@@ -29,6 +29,7 @@ WEIGHTS_BYTES, ACTIVATIONS_BYTES = 11304, 29784
 YF_DECODE_PY, YF_DECODE_FW, YF_DECODE_FW_HOST = 0, 1, 2
 # rounding of the requantisation step (include/yf_network.h, yf_network_set_requant_rounding)
 YF_ROUND_TFLITE_REF, YF_ROUND_TIES_UP, YF_ROUND_TIES_UP_ALL, YF_ROUND_SINGLE = 0, 1, 2, 3
+YF_ROUND_GENERIC_KERNELS = 0x100      # or-ed into a rounding: keep the reference rounding's four-instruction kernels (A/B against the sign-free kernel set)
 
 
 class AiError(ctypes.Structure):
@@ -457,7 +458,8 @@ class Network:
 
     def set_requant_rounding(self, rounding):
         """Which published rounding of TFLite's requantisation the network computes (YF_ROUND_*; default: the builtin reference kernels).
-        Same kernels, other constants; before or after init()."""
+        Other constants for the same kernels, or -- the roundings without a sign term, by default -- for the kernel set with the three-instruction
+        dense epilogue; before or after init()."""
         if self.lib.yf_network_set_requant_rounding(self.handle, int(rounding)) != 0:
             self._raise("yf_network_set_requant_rounding")
         return self

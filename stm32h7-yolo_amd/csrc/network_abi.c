@@ -61,12 +61,19 @@ static ai_error mk_error(unsigned type, unsigned code) { ai_error e; e.type = ty
 /* $YF_REQUANT_ROUNDING: lets an unmodified aiInit() (yoloface.c:188-211: create + init back to back) be steered from outside */
 static int rounding_from_env(void) {
   const char* v = getenv("YF_REQUANT_ROUNDING");
-  if (!v || !*v || !strcmp(v, "ref")) return YF_ROUND_TFLITE_REF;
-  if (!strcmp(v, "ties_up")) return YF_ROUND_TIES_UP;
-  if (!strcmp(v, "ties_up_all")) return YF_ROUND_TIES_UP_ALL;
-  if (!strcmp(v, "single")) return YF_ROUND_SINGLE;
+  if (!v || !*v) return YF_ROUND_TFLITE_REF;
+  char word[32];
+  snprintf(word, sizeof word, "%s", v);
+  int flags = 0;
+  char* plus = strchr(word, '+');          /* "ties_up+generic": that rounding on the four-instruction kernels (A/B of the two kernel sets) */
+  if (plus) { if (strcmp(plus, "+generic")) return -1; *plus = 0; flags = YF_ROUND_GENERIC_KERNELS; }
+  if (!strcmp(word, "ref")) return YF_ROUND_TFLITE_REF | flags;
+  if (!strcmp(word, "ties_up")) return YF_ROUND_TIES_UP | flags;
+  if (!strcmp(word, "ties_up_all")) return YF_ROUND_TIES_UP_ALL | flags;
+  if (!strcmp(word, "single")) return YF_ROUND_SINGLE | flags;
   return -1;                               /* unknown word: ai_network_init fails loudly instead of guessing */
 }
+static int rounding_is_valid(int r) { return r >= 0 && (r & ~YF_ROUND_GENERIC_KERNELS) < YF_ROUND_COUNT; }
 
 /* ------------------------------------------------------------------------------------------------ create / destroy */
 ai_error yf_impl_create(ai_handle* network, const ai_buffer* network_config) {
@@ -143,8 +150,8 @@ ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
     latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_ACTIVATIONS, "activations buffer smaller than 29784 bytes"); return false;
   }
   if (c->engine) { yf_engine_destroy(c->engine); c->engine = NULL; c->state = ST_CREATED; }
-  if (c->rounding < 0 || c->rounding >= YF_ROUND_COUNT) {
-    latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, "YF_REQUANT_ROUNDING is none of ref, ties_up, ties_up_all, single"); return false;
+  if (!rounding_is_valid(c->rounding)) {
+    latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_PARAMS, "YF_REQUANT_ROUNDING is none of ref, ties_up, ties_up_all, single (optionally followed by +generic)"); return false;
   }
 
   uint8_t* tables = NULL;
@@ -155,7 +162,7 @@ ai_bool yf_impl_init(ai_handle network, const ai_network_params* params) {
     latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK_WEIGHTS, t); return false;
   }
   char etext[400] = "";
-  const int erc = yf_engine_create(c->device, tables, &ix, &c->engine, etext, sizeof etext);
+  const int erc = yf_engine_create(c->device, tables, &ix, yf_rounding_signless_dense(c->rounding), &c->engine, etext, sizeof etext);
   free(tables);
   if (erc != YF_ENG_OK) { c->engine = NULL; latch(c, AI_ERROR_INIT_FAILED, AI_ERROR_CODE_NETWORK, etext); return false; }
   if (c->cfg_frames || c->cfg_waves) {
@@ -351,14 +358,14 @@ YF_API int yf_network_set_device(ai_handle network, int device) {
 YF_API int yf_network_set_requant_rounding(ai_handle network, int rounding) {
   yf_context* c = acquire(network);
   if (!c) return -1;
-  if (rounding < 0 || rounding >= YF_ROUND_COUNT) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_OUT_OF_RANGE, "no such requantisation rounding"); return -1; }
+  if (!rounding_is_valid(rounding)) { latch(c, AI_ERROR_INVALID_PARAM, AI_ERROR_CODE_OUT_OF_RANGE, "no such requantisation rounding"); return -1; }
   if (c->state == ST_READY && c->engine && rounding != c->rounding) {
     /* same weights (still the caller's, as on the MCU: network.c:3108-3267 keeps pointers into the blob), other constants, same layout */
     uint8_t* tables = NULL;
     yf_table_index ix;
     const int prc = yf_prepare_tables_rounding((const uint8_t*)c->bound_weights, c->bound_weights_bytes, rounding, &tables, &ix);
     if (prc != YF_PREP_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK_WEIGHTS, "table preparation failed"); return -1; }
-    const int erc = yf_engine_set_tables(c->engine, tables, &ix);
+    const int erc = yf_engine_set_tables(c->engine, tables, &ix, yf_rounding_signless_dense(rounding));
     free(tables);
     if (erc != YF_ENG_OK) { latch(c, AI_ERROR_INVALID_STATE, AI_ERROR_CODE_NETWORK, yf_engine_error(c->engine)); return -1; }
   }

@@ -13,10 +13,12 @@ typedef struct yf_engine yf_engine;
 
 enum { YF_ENG_OK = 0, YF_ENG_ERR_HIP = -1, YF_ENG_ERR_ARG = -2, YF_ENG_ERR_NO_DEVICE = -3, YF_ENG_ERR_VARIANT = -4 };
 
-int  yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen);
+/* signless_dense: the table blob carries the sign-free form of the dense stages' constants (ZR folded into C64: yf_host_prep.c) and the launches take the kernels
+ * whose dense convolutions requantise in three instructions (namespaces yfu / yf160u of yf_engine.hip); 0 = the four-instruction kernels, any rounding's constants */
+int  yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, int signless_dense, yf_engine** out, char* err, size_t errlen);
 void yf_engine_destroy(yf_engine* e);
 /* replace the table blob of a live engine (same layout, other constants: yf_network_set_requant_rounding); waits for the device first */
-int  yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix);
+int  yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix, int signless_dense);
 /* 1 if a production kernel of that shape is compiled in (frames_per_wg may carry the +200 experimental-build tag) */
 int  yf_engine_variant_exists(int frames_per_wg, int waves_per_wg);
 int  yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg);

@@ -25,6 +25,24 @@
 #undef YF_NS
 #undef YF_H0
 #undef YF_GENERIC
+// The same kernels once more with the SIGN-FREE three-instruction epilogue on their dense convolutions (yf_kernels.hip.h, rq4 SIGNLESS): what runs when the network's
+// requantisation rounding has no sign term (yf_network_set_requant_rounding: ties upward / single rounding; the host then folds ZR into C64 for the dense stages).
+// Namespaces yfu (56x56) and yf160u (160x160).  The kernels of yf / yf160 above -- the reference rounding's -- are untouched by this.
+#undef YF_STAGE_FN
+#define YF_NS yfu
+#define YF_RQ3_DENSE 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_STAGE_FN
+#undef YF_H0
+#define YF_NS yf160u
+#define YF_H0 160
+#define YF_GENERIC 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_H0
+#undef YF_GENERIC
+#undef YF_RQ3_DENSE
 #ifdef YF_LAB
 // laboratory: the 56x56 kernel once more, as a dump build that keeps the PRODUCTION stage order (yf_fused56.hip.h, YF_PDUMP) -- per-stage parity of what ships
 #undef YF_STAGE_FN
@@ -119,7 +137,8 @@ __global__ void __launch_bounds__(256) prepare_rgb565_kernel(const uint8_t* __re
 }
 
 typedef void (*fused_fn)(const yf::NetParams);
-struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; bool prod_order; };   // park: scratch bytes per frame slot of a workgroup; prod_order: the laboratory's dump build in the production stage order
+struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t park; const char* name; bool prod_order; bool signless; };
+// park: scratch bytes per frame slot of a workgroup; prod_order: the laboratory's dump build in the production stage order; signless: namespace yfu (sign-free dense epilogue)
 
 #define YF_VARIANT(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yf::yoloface56_fused<F, NW, DUMP>, yf::lds_bytes<F, NW, DUMP>(), yf::scratch_bytes_per_frame_slot<DUMP>(), \
                                   "yoloface56_fused<F=" #F ",NW=" #NW ">" }
@@ -127,8 +146,14 @@ struct Variant { int f, nw; bool dump; bool cam; fused_fn fn; size_t lds; size_t
                                 yf::scratch_bytes_per_frame_slot<false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input>" }
 // The product: the batched shape <2,8>, the one-frame-per-workgroup shape <1,8> for small batches, the camera-input form of <2,8> and ONE debug
 // (per-stage dump / stop_stage) build for the per-node observer.  A -DYF_LAB build (make lab) adds the other shapes for tools and tests.
+#define YF_VARIANT_U(F, NW, DUMP) { F, NW, DUMP, false, (fused_fn)yfu::yoloface56_fused<F, NW, DUMP>, yfu::lds_bytes<F, NW, DUMP>(), yfu::scratch_bytes_per_frame_slot<DUMP>(), \
+                                    "yoloface56_fused<F=" #F ",NW=" #NW ",sign-free dense epilogue>", false, true }
+#define YF_VARIANT_U_CAM(F, NW) { F, NW, false, true, (fused_fn)yfu::yoloface56_fused<F, NW, false, true>, yfu::lds_bytes<F, NW, false>(), \
+                                  yfu::scratch_bytes_per_frame_slot<false>(), "yoloface56_fused<F=" #F ",NW=" #NW ",RGB565 input,sign-free dense epilogue>", false, true }
 const Variant k_variants[] = {
   YF_VARIANT(2, 8, false), YF_VARIANT(1, 8, false), YF_VARIANT(2, 8, true), YF_VARIANT_CAM(2, 8),
+  // ... and the same four with the three-instruction epilogue on the dense convolutions, for the roundings without a sign term
+  YF_VARIANT_U(2, 8, false), YF_VARIANT_U(1, 8, false), YF_VARIANT_U(2, 8, true), YF_VARIANT_U_CAM(2, 8),
 #ifdef YF_LAB
   YF_VARIANT(1, 4, false), YF_VARIANT(2, 4, false), YF_VARIANT(4, 8, false), YF_VARIANT(2, 4, true),
   // the dump build in the production stage order (same NetParams layout; selected by YF_LAB_DUMP_PROD_ORDER=1 as the engine's dump variant)
@@ -143,7 +168,8 @@ struct yf_engine {
   int device = 0;
   int cus = 0;
   size_t lds_per_cu = 0;                         // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
-  int band_wgs_per_cu[3] = {1, 1, 1};            // resident workgroups per CU of the three banded 160x160 kernels on this device (occupancy query at creation)
+  int band_wgs_per_cu[2][3] = {{1, 1, 1}, {1, 1, 1}};   // resident workgroups per CU of the three banded 160x160 kernels on this device (occupancy query at creation), per kernel set
+  bool signless = false;                         // the tables are built for -- and the launches take -- the kernels with the sign-free dense epilogue (namespaces yfu / yf160u)
 #ifdef YF_LAB
   int grid_div = 1;                              // laboratory (YF_LAB_GRID_DIV): a launch takes 1 / grid_div of the resident grid (launch-policy what-ifs: several launches side by side)
   int fail_next_launch = 0;                      // laboratory: the next k fused launches get an invalid grid (tests the scratch lease on the failure path)
@@ -229,8 +255,8 @@ struct Downloader {
     (e_)->err = std::string(#call) + ": " + hipGetErrorString(rc_); return YF_ENG_ERR_HIP; } } while (0)
 
 static const Variant* shape_for(const yf_engine* e, long n);
-static const Variant* find_variant(int f, int nw, bool dump, bool cam = false, bool prod_order = false) {
-  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.cam == cam && v.prod_order == prod_order) return &v;
+static const Variant* find_variant(int f, int nw, bool dump, bool cam = false, bool prod_order = false, bool signless = false) {
+  for (const Variant& v : k_variants) if (v.f == f && v.nw == nw && v.dump == dump && v.cam == cam && v.prod_order == prod_order && v.signless == signless) return &v;
   return nullptr;
 }
 
@@ -238,11 +264,15 @@ static const Variant* find_variant(int f, int nw, bool dump, bool cam = false, b
 // dump build that keeps the production stage order instead (shape <2,8> only)
 static const Variant* dump_variant_for(const yf_engine* e, int f, int nw) {
 #ifdef YF_LAB
-  if (e->dump_prod_order) { const Variant* v = find_variant(f, nw, true, false, true); if (v) return v; }
-#else
-  (void)e;
+  if (e->dump_prod_order && !e->signless) { const Variant* v = find_variant(f, nw, true, false, true); if (v) return v; }
 #endif
-  return find_variant(f, nw, true);
+  return find_variant(f, nw, true, false, false, e->signless);
+}
+// the engine's three kernel shapes for a configuration (f, nw; 0 = the automatic choice), in the kernel set its tables are built for
+static void select_variants(yf_engine* e, int f, int nw, bool automatic) {
+  e->var = find_variant(f, nw, false, false, false, e->signless);
+  e->var_dump = dump_variant_for(e, f, nw);
+  e->var_small = automatic ? find_variant(1, 8, false, false, false, e->signless) : nullptr;
 }
 
 #ifdef YF_LAB
@@ -266,16 +296,19 @@ struct BandKernel { const void* fn; const char* name; unsigned threads; size_t l
 #define YF_K1_NW 8
 #endif
 #define YF_K1_NW_ YF_K1_NW
-static const BandKernel k_band_fused[3] = {      // round 3: K2 and K3 fused (three tensors cross HBM instead of five)
-  {(const void*)yf160::band::band_k1<YF_K1_NW_>, "band_k1", YF_K1_NW_ * 64, (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS},
-  {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS},
-  {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1},
+static const BandKernel k_band_fused[2][3] = {   // round 3: K2 and K3 fused (three tensors cross HBM instead of five); [1]: the set with the sign-free dense epilogue
+  {{(const void*)yf160::band::band_k1<YF_K1_NW_>, "band_k1", YF_K1_NW_ * 64, (size_t)yf160::band::K1_LDS, yf160::band::K1_BANDS},
+   {(const void*)yf160::band::band_k23<8>, "band_k23", 512, (size_t)yf160::band::K23_LDS, yf160::band::K23_BANDS},
+   {(const void*)yf160::band::band_k4<8>,  "band_k4", 512,  (size_t)yf160::band::K4_LDS, 1}},
+  {{(const void*)yf160u::band::band_k1<YF_K1_NW_>, "band_k1 (sign-free dense epilogue)", YF_K1_NW_ * 64, (size_t)yf160u::band::K1_LDS, yf160u::band::K1_BANDS},
+   {(const void*)yf160u::band::band_k23<8>, "band_k23 (sign-free dense epilogue)", 512, (size_t)yf160u::band::K23_LDS, yf160u::band::K23_BANDS},
+   {(const void*)yf160u::band::band_k4<8>,  "band_k4 (sign-free dense epilogue)", 512,  (size_t)yf160u::band::K4_LDS, 1}},
 };
 static int launch160_banded(yf_engine* e, const yf160::band::Params& prm, hipStream_t s) {
   for (int i = 0; i < 3; ++i) {
-    const BandKernel& k = k_band_fused[i];
+    const BandKernel& k = k_band_fused[e->signless][i];
     const long jobs = prm.n * k.jobs_per_frame;
-    const long full = (long)e->cus * e->band_wgs_per_cu[i];  // persistent grid: every workgroup resident, jobs grid-strided
+    const long full = (long)e->cus * e->band_wgs_per_cu[e->signless][i];  // persistent grid: every workgroup resident, jobs grid-strided
     const unsigned grid = (unsigned)(jobs < full ? jobs : full);
     void* args[] = {(void*)&prm};
     const hipError_t rc = hipLaunchKernel(k.fn, dim3(grid), dim3(k.threads), args, k.lds, s);
@@ -296,7 +329,7 @@ static bool layout_is_the_compiled_plan(const yf_table_index* ix) {
 
 extern "C" {
 
-int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, yf_engine** out, char* err, size_t errlen) {
+int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index* ix, int signless_dense, yf_engine** out, char* err, size_t errlen) {
   auto fail = [&](const std::string& m, int code) { if (err && errlen) snprintf(err, errlen, "%s", m.c_str()); return code; };
   if (!table_blob || !ix || !out) return fail("bad arguments", YF_ENG_ERR_ARG);
   int ndev = 0;
@@ -355,7 +388,8 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
     *wgs_per_cu = occ > 0 ? occ : 1;                          // a property of THIS engine's device (round 5 wrote it into the process-wide kernel table)
     return YF_ENG_OK;
   };
-  for (int i = 0; i < 3; ++i) { const int r = prepare_band(k_band_fused[i], &e->band_wgs_per_cu[i]); if (r != YF_ENG_OK) return r; }
+  for (int u = 0; u < 2; ++u)
+    for (int i = 0; i < 3; ++i) { const int r = prepare_band(k_band_fused[u][i], &e->band_wgs_per_cu[u][i]); if (r != YF_ENG_OK) return r; }
   { const char* ck = getenv("YF_160_CHUNK"); if (ck && atol(ck) > 0) e->chunk160 = atol(ck); }
 #ifdef YF_LAB
   { const char* fl = getenv("YF_LAB_FAIL_LAUNCHES"); if (fl) e->fail_next_launch = atoi(fl); }
@@ -377,20 +411,23 @@ int yf_engine_create(int device, const uint8_t* table_blob, const yf_table_index
   }
   if ((rc = hipHostMalloc(&e->h_small_in, (size_t)ZERO_COPY_N * 9408, hipHostMallocMapped)) != hipSuccess ||
       (rc = hipHostMalloc(&e->h_small_out, (size_t)ZERO_COPY_N * 882, hipHostMallocMapped)) != hipSuccess) return bail(rc, "hipHostMalloc(pinned staging)");
-  e->var = find_variant(2, 8, false);
-  e->var_dump = dump_variant_for(e, 2, 8);
-  e->var_small = find_variant(1, 8, false);
+  e->signless = signless_dense != 0;
+  select_variants(e, 2, 8, true);
   *out = e;
   return YF_ENG_OK;
 }
 
-int yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix) {
+int yf_engine_set_tables(yf_engine* e, const uint8_t* table_blob, const yf_table_index* ix, int signless_dense) {
   if (!e || !table_blob || !ix) return YF_ENG_ERR_ARG;
+  if (!find_variant(e->var->f, e->var->nw, false, false, false, signless_dense != 0)) { e->err = "the configured kernel shape has no build for this rounding"; return YF_ENG_ERR_VARIANT; }
   if (!layout_is_the_compiled_plan(ix)) { e->err = "table blob layout differs from the layout compiled into the kernels"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipDeviceSynchronize());             // launches in flight read the old constants to their end
   HIPCHK(e, hipMemcpy(e->d_tab, table_blob, ix->total_bytes, hipMemcpyHostToDevice));
   e->ix = *ix;
+  const bool automatic = e->var_small != nullptr;
+  e->signless = signless_dense != 0;             // the tables and the kernels that read them change together (the device is idle here)
+  select_variants(e, e->var->f, e->var->nw, automatic);
   return YF_ENG_OK;
 }
 
@@ -435,15 +472,13 @@ int yf_engine_variant_exists(int frames_per_wg, int waves_per_wg) { return find_
 int yf_engine_configure(yf_engine* e, int frames_per_wg, int waves_per_wg) {
   if (!e) return YF_ENG_ERR_ARG;
   if (frames_per_wg < 0) {                       /* back to the automatic choice: throughput shape, small batches one frame per workgroup */
-    e->var = find_variant(2, 8, false); e->var_dump = dump_variant_for(e, 2, 8); e->var_small = find_variant(1, 8, false);
+    select_variants(e, 2, 8, true);
     return YF_ENG_OK;
   }
   const int f = frames_per_wg > 0 ? frames_per_wg : e->var->f, nw = waves_per_wg > 0 ? waves_per_wg : e->var->nw;
-  const Variant* v = find_variant(f, nw, false);
-  if (!v) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
-  e->var = v;
-  e->var_small = nullptr;                        /* an explicitly configured shape runs every batch size */
-  e->var_dump = dump_variant_for(e, f, nw);      /* debug build of the SAME shape, or none: the dump / stage-timing entry points refuse instead of running another shape */
+  if (!find_variant(f, nw, false, false, false, e->signless)) { e->err = "no such kernel variant"; return YF_ENG_ERR_VARIANT; }
+  select_variants(e, f, nw, false);              /* an explicitly configured shape runs every batch size; debug build of the SAME shape, or none: the dump / stage-timing
+                                                    entry points refuse instead of running another shape */
   return YF_ENG_OK;
 }
 
@@ -534,7 +569,7 @@ int yf_engine_run_camera_device(yf_engine* e, const void* d_rgb565, void* d_out,
   if (d_dets && (!d_counts || cap <= 0 || (mode != YF_DECODE_PY && mode != YF_DECODE_FW && mode != YF_DECODE_FW_HOST))) return YF_ENG_ERR_ARG;
   if (((uintptr_t)d_rgb565 & 15) != 0) { e->err = "camera frames must be 16-byte aligned"; return YF_ENG_ERR_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
-  const Variant* v = find_variant(e->var->f, e->var->nw, false, true);
+  const Variant* v = find_variant(e->var->f, e->var->nw, false, true, false, e->signless);
   if (!v) { e->err = "no camera-input build of the configured kernel shape"; return YF_ENG_ERR_VARIANT; }
   const DecodeArgs dec = {d_dets, d_counts, cap, mode, w_scale, h_scale};
   return launch(e, v, d_rgb565, d_out, nullptr, n, (hipStream_t)stream, -1, d_dets ? &dec : nullptr);

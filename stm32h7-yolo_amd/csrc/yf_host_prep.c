@@ -107,18 +107,25 @@ static void build_requant_lut(int t_in, int t_out, uint8_t* lut, int form) {
  *   RQ_SINGLE C64 = off*2M + 2^(31+rs) + 2^63,                        ZR = (Z << rs) - 2^31
  * The last two have no sign term: the 2^63 keeps acc_p*2M + C64 inside [2^61, 2^64) for every accumulator the host admits
  * (|acc| < 2^29), so the multiply-add never carries out, and its 2^31 in the high word is taken back by ZR (32-bit wrap).  The
- * kernels' instruction sequence -- v_mad_u64_u32, v_addc_co_u32, v_ashrrev, v_med3 -- is the same for all three. */
-static void build_c64(long long off, int32_t m, int rs, int form, int z, uint32_t out[2], uint32_t* zr) {
+ * kernels' instruction sequence -- v_mad_u64_u32, v_addc_co_u32, v_ashrrev, v_med3 -- is the same for all three.
+ * FOLD (dense stages of the kernels with the sign-free epilogue, rq4 SIGNLESS: v_mad_u64_u32, v_ashrrev, v_med3): nothing reads the carry or ZR, so ZR rides in
+ * C64's high word and hi32 of the multiply-add is t itself (mod 2^32; no 2^63 needed):
+ *   RQ_UP     C64 = off*2M + 2^31 + (2^(rs-1) + (Z << rs))*2^32,      RQ_SINGLE C64 = off*2M + 2^(31+rs) + (Z << rs)*2^32,      ZR = 0 */
+static void build_c64(long long off, int32_t m, int rs, int form, int z, uint32_t out[2], uint32_t* zr, int fold) {
   unsigned long long c = (unsigned long long)off * (2ull * (unsigned long long)(uint32_t)m);   /* wraps mod 2^64 as intended */
   if (form == RQ_REF) c += (1ull << 31) + ((((unsigned long long)1 << (rs - 1)) - 1ull) << 32);
-  else if (form == RQ_UP) c += (1ull << 31) + (((unsigned long long)1 << (rs - 1)) << 32) + (1ull << 63);
-  else c += ((unsigned long long)1 << (31 + rs)) + (1ull << 63);
+  else if (form == RQ_UP) c += (1ull << 31) + (((unsigned long long)1 << (rs - 1)) << 32);
+  else c += ((unsigned long long)1 << (31 + rs));
+  *zr = (uint32_t)z << rs;
+  if (form != RQ_REF) {
+    if (fold) { c += (unsigned long long)*zr << 32; *zr = 0; }
+    else { c += 1ull << 63; *zr -= 0x80000000u; }
+  }
   out[0] = (uint32_t)c; out[1] = (uint32_t)(c >> 32);
-  *zr = ((uint32_t)z << rs) - (form == RQ_REF ? 0u : 0x80000000u);
 }
 
 /* Channel j of pass p.  abs_w = sum |w| (bounds the accumulator).  Returns 0 or an error code. */
-static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int32_t abs_w, yf_pass* p, int j, int form) {
+static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_t sum_w, int32_t abs_w, yf_pass* p, int j, int form, int fold) {
   const float s_in = t_scale(d->t_in), s_out = t_scale(d->t_out);
   const float s_w = f32_from_bits(d->wscale_bits[ch]);
   int32_t m; int sh;
@@ -132,14 +139,14 @@ static int build_chan(const yf_conv_desc* d, const uint8_t* blob, int ch, int32_
   /* O + sum w*x_raw must stay a positive 32-bit multiplicand and the true accumulator below 2^29 in magnitude */
   if ((bias2 < 0 ? -bias2 : bias2) + 255ll * abs_w >= (1ll << 29)) return YF_PREP_ERR_SHIFT_RANGE;
   p->mult2[j] = (uint32_t)m << 1;
-  build_c64(bias2 - (long long)YF_ACC_OFFSET, m, rs, form, t_zp(d->t_out) + 128, p->c64[j], &p->zr[j]);
+  build_c64(bias2 - (long long)YF_ACC_OFFSET, m, rs, form, t_zp(d->t_out) + 128, p->c64[j], &p->zr[j], fold);
   p->rshift[j] = rs;
   return 0;
 }
 /* padding channel of a pass (cout not a multiple of 4): harmless constants, the byte it produces is never read */
 static void pad_chan(yf_pass* p, int j) {
   p->mult2[j] = ((1u << 30) + 1u) << 1; p->rshift[j] = 1;
-  build_c64(-(long long)YF_ACC_OFFSET, (1 << 30) + 1, 1, RQ_REF, 128, p->c64[j], &p->zr[j]);
+  build_c64(-(long long)YF_ACC_OFFSET, (1 << 30) + 1, 1, RQ_REF, 128, p->c64[j], &p->zr[j], 0);
 }
 
 static const yf_conv_desc* find_conv(int tfl_op) {
@@ -176,14 +183,23 @@ static void conv1_slot(int ky, int kx, int c, int* step, int* slot) {
   *step = pix / 4; *slot = (pix % 4) * 4 + c;
 }
 
+/* 1 if the blob yf_prepare_tables_rounding builds for `rounding` is for the kernels with the sign-free dense epilogue (the engine launches those then) */
+int yf_rounding_signless_dense(int rounding) {
+  if (rounding & YF_ROUND_GENERIC_KERNELS) return 0;
+  return rounding > YF_ROUND_TFLITE_REF && rounding < YF_ROUND_COUNT && form_dense(rounding) != RQ_REF;
+}
+
 int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** out_blob, yf_table_index* ix) {
   return yf_prepare_tables_rounding(weights_blob, blob_bytes, YF_ROUND_TFLITE_REF, out_blob, ix);
 }
 
 int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, int rounding, uint8_t** out_blob, yf_table_index* ix) {
   if (!weights_blob || blob_bytes < YF_WEIGHTS_BLOB_BYTES || !out_blob || !ix) return YF_PREP_ERR_ARGS;
+  const int generic = (rounding & YF_ROUND_GENERIC_KERNELS) != 0;      /* constants for the four-instruction kernels (any rounding) instead of the sign-free dense form */
+  rounding &= ~YF_ROUND_GENERIC_KERNELS;
   if (rounding < 0 || rounding >= YF_ROUND_COUNT) return YF_PREP_ERR_ARGS;
   const int fd = form_dense(rounding), fo = form_other(rounding);      /* dense CONV_2D | DEPTHWISE_CONV_2D, LEAKY_RELU, ADD, QUANTIZE */
+  const int fold = fd != RQ_REF && !generic;                           /* == yf_rounding_signless_dense(rounding): the dense stages' ZR rides in C64 */
   memset(ix, 0, sizeof *ix);
   blob_t b = {0, 0, 0};
   int rc = 0;
@@ -222,7 +238,7 @@ int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, i
       } else {
         memcpy(row, w + (size_t)ch * kk, (size_t)kk);
       }
-      rc = build_chan(d, weights_blob, ch, sum_w, abs_w, (yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3, fd);
+      rc = build_chan(d, weights_blob, ch, sum_w, abs_w, (yf_pass*)(b.p + o->c_off) + ch / 4, ch & 3, fd, fold);
       if (rc) break;
     }
   }
@@ -252,7 +268,7 @@ int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, i
           sum_w += wv; abs_w += wv < 0 ? -wv : wv;
           wd[t * 4 + j] = ((uint32_t)(uint8_t)wv) << (8 * j);      /* byte j of the tap's dword carries channel j */
         }
-        rc = build_chan(d, weights_blob, ch, sum_w, abs_w, cc, j, fo);
+        rc = build_chan(d, weights_blob, ch, sum_w, abs_w, cc, j, fo, 0);
         if (rc) break;
       }
       if (rc) break;
@@ -275,7 +291,7 @@ int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, i
     a->kco = ((int32_t)1 << (a->rso - 1)) + a->zpo * ((int32_t)1 << a->rso);
     if (!rc && a->rso > 20) rc = YF_PREP_ERR_SHIFT_RANGE;
     a->mo2 = (uint32_t)a->mo << 1;
-    if (!rc) build_c64(-(long long)YF_ACC_OFFSET, a->mo, a->rso, fo, a->zpo + 128, a->c64o, &a->zro);
+    if (!rc) build_c64(-(long long)YF_ACC_OFFSET, a->mo, a->rso, fo, a->zpo + 128, a->c64o, &a->zro, 0);
   }
 
   /* ---------------- LUTs ---------------- */

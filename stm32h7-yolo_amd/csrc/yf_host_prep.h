@@ -18,13 +18,16 @@ enum {
 /* Rounding of the requantisation's right shift (the values of yf_requant_rounding, include/yf_network.h). */
 #ifndef YF_ROUND_ENUM
 #define YF_ROUND_ENUM
-enum { YF_ROUND_TFLITE_REF = 0, YF_ROUND_TIES_UP = 1, YF_ROUND_TIES_UP_ALL = 2, YF_ROUND_SINGLE = 3, YF_ROUND_COUNT };
+enum { YF_ROUND_TFLITE_REF = 0, YF_ROUND_TIES_UP = 1, YF_ROUND_TIES_UP_ALL = 2, YF_ROUND_SINGLE = 3, YF_ROUND_COUNT, YF_ROUND_GENERIC_KERNELS = 0x100 };
 #endif
 
 /* Build the device table blob from the caller's weight blob (ST layout, 11304 B).  *out_blob is malloc'd.
  * yf_prepare_tables = rounding YF_ROUND_TFLITE_REF; every rounding gives a blob of the SAME layout (only constants differ). */
 int yf_prepare_tables(const uint8_t* weights_blob, size_t blob_bytes, uint8_t** out_blob, yf_table_index* ix);
 int yf_prepare_tables_rounding(const uint8_t* weights_blob, size_t blob_bytes, int rounding, uint8_t** out_blob, yf_table_index* ix);
+/* `rounding` may carry YF_ROUND_GENERIC_KERNELS.  Without it the dense stages of a rounding that has no sign term get the FOLDED constants of the three-instruction
+ * epilogue (ZR inside C64), and the engine must launch the kernels built for them: */
+int yf_rounding_signless_dense(int rounding);
 int32_t yf_mbqm_form(int32_t x, int32_t mult, int shift, int form);   /* form: 0 reference, 1 ties upward, 2 single rounding */
 
 /* TFLite QuantizeMultiplier / MultiplyByQuantizedMultiplier (exposed for the CPU tests of the host logic). */

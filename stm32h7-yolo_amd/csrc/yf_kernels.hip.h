@@ -187,9 +187,29 @@ typedef unsigned long v4ul __attribute__((ext_vector_type(4)));
 // and the caller finishes with  idx = med3(t >> rshift, 0, 255).  Inline assembly because the carry-out of the multiply-add
 // has no C++ spelling; hipcc does not pad hazards for an asm statement (cdna_hip_programming.md 5.7), so the block that
 // consumes MFMA results opens with the wait states an MFMA result needs before a VALU read (the compiler emits 8 here).
-template <bool AFTER_MFMA>
+//
+// SIGNLESS (round 6): the roundings without a sign term -- the right shift breaks ties UPWARD (ruy's vector kernels, ARM srshl) or the product is rounded ONCE
+// (ruy's portable path): yf_network_set_requant_rounding -- need neither the carry nor a separate ZR: the host folds ZR into C64's high word (yf_host_prep.c,
+// build_c64), hi32 of the multiply-add IS t, and the epilogue is THREE VALU instructions per output: v_mad_u64_u32, v_ashrrev, v_med3.  The kernels of namespace
+// yfu / yf160u (yf_engine.hip) build their DENSE convolutions this way (DENSE_SIGNLESS below); depthwise convolutions and the residual adds keep the four-instruction
+// form, which serves every rounding (under "ties upward on the dense convs" they keep TFLite's reference rounding, which has the sign term).
+template <bool AFTER_MFMA, bool SIGNLESS = false>
 __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, int (&t)[4]) {
   v2u d0, d1, d2, d3;
+  if constexpr (SIGNLESS) {     // the carry-out lands in vcc and is not read: no SGPR pairs held for it
+    (void)zr;
+#define YF_RQ3_MADS "v_mad_u64_u32 %0, vcc, %4, %8, %12\n\tv_mad_u64_u32 %1, vcc, %5, %9, %13\n\t" \
+                    "v_mad_u64_u32 %2, vcc, %6, %10, %14\n\tv_mad_u64_u32 %3, vcc, %7, %11, %15"
+#define YF_RQ3_OPS : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) \
+                   : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(m2[0]), "v"(m2[1]), "v"(m2[2]), "v"(m2[3]), \
+                     "s"(c64[0]), "s"(c64[1]), "s"(c64[2]), "s"(c64[3]) : "vcc"
+    if constexpr (AFTER_MFMA) asm("s_nop 7\n\ts_nop 1\n\t" YF_RQ3_MADS YF_RQ3_OPS);
+    else asm(YF_RQ3_MADS YF_RQ3_OPS);
+#undef YF_RQ3_MADS
+#undef YF_RQ3_OPS
+    t[0] = (int)d0[1]; t[1] = (int)d1[1]; t[2] = (int)d2[1]; t[3] = (int)d3[1];
+    return;
+  }
   unsigned long cy0, cy1, cy2, cy3;
 #define YF_RQ4_MADS "v_mad_u64_u32 %0, %4, %8, %12, %16\n\tv_mad_u64_u32 %1, %5, %9, %13, %17\n\t" \
                     "v_mad_u64_u32 %2, %6, %10, %14, %18\n\tv_mad_u64_u32 %3, %7, %11, %15, %19"
@@ -200,14 +220,6 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
   else asm(YF_RQ4_MADS YF_RQ4_OPS);
 #undef YF_RQ4_MADS
 #undef YF_RQ4_OPS
-#if defined(YF_LAB) && defined(YF_WHATIF_RQ3)
-  // Timing-only what-if (laboratory, WRONG results with the shipped tables; profiles/r06_ties_up_epilogue_ab.txt): the epilogue WITHOUT its v_addc_co_u32.  A rounding
-  // with no sign term (ties upward, single rounding: yf_host_prep.c) needs neither the carry nor a separate ZR -- ZR folds into C64's high word -- so a kernel built
-  // for those roundings alone would requantise in three VALU instructions per output.  The product serves every rounding with the four-instruction form.
-  (void)zr; (void)cy0; (void)cy1; (void)cy2; (void)cy3;
-  t[0] = (int)d0[1]; t[1] = (int)d1[1]; t[2] = (int)d2[1]; t[3] = (int)d3[1];
-  return;
-#endif
   asm("v_addc_co_u32_e64 %0, vcc, %4, %8, %12\n\tv_addc_co_u32_e64 %1, vcc, %5, %9, %13\n\t"
       "v_addc_co_u32_e64 %2, vcc, %6, %10, %14\n\tv_addc_co_u32_e64 %3, vcc, %7, %11, %15"
       : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
@@ -216,18 +228,30 @@ __device__ __forceinline__ void rq4(const v4i acc, const v4u m2, const v4u zr, c
       : "vcc");
 }
 // the four requantised channels of a pass as LUT indices / unsigned bytes (q + 128)
-template <bool AFTER_MFMA>
+template <bool AFTER_MFMA, bool SIGNLESS = false>
 __device__ __forceinline__ void requant4(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[4]) {
   int t[4];
-  rq4<AFTER_MFMA>(acc, m2, zr, c64, t);
+  rq4<AFTER_MFMA, SIGNLESS>(acc, m2, zr, c64, t);
 #pragma unroll
   for (int j = 0; j < 4; ++j) idx[j] = min(max(t[j] >> rs[j], 0), 255);     // v_ashrrev, v_med3_i32
 }
 // the same for TWO channels: the last pass of a layer with 4k + 2 output channels (6, 18) carries two padding channels whose
 // requantisation, LUT reads and packing would be thrown away
-template <bool AFTER_MFMA>
+template <bool AFTER_MFMA, bool SIGNLESS = false>
 __device__ __forceinline__ void requant2(const v4i acc, const v4u m2, const v4u zr, const v4ul c64, const v4i rs, int (&idx)[2]) {
   v2u d0, d1;
+  if constexpr (SIGNLESS) {
+    (void)zr;
+    if constexpr (AFTER_MFMA)
+      asm("s_nop 7\n\ts_nop 1\n\tv_mad_u64_u32 %0, vcc, %2, %4, %6\n\tv_mad_u64_u32 %1, vcc, %3, %5, %7"
+          : "=&v"(d0), "=&v"(d1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]) : "vcc");
+    else
+      asm("v_mad_u64_u32 %0, vcc, %2, %4, %6\n\tv_mad_u64_u32 %1, vcc, %3, %5, %7"
+          : "=&v"(d0), "=&v"(d1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]) : "vcc");
+    idx[0] = min(max((int)d0[1] >> rs[0], 0), 255);
+    idx[1] = min(max((int)d1[1] >> rs[1], 0), 255);
+    return;
+  }
   unsigned long cy0, cy1;
   int t0, t1;
   if constexpr (AFTER_MFMA)
@@ -236,12 +260,6 @@ __device__ __forceinline__ void requant2(const v4i acc, const v4u m2, const v4u 
   else
     asm("v_mad_u64_u32 %0, %2, %4, %6, %8\n\tv_mad_u64_u32 %1, %3, %5, %7, %9"
         : "=&v"(d0), "=&v"(d1), "=&s"(cy0), "=&s"(cy1) : "v"(acc[0]), "v"(acc[1]), "v"(m2[0]), "v"(m2[1]), "s"(c64[0]), "s"(c64[1]));
-#if defined(YF_LAB) && defined(YF_WHATIF_RQ3)
-  (void)zr; (void)cy0; (void)cy1;
-  idx[0] = min(max((int)d0[1] >> rs[0], 0), 255);
-  idx[1] = min(max((int)d1[1] >> rs[1], 0), 255);
-  return;
-#endif
   asm("v_addc_co_u32_e64 %0, vcc, %2, %4, %6\n\tv_addc_co_u32_e64 %1, vcc, %3, %5, %7"
       : "=&v"(t0), "=&v"(t1) : "v"(zr[0]), "v"(zr[1]), "v"(d0[1]), "v"(d1[1]), "s"(cy0), "s"(cy1) : "vcc");
   idx[0] = min(max(t0 >> rs[0], 0), 255);
@@ -253,6 +271,11 @@ __device__ __forceinline__ uint32_t join2(uint32_t b0, uint32_t b1) {
   return v;
 }
 constexpr int ACC0 = YF_ACC_OFFSET;            // MFMA C operand: the inline constant 2.0 (no v_mov)
+#ifdef YF_RQ3_DENSE
+constexpr bool DENSE_SIGNLESS = true;          // this namespace's dense convolutions requantise in the sign-free three-instruction form (rq4)
+#else
+constexpr bool DENSE_SIGNLESS = false;
+#endif
 // A register with no particular content and no instruction behind it: the k-slots of an MFMA B operand whose weights are
 // zero may hold anything (integer arithmetic: 0 * x = 0), so they are not cleared.
 __device__ __forceinline__ int any_value() { int u; asm volatile("" : "=v"(u)); return u; }
@@ -820,12 +843,12 @@ YF_STAGE_FN void dense2_stage(char* frames, char* out_all, const uint8_t* __rest
           if (half) {
             if constexpr (HALF_L) {
               int idx2[2];
-              requant2<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx2);
+              requant2<true, DENSE_SIGNLESS>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx2);
               epilogue2_half<EPI, LUT_ID, LA>(dstpix, addpix, t * 4, idx2, ad);
             }
           } else {
             int idx[4];
-            requant4<true>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
+            requant4<true, DENSE_SIGNLESS>(acc, pv[t].m2, pv[t].zr, ksr[t].c64, ksr[t].rs, idx);
             epilogue2<EPI, LUT_ID, LA, STASH_LUT>(dstpix, addpix, headpix, t * 4, ps * 4, idx, ad, stashpix);
           }
         }
@@ -895,7 +918,7 @@ YF_STAGE_FN void conv1_2_stage(char* frames, const uint8_t* __restrict__ tab, in
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][1], b1, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ps][2], b2, acc, 0, 0, 0);
       int idx[4];
-      requant4<true>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
+      requant4<true, DENSE_SIGNLESS>(acc, pv[ps].m2, pv[ps].zr, k.c64, k.rs, idx);
       epilogue2<EPI_LUT, YF_L_LEAKY2, 0>(dstpix, nullptr, nullptr, 4 * ps, 0, idx, ad);
     }
   }

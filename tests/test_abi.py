@@ -230,7 +230,7 @@ def test_frozen_kernels_are_instruction_identical(yf):
     import sys
     yf.load()                                     # builds the library if it is stale
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hashes.py"), "--check"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "12 kernels: instruction streams identical" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "12 of 12 frozen kernels: instruction streams identical" in r.stdout, r.stdout + r.stderr
 
 
 def test_handle_and_param_validation(yf):

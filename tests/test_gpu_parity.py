@@ -259,15 +259,17 @@ def test_baseline_config2_batch_4096(network, oracle, golden, torch_cuda):
 ROUNDING_TO_VARIANT = {0: 0, 1: 1, 2: 2, 3: 4}
 
 
-@pytest.mark.parametrize("rounding", [1, 2, 3])
+@pytest.mark.parametrize("rounding", [1, 2, 3, 0x101, 0x103])
 def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, oracle, golden, torch_cuda, rounding):
-    """yf_network_set_requant_rounding (round 6): the SAME kernels with the constants of another published rounding of TFLite's requantisation
-    -- ties upward on the dense convs (ruy, what tflite_prediction.py:23's default resolver most likely runs), ties upward everywhere, single
-    rounding on the dense convs -- bit-exact against the oracle's statement of that variant: the six golden frames, the reference's 27 sample
-    images, 4096 seeded frames (BASELINE configs[1]'s input) with the fused decode, every fused stage through the dump build, a 160x160 block,
-    ai_network_run on host arrays.  Switching back restores the reference rounding bit for bit."""
+    """yf_network_set_requant_rounding (round 6): another published rounding of TFLite's requantisation -- ties upward on the dense convs (ruy, what
+    tflite_prediction.py:23's default resolver most likely runs), ties upward everywhere, single rounding on the dense convs -- bit-exact against the
+    oracle's statement of that variant: the six golden frames, the reference's 27 sample images, 4096 seeded frames (BASELINE configs[1]'s input) with
+    the fused decode, every fused stage through the dump build, a 160x160 block, ai_network_run on host arrays (small batches: the one-frame-per-
+    workgroup shape).  By default these roundings run the second kernel set, whose dense convolutions requantise in three instructions (no sign term:
+    no carry, ZR folded into C64); 0x100 | rounding (YF_ROUND_GENERIC_KERNELS) keeps the reference rounding's four-instruction kernels with that
+    rounding's constants -- same results.  Switching back restores the reference rounding, and its kernels, bit for bit."""
     torch = torch_cuda
-    variant = ROUNDING_TO_VARIANT[rounding]
+    variant = ROUNDING_TO_VARIANT[rounding & 0xFF]
     real = np.fromfile(os.path.join(ROOT, "tests", "golden", "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
     x = rnd(1, 4096)
     x[:6] = golden["inputs"]
@@ -279,6 +281,7 @@ def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, orac
     try:
         network.set_requant_rounding(rounding)
         assert network.requant_rounding == rounding
+        assert ("sign-free dense epilogue" in network.kernel_name) == (rounding < 0x100) and ("sign-free" in network.kernel_name_for(5)) == (rounding < 0x100)
         d_in = torch.from_numpy(x).cuda()
         d_out = torch.zeros((4096, 7, 7, 18), dtype=torch.int8, device="cuda")
         cap = 4
@@ -320,6 +323,7 @@ def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, orac
         assert ei.value.type == 0x14 and network.requant_rounding == rounding               # AI_ERROR_INVALID_PARAM latched, nothing changed
     finally:
         network.set_requant_rounding(0)
+    assert "sign-free" not in network.kernel_name
     network.run_device(d_in.data_ptr(), d_out.data_ptr(), 4096)
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), ref0)
@@ -333,11 +337,11 @@ def test_requant_rounding_from_the_environment_steers_an_unmodified_caller(oracl
             "x = np.fromfile(%r, np.int8).reshape(-1, 56, 56, 3)\n"
             "try:\n    net = yf.Network(device=0).init()\nexcept Exception as e:\n    print('INIT FAILED', e); sys.exit(3)\n"
             "print(net.requant_rounding); sys.stdout.flush(); sys.stdout.buffer.write(net.run(x).tobytes())\n") % (ROOT, os.path.join(ROOT, "tests", "golden", "golden_inputs.bin"))
-    for word, variant in (("ties_up", 1), ("ref", 0)):
+    for word, variant, value in (("ties_up", 1, 1), ("ties_up+generic", 1, 0x101), ("ref", 0, 0)):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=dict(os.environ, YF_REQUANT_ROUNDING=word))
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         head, _, raw = r.stdout.partition(b"\n")
-        assert int(head) == {"ties_up": 1, "ref": 0}[word]
+        assert int(head) == value
         assert np.array_equal(np.frombuffer(raw, np.int8).reshape(-1, 7, 7, 18), oracle.run(golden["inputs"], variant=variant))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=dict(os.environ, YF_REQUANT_ROUNDING="nearest"))
     assert r.returncode == 3 and b"YF_REQUANT_ROUNDING" in r.stdout

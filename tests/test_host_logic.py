@@ -313,6 +313,9 @@ def test_add_tables(prep, oracle, pack):
 ROUNDINGS = {1: ("ties_up", 1, 1, 0), 2: ("ties_up_all", 2, 1, 1), 3: ("single", 4, 2, 0)}
 
 
+GENERIC = 0x100          # YF_ROUND_GENERIC_KERNELS: constants for the four-instruction kernels instead of the sign-free dense form
+
+
 def _prep_rounding(prep, rounding):
     lib = prep["lib"]
     lib.yf_prepare_tables_rounding.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Index)]
@@ -322,10 +325,18 @@ def _prep_rounding(prep, rounding):
     return ix, bytes((ctypes.c_uint8 * ix.total_bytes).from_address(out.value))
 
 
-def _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, zp_out, abs_w, rng, mode):
+def _device_requant3(dot, mult, rs, c64):
+    """The sign-free epilogue of the kernels in namespaces yfu / yf160u (yf_kernels.hip.h, rq4 SIGNLESS): t = hi32(acc_p * 2M + C64) as a signed
+    32-bit word (v_mad_u64_u32; the carry-out is not read, ZR is inside C64), y = t >> rs (v_ashrrev)."""
+    t = (((O + dot) * (2 * mult) + c64) >> 32) & 0xFFFFFFFF
+    t = t - (1 << 32) if t >= (1 << 31) else t
+    return t >> rs
+
+
+def _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, zp_out, abs_w, rng, mode, folded=False):
     """the kernel's four instructions with a non-reference rounding's constants == the oracle's statement of that rounding + zp_out + 128, on
     random accumulators and on both signs of every kind of tie; the multiply-add must never carry out (its carry is TFLite's sign term in the
-    reference form and has to stay 0 in the others)"""
+    reference form and has to stay 0 in the others).  folded: the three-instruction form (ZR inside C64, ZR field 0)."""
     lim = 255 * abs_w
     dots = np.concatenate([rng.integers(-lim, lim + 1, 200), [0, 1, -1, lim, -lim, -bias2, -bias2 - 1, -bias2 + 1]])
     half = 1 << (rs - 1)
@@ -333,22 +344,31 @@ def _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, zp_out, abs_w
         target = k * (1 << rs) + half
         a = int(round(target * 2.0**31 / mult))
         dots = np.concatenate([dots, [a - bias2 + d for d in (-2, -1, 0, 1, 2)], [-a - bias2 + d for d in (-2, -1, 0, 1, 2)]])
-    assert zr == (((zp_out + 128) << rs) - (1 << 31)) % (1 << 32)
+    assert zr == (0 if folded else (((zp_out + 128) << rs) - (1 << 31)) % (1 << 32))
     for dot in dots:
         dot = int(dot)
         acc_p = O + dot
         n = acc_p * (2 * mult) + c64
+        want = oracle.lib.yfo_mbqm_mode(dot + bias2, mult, -rs, mode) + zp_out + 128
+        if folded:
+            assert 0 < acc_p < (1 << 32) and _device_requant3(dot, mult, rs, c64) == want, (dot, bias2, mult, rs, mode)
+            continue
         assert 0 < acc_p < (1 << 32) and (1 << 61) <= n < (1 << 64), "no carry-out"
-        assert _device_requant(dot, mult, rs, zr, c64) == oracle.lib.yfo_mbqm_mode(dot + bias2, mult, -rs, mode) + zp_out + 128, (dot, bias2, mult, rs, mode)
+        assert _device_requant(dot, mult, rs, zr, c64) == want, (dot, bias2, mult, rs, mode)
 
 
+@pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("rounding", sorted(ROUNDINGS))
-def test_rounding_modes_are_other_constants_in_the_same_layout(prep, oracle, pack, rounding):
+def test_rounding_modes_are_other_constants_in_the_same_layout(prep, oracle, pack, rounding, generic):
     """yf_network_set_requant_rounding: every rounding is a table blob of the SAME layout (the kernels address it at compiled-in offsets) whose
     weights are the reference blob's, and whose {C64, ZR} per channel, byte LUTs and add tables state the rounding the oracle's variant states:
-    dense convs by the variant's dense form, depthwise convs / LEAKY_RELU / QUANTIZE / ADD by its form for everything else."""
+    dense convs by the variant's dense form, depthwise convs / LEAKY_RELU / QUANTIZE / ADD by its form for everything else.  The dense stages'
+    constants come in two forms: FOLDED (default: ZR inside C64, for the kernels whose dense epilogue is three instructions -- the engine launches
+    those, yf_rounding_signless_dense) and, with YF_ROUND_GENERIC_KERNELS, the form the four-instruction kernels take for any rounding."""
     name, variant, m_dense, m_other = ROUNDINGS[rounding]
-    ix, tab = _prep_rounding(prep, rounding)
+    ix, tab = _prep_rounding(prep, rounding | (GENERIC if generic else 0))
+    lib = prep["lib"]
+    assert lib.yf_rounding_signless_dense(rounding) == 1 and lib.yf_rounding_signless_dense(rounding | GENERIC) == 0 and lib.yf_rounding_signless_dense(0) == 0
     ix0, tab0 = prep["ix"], prep["tab"]
     skip = Index.add.offset, Index.add.offset + Index.add.size                     # the add records carry rounding-dependent constants (checked below)
     assert bytes(ix)[:skip[0]] == bytes(ix0)[:skip[0]] and bytes(ix)[skip[1]:] == bytes(ix0)[skip[1]:] and len(tab) == len(tab0)
@@ -366,11 +386,12 @@ def test_rounding_modes_are_other_constants_in_the_same_layout(prep, oracle, pac
             assert (mult, rs) == _chan(tab0, d.c_off, ch)[:2]
             wf = w[ch].reshape(-1)
             bias2 = int(bt["data"][ch]) - T[t_in]["zp"] * int(wf.sum())
+            tail = (1 << 63) if generic else (((to["zp"] + 128) << rs) << 32)
             if m_dense == 1:
-                assert c64 == ((bias2 - O) * 2 * mult + (1 << 31) + ((1 << (rs - 1)) << 32) + (1 << 63)) % (1 << 64)
+                assert c64 == ((bias2 - O) * 2 * mult + (1 << 31) + ((1 << (rs - 1)) << 32) + tail) % (1 << 64)
             else:
-                assert c64 == ((bias2 - O) * 2 * mult + (1 << (31 + rs)) + (1 << 63)) % (1 << 64)
-            _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(wf).sum()), rng, m_dense)
+                assert c64 == ((bias2 - O) * 2 * mult + (1 << (31 + rs)) + tail) % (1 << 64)
+            _check_requant_identity_mode(oracle, bias2, mult, rs, zr, c64, to["zp"], int(np.abs(wf).sum()), rng, m_dense, folded=not generic)
             n_changed += 1
     for s, op in enumerate(DW_OPS):
         o, d = ops[op], ix.dw[s]
@@ -430,8 +451,10 @@ def test_prepare_rejects_bad_arguments(prep):
     assert lib.yf_prepare_tables(None, 11304, ctypes.byref(out), ctypes.byref(ix)) == 1
     lib.yf_prepare_tables_rounding.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Index)]
     blob = (ctypes.c_uint8 * 11304).in_dll(lib, "yf_weights_blob")
-    for bad in (-1, 4, 99):
+    for bad in (-1, 4, 99, 0x104, 0x200):
         assert lib.yf_prepare_tables_rounding(blob, 11304, bad, ctypes.byref(out), ctypes.byref(ix)) == 1
+    assert lib.yf_prepare_tables_rounding(blob, 11304, 0x100, ctypes.byref(out), ctypes.byref(ix)) == 0      # reference rounding, generic kernels: the default blob
+    assert bytes((ctypes.c_uint8 * ix.total_bytes).from_address(out.value)) == prep["tab"]
 
 
 def test_fp16_prefetch_wait_count_matches_the_isa(tmp_path):

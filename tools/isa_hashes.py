@@ -35,14 +35,25 @@ def hashes(lib):
             subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
                                   stderr=subprocess.DEVNULL)
             dis += subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
-    out, cur = {}, None
+    out, cur, getpc = {}, None, -9
     for ln in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:", ln)
         if m:
             cur = m.group(1)
             out[cur] = []
         elif cur and ln[:1] in " \t" and ln.strip():           # instruction lines are indented; "file format" / "Disassembly of section" lines are not
-            out[cur].append(re.sub(r"\s*//.*$", "", ln.strip()))
+            ins = re.sub(r"\s*//.*$", "", ln.strip())
+            # the address of a global (decode tables, ...) is formed pc-relatively: s_getpc_b64, then s_add_u32 / s_addc_u32 with the RESOLVED distance as a literal.
+            # That literal moves whenever another kernel is added to the code object; it is a relocation, not an instruction of the kernel: normalised.
+            if ins.startswith("s_getpc_b64"):
+                getpc = len(out[cur])
+            elif len(out[cur]) - getpc <= 4 and re.match(r"s_addc?_u32 s\d+, s\d+, 0x[0-9a-f]+$", ins):
+                ins = re.sub(r"0x[0-9a-f]+$", "<pc-relative>", ins)
+            out[cur].append(ins)
+    for name, body in out.items():                          # what follows a kernel's last s_endpgm is alignment padding up to the next kernel (none behind the last one)
+        ends = [i for i, ins in enumerate(body) if ins.startswith("s_endpgm")]
+        if ends:
+            del body[ends[-1] + 1:]
     return sorted((name, hashlib.sha256("\n".join(body).encode()).hexdigest()[:16], len(body)) for name, body in out.items() if name.startswith("_Z"))
 
 
@@ -52,9 +63,12 @@ def main():
     lines = [f"{h} {n} {name}" for name, h, n in hashes(lib)]
     if "--check" in sys.argv:
         want = [ln.strip() for ln in open(FROZEN) if ln.strip() and not ln.startswith("#")]
-        diff = sorted(set(lines) ^ set(want))
-        print("\n".join(diff) if diff else f"{len(lines)} kernels: instruction streams identical to {os.path.relpath(FROZEN, ROOT)}")
-        sys.exit(1 if diff else 0)
+        missing = sorted(set(want) - set(lines))            # a frozen kernel that is gone or disassembles differently
+        extra = sorted(set(lines) - set(want))              # kernels added since (round 6: the second kernel set with the sign-free dense epilogue)
+        if missing:
+            print("CHANGED or missing:\n" + "\n".join(missing) + "\nnow:\n" + "\n".join(ln for ln in lines if ln.split()[2] in {m.split()[2] for m in missing}))
+        print(f"{len(want) - len(missing)} of {len(want)} frozen kernels: instruction streams identical to {os.path.relpath(FROZEN, ROOT)}; {len(extra)} kernels beside them")
+        sys.exit(1 if missing else 0)
     print("\n".join(lines))
 
 
