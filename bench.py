@@ -38,9 +38,9 @@ VALU_CYCLES_PER_INSTR = 4.0                  # issue cost of a wave64 VALU instr
 A160_BYTES_PER_FRAME = 160 * 160 * 3 + 20 * 20 * 18          # 84 000 B: algorithmic bytes of the 160x160 variant
 FP16_BYTES_PER_FRAME = 56 * 56 * 3 * 2 + 7 * 7 * 18 * 4      # fp16 frame in, fp32 logits out
 CAMERA_BYTES_PER_FRAME = 112 * 112 * 2 + 7 * 7 * 18          # RGB565 camera frame in, int8 head out (the prepared 56x56 frame never exists in HBM)
-PROFILE_CAMERA = "profiles/r05_camera/summary.json"
-PROFILE_160 = "profiles/r05_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
-PROFILE_FP16 = "profiles/r05_fp16/summary.json"              # stamped with the build id they were taken on
+PROFILE_CAMERA = "profiles/r06_camera/summary.json"
+PROFILE_160 = "profiles/r06_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
+PROFILE_FP16 = "profiles/r06_fp16/summary.json"              # stamped with the build id they were taken on
 
 
 def kernel_source_hash():
@@ -101,13 +101,31 @@ def cpu_model():
 ROUNDINGS = {"ref": (0, 0), "ties_up": (1, 1), "ties_up_all": (2, 2), "single": (3, 4), "ties_up+generic": (0x101, 1)}   # +generic: that rounding on the reference rounding's kernels
 
 
+def cpu_quota_cores():
+    """CPU time this process's cgroup may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable.  A one-GPU box of the pool
+    shows all of the host's cores in the affinity mask and limits the TIME: threads beyond the quota only take turns."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(x, got_heads, variant=0):
     """The oracle (scalar C restatement, kind "port") timed on this box's host cores on the SAME 4096 frames -- about 2 s of CPU work in all;
     also the in-bench parity check of the GPU result.  Three figures, each the MEDIAN of 3 repetitions ("(i) single thread and
     (ii) all cores"), each with its thread count:
       value / cores                 16 threads: the CPU share of a ONE-GPU box of this pool (gpurun: "16 for one GPU"), what rounds 1-5 reported
       all_cores_images_per_s        one thread per core this process may run on (affinity_cores: 256 on the driver's box) -- north_star's "the GPU
-                                    box's own cores (core count stated)"
+                                    box's own cores (core count stated)".  On a one-GPU box of this pool it comes out BELOW the 16-thread figure (13.6 k
+                                    against 18.9 k): the affinity mask shows the host's 256 cores, the cgroup grants the CPU time of a share of them
+                                    (cpu_quota_cores, reported when readable), and 256 threads then take turns
       single_thread_images_per_s    one thread, on 512 of the frames
     with the CPU model and the box's core count beside them.  Returns (dict, mismatching head bytes, the oracle's heads)."""
     from oracle.oracle import Oracle
@@ -133,6 +151,7 @@ def cpu_baseline(x, got_heads, variant=0):
                        f"single thread: {one:.0f} images/s",
                 best_images_per_s=round(best, 1), all_cores_images_per_s=round(all_rate, 1), all_cores_threads=affinity,
                 all_cores_best_images_per_s=round(all_best, 1), affinity_cores=affinity, box_cores=os.cpu_count(), cpu_model=cpu_model(),
+                cpu_quota_cores=cpu_quota_cores(),
                 single_thread_images_per_s=round(one, 1)), mism, ref
 
 

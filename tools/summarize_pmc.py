@@ -18,11 +18,17 @@ def main():
         rows = [r for r in csv.DictReader(open(f)) if headline(r["Kernel_Name"])]
         if rows:
             full = max(int(r["Grid_Size_X"]) for r in rows)
-            iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if int(r["Grid_Size_X"]) == full)
+            iv3 = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "")) for r in rows if int(r["Grid_Size_X"]) == full)
+            iv = [(b, e) for b, e, _ in iv3]
+            sid = [q for _, _, q in iv3]
             # bench.py alternates the timed steps between two streams: those launches OVERLAP their neighbours (a launch's ramp / drain runs beside the next
             # step's), so their own durations are longer than the step they cost.  The kernel's duration ALONE is that of the launches that overlap nobody
             # (clock settle, the kernel-time region: one stream, back to back) -- what roofline.kernel_ms of the line is compared with.
-            lap = [(i > 0 and iv[i][0] < iv[i - 1][1]) or (i + 1 < len(iv) and iv[i + 1][0] < iv[i][1]) for i in range(len(iv))]
+            # (an overlap counts when the neighbour runs on ANOTHER stream, or lasts more than a microsecond: back-to-back launches of ONE stream show the next
+            # launch's start a few hundred nanoseconds before the previous one's end stamp -- round 6's first summary filed 728 such launches under "overlapped")
+            def laps(i, j):
+                return iv[j][0] < iv[i][1] and (sid[i] != sid[j] or iv[i][1] - iv[j][0] > 1000)
+            lap = [(i > 0 and laps(i - 1, i)) or (i + 1 < len(iv) and laps(i, i + 1)) for i in range(len(iv))]
             alone = [e - b for (b, e), o in zip(iv, lap) if not o]
             over = [e - b for (b, e), o in zip(iv, lap) if o]
             d = alone or [e - b for b, e in iv]
