@@ -1056,7 +1056,19 @@ def test_interpreter_mirror(oracle, golden, network):
     assert [tuple(int(v) for v in b) for b in boxes] == [(d["x1"], d["y1"], d["x2"], d["y2"]) for d in want]
     with pytest.raises(Exception, match="superseded"):       # the mirror owns the library's single instance now
         network.run_device(0, 0, 1)
+    # tf.lite.Interpreter's experimental_op_resolver_type selects the kernel set, here the rounding: BUILTIN_REF = the oracle's definition,
+    # BUILTIN (the optimized kernels: ruy on the dense convs) = ties upward, stated by the oracle's variant 1; AUTO = the library's default (reference)
+    for resolver, variant in (("BUILTIN_REF", 0), ("BUILTIN", 1), ("AUTO", 0)):
+        it = ip.Interpreter(model_path="yoloface_int8.tflite", experimental_op_resolver_type=resolver)
+        it.allocate_tensors()
+        it.resize_tensor_input(0, [6, 56, 56, 3])
+        it.set_tensor(0, golden["inputs"])
+        it.invoke()
+        assert np.array_equal(it.get_tensor(100), oracle.run(golden["inputs"], variant=variant)), resolver
+    with pytest.raises(ValueError):
+        ip.Interpreter(experimental_op_resolver_type="XNNPACK")
     network.reclaim().init()  # hand the singleton back to the session fixture for the later tests
+    assert network.requant_rounding == 0
 
 
 @pytest.mark.parametrize("binary", ["abi_ref_caller", "abi_ref_runtime_caller"])
