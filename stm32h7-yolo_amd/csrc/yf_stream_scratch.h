@@ -25,13 +25,18 @@
 //   - release_stream() gives a stream's region back at once (yf_network_release_stream);
 //   - hipStreamPerThread is one handle value for a different stream per host thread: the key is (handle, thread), and such a region always
 //     records its event.
-// A stream is identified by its handle VALUE.  A host may drop a stream without release_stream() only once its launches have completed
-// (it synchronised the stream or consumed the results): the runtime may hand the same handle value to a new stream, and a launch of the
-// old one still in flight would then share the region with the new one's.
+// STREAM IDENTITY (round 6).  This runtime hands the SAME handle value to the next stream as soon as one is destroyed (tools/probe/stream_id_probe.py: forty
+// create / destroy cycles, one handle value), so the handle alone cannot tell a stream from its successor -- a launch of a destroyed stream still in flight
+// and a new stream would share a region (rounds 3-5: a documented contract, "drop a stream only once its launches have completed").  Where the runtime
+// exports hipStreamGetId (ROCm 7.1's libamdhip64; resolved with dlsym: PyTorch 2.10's bundled runtime does not have it) a region is keyed by (handle, thread,
+// stream ID): ids are unique over the life of the process, a successor under the same handle value is a NEW stream and gets a region of its own, and the
+// predecessor's region changes hands like any other -- when its event has completed, or through the all-busy path.  Without the call the key is the handle
+// value and the contract stands.
 // The first launch on a new stream may allocate (a blocking hipMalloc): INTEGRATION.md says so.  The map is mutex-protected.
 #ifndef YF_STREAM_SCRATCH_H
 #define YF_STREAM_SCRATCH_H
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -41,7 +46,8 @@
 struct yf_stream_scratch {
   size_t max_regions = 8;                          // the owner may lower it (the 160x160 arena: 4)
   // dirty: launched on without an event; acquired: handed out by get(), its launch not yet marked
-  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired; };
+  struct Region { hipStream_t stream; size_t thread; char* ptr; size_t bytes; hipEvent_t done; bool marked; unsigned long long stamp; bool dirty; bool acquired;
+                  unsigned long long uid; bool has_uid; };        // uid: hipStreamGetId of the owner (has_uid: the runtime has the call)
   std::mutex mu;
   std::condition_variable cv_marked;               // a mark() or release: somebody waiting in get() for a region that is not acquired may look again
   std::vector<Region> regions;
@@ -67,7 +73,22 @@ struct yf_stream_scratch {
   };
 
   static size_t thread_key(hipStream_t s) { return s == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0; }
-  Region* find(hipStream_t s, size_t tk) { for (Region& r : regions) if (r.stream == s && r.thread == tk) return &r; return nullptr; }
+  // the runtime's id of a LIVE stream (the caller's own: never a stored handle), false where the runtime has no hipStreamGetId
+  static bool stream_uid(hipStream_t s, unsigned long long* id) {
+#ifdef YF_FAKE_HIP_STREAM_ID                      /* the CPU test's fake runtime (tests/csrc/fake_hip) */
+    return fake_hip::has_stream_id() && hipStreamGetId(s, id) == hipSuccess;
+#else
+    typedef hipError_t (*fn_t)(hipStream_t, unsigned long long*);
+    static const fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, "hipStreamGetId");
+    return fn != nullptr && fn(s, id) == hipSuccess;
+#endif
+  }
+  Region* find(hipStream_t s, size_t tk) {
+    unsigned long long uid = 0;
+    const bool has = stream_uid(s, &uid);
+    for (Region& r : regions) if (r.stream == s && r.thread == tk && (!has || !r.has_uid || r.uid == uid)) return &r;
+    return nullptr;
+  }
   static bool idle(const Region& r) { return !r.acquired && !r.dirty && (!r.marked || hipEventQuery(r.done) == hipSuccess); }
   // Region of at least `bytes` bytes for a launch on `s`; the caller launches and then calls lease.mark().
   hipError_t get(hipStream_t s, size_t bytes, Lease* lease) {
@@ -81,7 +102,7 @@ struct yf_stream_scratch {
     while (!r) {
       for (Region& c : regions) if (idle(c)) { r = &c; break; }                       // an idle region changes hands
       if (!r && regions.size() < max_regions) {
-        Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false};
+        Region n = {s, tk, nullptr, 0, nullptr, false, 0, false, false, 0, false};
         const hipError_t rc = hipEventCreateWithFlags(&n.done, hipEventDisableTiming);
         if (rc != hipSuccess) return rc;
         regions.push_back(n);
@@ -99,6 +120,7 @@ struct yf_stream_scratch {
         if (rc != hipSuccess) return rc;
       }
       r->stream = s; r->thread = tk; r->marked = false; r->dirty = false;
+      r->has_uid = stream_uid(s, &r->uid);
     }
     if (r->bytes < bytes) {                                                           // grow: hipFree waits for the device, nothing still reads the old block
       if (r->ptr) (void)hipFree(r->ptr);
@@ -129,10 +151,10 @@ struct yf_stream_scratch {
   // the caller is done with `s` (about to destroy it): its region is freed once its last launch has completed
   hipError_t release_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(mu);
-    const size_t tk = thread_key(s);
+    Region* mine = find(s, thread_key(s));
     for (size_t i = 0; i < regions.size(); ++i) {
       Region& r = regions[i];
-      if (r.stream != s || r.thread != tk) continue;
+      if (&r != mine) continue;
       if (r.marked && !r.dirty) (void)hipEventSynchronize(r.done);
       if (r.ptr) (void)hipFree(r.ptr);                                                // (hipFree waits for the device: a dirty region's launches are through)
       (void)hipEventDestroy(r.done);

@@ -13,7 +13,8 @@
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorInvalidHandle = 400, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 enum { hipEventDisableTiming = 2 };
-struct fake_stream { std::atomic<long> enqueued{0}, completed{0}; void enqueue() { ++enqueued; } void drain() { completed = enqueued.load(); } };   /* atomic: the threaded cases drain their own streams while the map drains all */
+#define YF_FAKE_HIP_STREAM_ID 1      /* yf_stream_scratch.h calls hipStreamGetId below directly instead of resolving it with dlsym */
+struct fake_stream { unsigned long long id = 0; std::atomic<long> enqueued{0}, completed{0}; void enqueue() { ++enqueued; } void drain() { completed = enqueued.load(); } };   /* atomic: the threaded cases drain their own streams while the map drains all */
 struct fake_event { fake_stream* on = nullptr; long at = 0; };
 typedef fake_stream* hipStream_t;
 typedef fake_event* hipEvent_t;
@@ -24,12 +25,20 @@ inline long& mallocs() { static long n = 0; return n; }
 inline long& frees() { static long n = 0; return n; }
 inline long& device_syncs() { static long n = 0; return n; }
 inline long& fail_mallocs() { static long n = 0; return n; }
-inline hipStream_t create() { fake_stream* s = new fake_stream(); live().insert(s); all().push_back(s); return s; }
+inline bool& has_stream_id() { static bool b = true; return b; }      /* false: a runtime without hipStreamGetId (PyTorch 2.10's bundled libamdhip64) */
+inline unsigned long long& next_id() { static unsigned long long n = 100; return n; }
+inline hipStream_t create() { fake_stream* s = new fake_stream(); s->id = next_id()++; live().insert(s); all().push_back(s); return s; }
+/* "the runtime hands the handle value of a destroyed stream to a NEW stream": same address, new id, nothing enqueued on the new one */
+inline void reincarnate(hipStream_t s) { s->id = next_id()++; live().insert(s); }
 inline void destroy(hipStream_t s) { live().erase(s); }            /* the object stays allocated: a stale handle value is still a valid address */
 inline void free_all() { for (fake_stream* s : all()) delete s; all().clear(); live().clear(); }
 inline void drain_all() { for (fake_stream* s : all()) s->drain(); }
 }
 #define hipStreamPerThread ((hipStream_t)2)
+inline hipError_t hipStreamGetId(hipStream_t s, unsigned long long* id) {
+  if (s != hipStreamPerThread && !fake_hip::live().count(s)) { std::fprintf(stderr, "fake HIP: hipStreamGetId on a destroyed stream\n"); std::abort(); }
+  *id = s == hipStreamPerThread ? 1 : s->id; return hipSuccess;
+}
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = new fake_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {

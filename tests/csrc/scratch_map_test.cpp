@@ -77,17 +77,43 @@ int main() {
     CHECK(good_launch(one, e) == hipSuccess && one.count() == 1 && fake_hip::device_syncs() == syncs + 1);
     one.release();
   }
-  {   // 4. the same handle VALUE comes back for a new stream (the runtime reuses addresses): it finds the old region -- safe, because a stream may only be
-      //    dropped once its launches have completed
-    yf_stream_scratch m;
-    hipStream_t a = fake_hip::create();
-    char *p1 = nullptr, *p2 = nullptr;
-    CHECK(good_launch(m, a, 1024, &p1) == hipSuccess);
-    a->drain();
-    fake_hip::destroy(a);
-    fake_hip::live().insert(a);                                                // "a new stream at the same address"
-    CHECK(good_launch(m, a, 1024, &p2) == hipSuccess && p1 == p2 && m.count() == 1);
-    m.release();
+  {   // 4. the same handle VALUE comes back for a new stream (this runtime reuses the address at once: tools/probe/stream_id_probe.py).
+      //    (a) a runtime WITHOUT hipStreamGetId: the key is the handle value, the new stream finds the old region -- safe only because a stream may be
+      //        dropped only once its launches have completed;
+    fake_hip::has_stream_id() = false;
+    {
+      yf_stream_scratch m;
+      hipStream_t a = fake_hip::create();
+      char *p1 = nullptr, *p2 = nullptr;
+      CHECK(good_launch(m, a, 1024, &p1) == hipSuccess);
+      a->drain();
+      fake_hip::destroy(a);
+      fake_hip::reincarnate(a);                                                // "a new stream at the same address"
+      CHECK(good_launch(m, a, 1024, &p2) == hipSuccess && p1 == p2 && m.count() == 1);
+      m.release();
+    }
+    fake_hip::has_stream_id() = true;
+    {   // (b) (round 6) WITH hipStreamGetId the key carries the stream's id: the successor is a NEW stream.  The predecessor was destroyed with its launch STILL IN
+        //     FLIGHT (nothing drained, no release: the host's mistake) -- rounds 3-5 would have handed its region to the successor, both launches on the same bytes
+      yf_stream_scratch m;
+      hipStream_t b = fake_hip::create(), a = fake_hip::create();
+      char *pb = nullptr, *p1 = nullptr, *p2 = nullptr;
+      CHECK(good_launch(m, b, 1024, &pb) == hipSuccess);                       // company, so that a's launch is named by an event
+      CHECK(good_launch(m, a, 1024, &p1) == hipSuccess);                       // in flight ...
+      fake_hip::destroy(a);                                                    // ... and its stream destroyed
+      fake_hip::reincarnate(a);
+      CHECK(good_launch(m, a, 1024, &p2) == hipSuccess);
+      CHECK(p2 != p1 && m.count() == 3);                                       // a region of its own: the bytes of the launch in flight are not shared
+      // once the predecessor's launch has completed, its region is idle and changes hands like any other
+      fake_hip::drain_all();
+      hipStream_t c = fake_hip::create();
+      char* pc = nullptr;
+      CHECK(good_launch(m, c, 1024, &pc) == hipSuccess && m.count() == 3 && (pc == p1 || pc == pb || pc == p2));
+      // and release_stream() of the successor frees ITS region, not the predecessor's
+      const size_t before = m.count();
+      CHECK(m.release_stream(a) == hipSuccess && m.count() == before - 1);
+      m.release();
+    }
   }
   {   // 5. 64 short-lived streams, three launches each, dropped after their work completed, never released: bounded footprint
     yf_stream_scratch m;

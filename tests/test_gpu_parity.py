@@ -1340,6 +1340,24 @@ def test_the_n_rank_flow_from_a_pure_c_host():
     assert line["gathered_counts_in_rank_order_on_every_rank"] is None and line["value"] > 0
 
 
+def test_a_stream_destroyed_with_a_launch_in_flight_does_not_share_its_scratch():
+    """"the one place where a host mistake corrupts results silently".  The runtime hands a destroyed stream's handle VALUE to the next
+    stream at once; rounds 3-5 keyed the launch scratch by that value.  tools/c_host/yf_stream_reuse.c (a C host on /opt/rocm's runtime, which exports
+    hipStreamGetId; PyTorch 2.10's bundled runtime does not) launches on a stream, destroys it with the launch in flight, launches on its successor -- twenty times:
+    the successor gets a region of its OWN (two alive at once whenever the handle value came back) and every launch equals its synchronous reference run."""
+    import json
+    exe = os.path.join(ROOT, "stm32h7-yolo_amd", "lib", "yf_c_stream_reuse")
+    if not os.path.exists(exe):
+        pytest.skip("stm32h7-yolo_amd/lib/yf_c_stream_reuse was not built (make -C stm32h7-yolo_amd/csrc chost)")
+    r = subprocess.run([exe, ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    print(line)
+    assert line["launches_that_differ_from_their_reference"] == 0
+    if line["runtime_has_hipStreamGetId"] and line["successor_got_the_same_handle_value"]:
+        assert line["regions_alive_at_once_max"] >= 2
+
+
 def test_compact_wire_records_on_the_gpu(yf, network, oracle, torch_cuda):
     """yf_network_pack_detections_device / _unpack_ (the 12-byte wire form of the multi-GPU exchange, one launch each): the packed bytes equal the tensor-op
     statement of the format (sharding.pack_compact) also where the record buffer holds stale bytes beyond a frame's count; the sparse heads equal
