@@ -50,6 +50,13 @@
 #define YF_DUMP_PROD_ORDER 1
 #include "yf_kernels.hip.h"
 #undef YF_NS
+#undef YF_H0
+#undef YF_STAGE_FN
+#define YF_NS yfpdu                 /* ... and of the kernel set with the sign-free dense epilogue */
+#define YF_RQ3_DENSE 1
+#include "yf_kernels.hip.h"
+#undef YF_NS
+#undef YF_RQ3_DENSE
 #undef YF_DUMP_PROD_ORDER
 #undef YF_H0
 #endif
@@ -159,6 +166,8 @@ const Variant k_variants[] = {
   // the dump build in the production stage order (same NetParams layout; selected by YF_LAB_DUMP_PROD_ORDER=1 as the engine's dump variant)
   { 2, 8, true, false, (fused_fn)yfpd::yoloface56_fused<2, 8, true>, yfpd::lds_bytes<2, 8, true>(), yfpd::scratch_bytes_per_frame_slot<true>(),
     "yoloface56_fused<F=2,NW=8,dump in production order>", true },
+  { 2, 8, true, false, (fused_fn)yfpdu::yoloface56_fused<2, 8, true>, yfpdu::lds_bytes<2, 8, true>(), yfpdu::scratch_bytes_per_frame_slot<true>(),
+    "yoloface56_fused<F=2,NW=8,dump in production order,sign-free dense epilogue>", true, true },
 #endif
 };
 
@@ -264,7 +273,7 @@ static const Variant* find_variant(int f, int nw, bool dump, bool cam = false, b
 // dump build that keeps the production stage order instead (shape <2,8> only)
 static const Variant* dump_variant_for(const yf_engine* e, int f, int nw) {
 #ifdef YF_LAB
-  if (e->dump_prod_order && !e->signless) { const Variant* v = find_variant(f, nw, true, false, true); if (v) return v; }
+  if (e->dump_prod_order) { const Variant* v = find_variant(f, nw, true, false, true, e->signless); if (v) return v; }
 #endif
   return find_variant(f, nw, true, false, false, e->signless);
 }

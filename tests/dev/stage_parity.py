@@ -5,7 +5,8 @@ Uses the library's dump entry point (yf_network_run_device_dump) and compares ev
 matching tflite op output of the oracle.  Prints the first failing stage.
 
     stage_parity.py [n]                       the product library's debug build (staged order: what the per-node observer runs)
-    stage_parity.py --prod-order n [n ...]    the laboratory library's dump build that KEEPS THE PRODUCTION STAGE ORDER (yf_fused56.hip.h, YF_PDUMP:
+    stage_parity.py --prod-order [--ties-up] n [n ...]    (--ties-up: the second kernel set, against the oracle's variant of that rounding)
+                                              the laboratory library's dump build that KEEPS THE PRODUCTION STAGE ORDER (yf_fused56.hip.h, YF_PDUMP:
                                               pools beside the branch on 3 + 5 waves, conv2d_10's output on concat_22's bytes, the 7x7 tail once per pair of
                                               groups on four frames through the HBM park), on a grid of ONE workgroup so that consecutive groups pair up:
                                               n = 5 -> a pair and an unpaired last group holding one frame; n = 8 -> two pairs; then once more on the full
@@ -16,6 +17,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PROD_ORDER = "--prod-order" in sys.argv
+VARIANT = 0                                     # oracle variant the dumps are compared with (--ties-up: rounding "ties upward on the dense convs" = the second kernel set)
+if "--ties-up" in sys.argv:
+    sys.argv.remove("--ties-up")
+    os.environ["YF_REQUANT_ROUNDING"] = "ties_up"
+    VARIANT = 1
 if PROD_ORDER:                                  # before the library is loaded: the laboratory build and its switches (yf_engine.hip, YF_LAB)
     sys.argv.remove("--prod-order")
     os.environ["YF_LIB_PATH"] = os.path.join(ROOT, "stm32h7-yolo_amd", "lib_lab", "libyf_network.so")
@@ -54,7 +60,7 @@ def prod_order(sizes_n):
         net = yf.Network().init()
         for n in sizes_n:
             x = np.random.default_rng(100 + n).integers(-128, 128, (n, 56, 56, 3), dtype=np.int8)
-            head_ref, dump_ref = orc.run(x, dump=True, threads=8)
+            head_ref, dump_ref = orc.run(x, dump=True, threads=8, variant=VARIANT)
             d_in = torch.from_numpy(x).cuda()
             d_out = torch.full((n + 1, 7, 7, 18), 77, dtype=torch.int8, device="cuda")
             d_dump = torch.full((n + 1, net.dump_bytes()), 77, dtype=torch.int8, device="cuda")
@@ -67,7 +73,7 @@ def prod_order(sizes_n):
                     bad_stages.append(name)
                 off += sizes[op]
             good = not bad_stages and np.array_equal(head[:n], head_ref) and (head[n] == 77).all() and (dump[n] == 77).all()
-            print(f"production order, {label}, n = {n}: {'25 stage tensors + head ok' if good else 'MISMATCH ' + str(bad_stages)}")
+            print(f"production order, {net.kernel_name}, {label}, n = {n}: {'25 stage tensors + head ok' if good else 'MISMATCH ' + str(bad_stages)}")
             ok &= bool(good)
         net.destroy()
     print("stage parity (production order) ok" if ok else "stage parity (production order) FAILED")

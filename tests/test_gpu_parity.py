@@ -633,9 +633,11 @@ def test_every_fused_stage_in_the_production_stage_order(torch_cuda):
     workgroup the groups of 5, 3 and 8 frames pair up (5: a pair and an unpaired last group that holds one frame), then the full grid; the 25 fused-stage
     tensors of every frame equal the oracle's ops, and nothing is written behind the batch.  Fresh process (the lab library instead of the product)."""
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "stage_parity.py"), "--prod-order", "5", "3", "8", "130"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "stage parity (production order) ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("25 stage tensors + head ok") == 8
+    for extra in ([], ["--ties-up"]):            # the reference rounding's kernel, and the second kernel set (sign-free dense epilogue) against the oracle's variant (U)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "stage_parity.py"), "--prod-order"] + extra + ["5", "3", "8", "130"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "stage parity (production order) ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        assert r.stdout.count("25 stage tensors + head ok") == 8
+        assert ("sign-free dense epilogue" in r.stdout) == bool(extra)
 
 
 @pytest.mark.skipif(not os.path.exists(LAB_LIB), reason="the lab library is not built (make -C stm32h7-yolo_amd/csrc lab)")
