@@ -204,6 +204,29 @@ def test_load_without_a_build_tool_checks_the_build_id():
     assert out == "REFUSED 0 True", log                     # ... and refuses a library built from other sources
 
 
+def test_requant_rounding_is_a_property_of_the_created_network(yf):
+    """yf_network_set_requant_rounding without a GPU in sight (host logic only): the choice is stored on a created network (and used by the next
+    ai_network_init), an unknown value latches AI_ERROR_INVALID_PARAM and changes nothing, ai_network_create resets it to $YF_REQUANT_ROUNDING (unset:
+    the reference rounding), YF_ROUND_GENERIC_KERNELS rides along, a foreign handle is refused, and the scratch statistics of a network that never
+    launched are zero."""
+    b = __import__("importlib").import_module("stm32h7-yolo_amd.binding")
+    lib = yf.load()
+    assert lib.yf_network_get_requant_rounding(ctypes.c_void_p(0x1234)) == -1 and lib.yf_network_set_requant_rounding(ctypes.c_void_p(0x1234), 1) == -1
+    net = yf.Network()
+    assert net.requant_rounding == b.YF_ROUND_TFLITE_REF
+    for r in (b.YF_ROUND_TIES_UP, b.YF_ROUND_TIES_UP_ALL, b.YF_ROUND_SINGLE, b.YF_ROUND_TIES_UP | b.YF_ROUND_GENERIC_KERNELS, b.YF_ROUND_TFLITE_REF):
+        assert net.set_requant_rounding(r).requant_rounding == r
+    net.set_requant_rounding(b.YF_ROUND_TIES_UP)
+    for bad in (4, -1, 0x104, 0x200):
+        with pytest.raises(yf.NetworkError) as ei:
+            net.set_requant_rounding(bad)
+        assert ei.value.type == 0x14 and net.requant_rounding == b.YF_ROUND_TIES_UP
+    assert net.scratch_stats() == dict(events_recorded=0, events_skipped=0, event_waits=0, device_syncs=0, acquire_waits=0, regions=0)
+    net2 = yf.Network()                                  # ai_network_create again: back to the environment's choice
+    assert net2.requant_rounding == b.YF_ROUND_TFLITE_REF
+    net2.destroy()
+
+
 @pytest.mark.skipif(not _no_gpu(), reason="checks the behaviour WITHOUT a GPU")
 def test_c_rank_host_fails_cleanly_without_a_gpu():
     """tools/c_host/yf_ranks.c on a box without a GPU: every rank fails at its first HIP call, the parent neither hangs on its pipes nor dies of SIGPIPE

@@ -256,11 +256,24 @@ int main(int argc, char** argv) {
   for (int r = 0; r < world && !bad; ++r) if (write_all(down[r][1], "g", 1) != 0) bad = 1;     /* ... and they enter the timed region together */
   if (bad) for (int r = 0; r < world; ++r) close(down[r][1]);      /* a rank died: the others' reads end instead of waiting for ever */
   for (int r = 0; r < world; ++r) if (!reported[r]) { EXPECT(r, 'R'); if (!reported[r]) rep[r].status = 2; }
-  int worst = 0;
-  for (int r = 0; r < world; ++r) {
-    int st = 0;
-    if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st)) { worst = 2; continue; }
-    if (WEXITSTATUS(st) > worst) worst = WEXITSTATUS(st);
+  /* Collect the ranks.  After a failure the survivors may sit in a collective whose peer is gone, for ever: they get 20 s to leave by themselves (their pipe reads
+   * have ended), then SIGKILL -- the parent must not hang on the first 8-GPU run because one rank died. */
+  int worst = 0, left = world, done[MAX_RANKS] = {0};
+  for (double t_kill = now_s() + 20.0; left > 0;) {
+    for (int r = 0; r < world; ++r) {
+      if (done[r]) continue;
+      int st = 0;
+      const pid_t w = waitpid(pid[r], &st, bad ? WNOHANG : 0);
+      if (w == 0) continue;
+      done[r] = 1; --left;
+      if (w < 0 || !WIFEXITED(st)) { worst = 2; bad = 1; continue; }
+      if (WEXITSTATUS(st) > worst) worst = WEXITSTATUS(st);
+      if (WEXITSTATUS(st) == 2) bad = 1;
+    }
+    if (left > 0 && bad) {
+      if (now_s() > t_kill) { for (int r = 0; r < world; ++r) if (!done[r]) kill(pid[r], SIGKILL); t_kill = now_s() + 1e9; }
+      else { struct timespec nap = {0, 50 * 1000 * 1000}; nanosleep(&nap, NULL); }
+    }
   }
   double elapsed = 0, kernel_ms = 0;
   int order_ok = 1, golden_ok = 1, own_ok = 1;
