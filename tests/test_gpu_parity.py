@@ -291,6 +291,7 @@ def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, orac
         torch.cuda.synchronize()
         got = d_out.cpu().numpy()
         assert np.array_equal(got, want)
+        assert np.array_equal(got[:6], np.load(os.path.join(ROOT, "tests", "golden", "golden_heads_variants.npz"))[{1: "U", 2: "U_all", 4: "S"}[variant]])     # the committed fixture
         counts, buf = d_c.cpu().numpy(), d_d.cpu().numpy().view(yf.DET_DTYPE).reshape(4096, cap)
         for f in list(range(40)) + list(np.nonzero(counts)[0][:200]):
             py = oracle.decode_py(want[f], f)
@@ -318,6 +319,30 @@ def test_selectable_requant_rounding_equals_the_oracle_variant(yf, network, orac
         network.run_device_hw(160, 160, d_b.data_ptr(), d_o.data_ptr(), 3)
         torch.cuda.synchronize()
         assert np.array_equal(d_o.cpu().numpy(), oracle.run(block, threads=3, variant=variant))
+        # camera frames -> heads + firmware-mode records in one launch (the camera-input build of the kernel set in force); and ragged batches on both shapes
+        raw = np.random.default_rng(34).integers(0, 256, (131, 112 * 112 * 2), dtype=np.uint8)
+        cam_ref = oracle.run(np.stack([oracle.prepare_rgb565(r) for r in raw]), threads=8, variant=variant)
+        d_raw = torch.from_numpy(raw).cuda()
+        d_ch = torch.zeros((131, 7, 7, 18), dtype=torch.int8, device="cuda")
+        d_cd = torch.zeros((131, cap, 28), dtype=torch.uint8, device="cuda")
+        d_cc = torch.zeros((131,), dtype=torch.int32, device="cuda")
+        network.run_camera_device(d_raw.data_ptr(), d_ch.data_ptr(), 131, d_cd.data_ptr(), d_cc.data_ptr(), cap, yf.YF_DECODE_FW)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_ch.cpu().numpy(), cam_ref)
+        cc, cbuf = d_cc.cpu().numpy(), d_cd.cpu().numpy().view(yf.DET_DTYPE).reshape(131, cap)
+        for f in range(131):
+            fw = oracle.decode_c(cam_ref[f], f)
+            assert cc[f] == len(fw) and [(int(d["anchor"]), int(d["row"]), int(d["col"]), int(d["x1"]), int(d["y1"]), int(d["x2"]), int(d["y2"])) for d in cbuf[f, :min(cap, cc[f])]] == \
+                   [(d[1], d[2], d[3], d[6], d[7], d[8], d[9]) for d in fw][:cap]
+        for shape in ((2, 8), (1, 8)):
+            network.configure(*shape)
+            for nn in (1, 7, 513, 1027):
+                d_r = torch.full((nn + 1, 7, 7, 18), 77, dtype=torch.int8, device="cuda")
+                network.run_device(d_in.data_ptr(), d_r.data_ptr(), nn)
+                torch.cuda.synchronize()
+                r_got = d_r.cpu().numpy()
+                assert np.array_equal(r_got[:nn], want[:nn]) and (r_got[nn] == 77).all(), (shape, nn)
+        network.configure(-1, -1)
         with pytest.raises(Exception) as ei:
             network.set_requant_rounding(7)
         assert ei.value.type == 0x14 and network.requant_rounding == rounding               # AI_ERROR_INVALID_PARAM latched, nothing changed

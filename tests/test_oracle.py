@@ -273,6 +273,26 @@ def test_rounding_variant_exposure(oracle, golden):
             assert got[v] == want[v], (name, v, got[v])
 
 
+def test_golden_vectors_of_the_rounding_variants(oracle, golden):
+    """tests/golden/golden_heads_variants.npz + golden_variants_meta.json (make_golden_variants.py): every variant's heads on the golden frames bit for bit, the
+    sha256 of every head of the 27 real frames, the Python-decode boxes of the golden frames.  Interpreter-unverified like every golden here; what they buy: a
+    refactor of a variant is pinned, and an interpreter run elsewhere has something to be compared with."""
+    import json
+    from oracle.oracle import VARIANTS
+    want = np.load(os.path.join(GOLDEN, "golden_heads_variants.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "golden_variants_meta.json")))["variants"]
+    real = np.fromfile(os.path.join(GOLDEN, "real_frames_56.bin"), np.int8).reshape(-1, 56, 56, 3)
+    for name, v in VARIANTS.items():
+        if name == "R":
+            continue
+        key = name.replace("-", "_")
+        h = oracle.run(golden["inputs"], variant=v)
+        assert np.array_equal(h, want[key]), name
+        assert [hashlib.sha256(a.tobytes()).hexdigest() for a in oracle.run(real, variant=v)] == meta[key]["real_frames_head_sha256"], name
+        boxes = [[[int(d[1]), int(d[2]), int(d[3]), int(d[6]), int(d[7]), int(d[8]), int(d[9])] for d in oracle.decode_py(h[f], f)] for f in range(h.shape[0])]
+        assert boxes == meta[key]["golden_detections_py"], name
+
+
 def test_decode_threshold_identity(oracle):
     """conf > 0.7 (py) and conf >= 0.7 (firmware) are both equivalent to q_conf >= -9."""
     sig = oracle.sig
