@@ -408,6 +408,7 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
     d_ins = [torch.from_numpy(x).cuda() for x in xs]
     d_outs = [[torch.zeros((sizes[k], 7, 7, 18), dtype=torch.int8, device="cuda") for _ in range(12)] for k in range(2)]
     torch.cuda.synchronize()
+    st0 = network.scratch_stats()
     for it in range(12):
         for k in range(2):
             network.run_device(d_ins[k].data_ptr(), d_outs[k][it].data_ptr(), sizes[k], streams[k].cuda_stream)
@@ -415,6 +416,18 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
     for k in range(2):
         for it in range(12):
             assert np.array_equal(d_outs[k][it].cpu().numpy(), refs[k]), (k, it)
+    # what the scratch map did, as a host reads it (yf_network_scratch_stats, round 6): 24 launches were marked -- in company they record their events (the very first
+    # may still have been alone) --, two regions at least exist, and nobody waited for the device
+    st1 = network.scratch_stats()
+    assert (st1["events_recorded"] - st0["events_recorded"]) + (st1["events_skipped"] - st0["events_skipped"]) == 24
+    assert st1["events_recorded"] - st0["events_recorded"] >= 22 and st1["regions"] >= 2 and st1["device_syncs"] == st0["device_syncs"]
+    alone = torch.cuda.Stream()                       # ... and a stream that has the library to itself again skips its events
+    torch.cuda.synchronize()
+    for it in range(6):
+        network.run_device(d_ins[0].data_ptr(), d_outs[0][it].data_ptr(), sizes[0], alone.cuda_stream)
+    torch.cuda.synchronize()
+    st2 = network.scratch_stats()
+    assert st2["events_skipped"] - st1["events_skipped"] >= 5, (st1, st2)
 
 
 def test_short_lived_streams_keep_the_scratch_bounded(network, oracle, torch_cuda):
