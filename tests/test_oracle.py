@@ -293,6 +293,24 @@ def test_golden_vectors_of_the_rounding_variants(oracle, golden):
         assert boxes == meta[key]["golden_detections_py"], name
 
 
+def test_which_tflite_names_the_variant(tmp_path):
+    """tools/which_tflite.py (what an integrator with TensorFlow runs to settle the rounding question): the heads of each variant are recognised, foreign heads are not."""
+    import subprocess
+    import sys
+    v = np.load(os.path.join(GOLDEN, "golden_heads_variants.npz"))
+    tool = os.path.join(ROOT, "tools", "which_tflite.py")
+    for name, arr in (("R", np.fromfile(os.path.join(GOLDEN, "golden_heads.bin"), np.int8)), ("U", v["U"]), ("S", v["S"])):
+        p = tmp_path / f"{name}.bin"
+        arr.tofile(p)
+        r = subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+        assert r.returncode == 0 and f"computes variant {name}:" in r.stdout, r.stdout
+    bad = v["U"].copy()
+    bad[0, 0, 0, 0] ^= 1
+    bad.tofile(tmp_path / "bad.bin")
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "bad.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "NO variant matches" in r.stdout
+
+
 def test_decode_threshold_identity(oracle):
     """conf > 0.7 (py) and conf >= 0.7 (firmware) are both equivalent to q_conf >= -9."""
     sig = oracle.sig
