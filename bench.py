@@ -41,6 +41,7 @@ CAMERA_BYTES_PER_FRAME = 112 * 112 * 2 + 7 * 7 * 18          # RGB565 camera fra
 PROFILE_CAMERA = "profiles/r06_camera/summary.json"
 PROFILE_160 = "profiles/r06_160/summary.json"                # rocprofv3 summaries of `bench.py --only-secondary ...` (tools/profile_secondary.sh),
 PROFILE_FP16 = "profiles/r06_fp16/summary.json"              # stamped with the build id they were taken on
+PROFILE_TIES_UP = "profiles/r06_u_pmc_current.json"          # tools/profile_pmc.sh r06u --requant-rounding ties_up: the second kernel set's counters
 
 
 def kernel_source_hash():
@@ -291,11 +292,14 @@ def secondary_ties_up(net, dev, stream, settle_ms=60.0, iters=20):
     finally:
         net.set_requant_rounding(yf.YF_ROUND_TFLITE_REF)
     gbs = n * ALGO_BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+    prof, why = stamped_profile(PROFILE_TIES_UP, lambda d: d.get("source_hash"))
     return {"workload": "BASELINE configs[1]'s batch (4096 int8 56x56x3 frames, 8 batches rotating in HBM) with requantisation rounding 'ties upward on the dense convs' "
                         "(yf_network_set_requant_rounding(YF_ROUND_TIES_UP)); one launch stream", "ms_per_step": round(ms, 4), "timed_steps": iters,
             "images_per_s": round(n / ms * 1e3, 1), "algorithmic_bytes_per_step": n * ALGO_BYTES_PER_FRAME,
-            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                         "traffic_missing": "no counter pass was taken on this kernel set"},
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                         **({"traffic": prof["hbm_bytes_per_launch"], "traffic_source": f"{PROFILE_TIES_UP} (FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                             "kernel_us_in_trace": round(prof["kernel_trace_avg_ns"] / 1e3, 2), "valu_instructions_per_launch": prof.get("SQ_INSTS_VALU")}
+                            if prof else {"traffic": None, "traffic_missing": why})},
             "kernel": kernel, "kernel_source_hash": kernel_source_hash(),
             "parity": "first 256 heads bit-exact vs the oracle's variant 'ties upward on the dense convs'" if ok else "MISMATCH vs the oracle's variant"}
 
