@@ -226,7 +226,7 @@ enum { YF_DECODE_PY = 0,      /* yoloface/tflite/tflite_prediction.py:42-63: anc
  * The rounding lives in the per-channel constants {C64, ZR}, the LeakyReLU / QUANTIZE byte tables and the add tables that ai_network_init builds
  * (csrc/yf_host_prep.c); the four-instruction requantisation of the reference rounding's kernels serves every one of them.  The three roundings whose
  * dense convolutions have NO sign term (ties upward, single rounding) by default run a second set of the same kernels whose dense convolutions
- * requantise in THREE instructions (no carry, ZR folded into C64: 7 % less kernel time, profiles/r06_ties_up_epilogue_ab.txt); or-ing
+ * requantise in THREE instructions (no carry, ZR folded into C64: 5.5 % less kernel time, profiles/r06_ties_up_epilogue_ab.txt); or-ing
  * YF_ROUND_GENERIC_KERNELS into the rounding keeps them on the reference rounding's kernels (same results; for A/B).  Call after ai_network_create, before or after
  * ai_network_init (a ready network waits for its launches, rebuilds its tables from the weights it was initialised with -- which the caller
  * still owns, as on the MCU -- and uploads them); ai_network_create resets the choice to $YF_REQUANT_ROUNDING ("ref", "ties_up",
