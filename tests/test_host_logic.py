@@ -485,3 +485,32 @@ def test_fp16_prefetch_wait_count_matches_the_isa(tmp_path):
         assert len(loads) >= n and not stores, (n, loads, stores)
         checked += 1
     assert checked >= 1
+
+
+def test_profile_summary_separates_overlapped_launches_from_back_to_back_ones(tmp_path):
+    """tools/summarize_pmc.py (what profiles/*_pmc_summary.json come from): a launch counts as OVERLAPPED only against a neighbour on ANOTHER stream (or by more than a
+    microsecond) -- back-to-back launches of one stream show the next start a few hundred nanoseconds before the previous end stamp, and round 6's first summary filed 728
+    of them under "overlapped", which moved the "kernel alone" average.  Synthetic trace: ten launches back to back on stream 4 (each starting 150 ns early), then six
+    alternating between streams 5 and 6 with real overlap, plus a small-grid launch that must not count."""
+    import json
+    import subprocess
+    import sys
+    d = tmp_path / "prof"
+    (d / "trace").mkdir(parents=True)
+    rows, t = [], 1_000_000
+    name = "void yf::yoloface56_fused<2, 8, false, false>(yf::NetParams)"
+    for k in range(10):                                   # one stream, back to back: start 150 ns before the previous end
+        rows.append((t, t + 140_000, 4, 262144)); t += 140_000 - 150
+    t += 1_000_000
+    for k in range(6):                                    # two streams: each launch starts 130 us before the previous one ends
+        rows.append((t, t + 260_000, 5 + k % 2, 262144)); t += 130_000
+    rows.append((t + 2_000_000, t + 2_024_000, 4, 512))   # a one-frame launch of the same kernel: not a full batch
+    with open(d / "trace" / "t_kernel_trace.csv", "w") as f:
+        f.write("Kind,Agent_Id,Queue_Id,Stream_Id,Kernel_Name,Start_Timestamp,End_Timestamp,Grid_Size_X\n")
+        for b, e, s, g in rows:
+            f.write(f'KERNEL_DISPATCH,1,1,{s},"{name}",{b},{e},{g}\n')
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), str(d)], stdout=subprocess.DEVNULL)
+    res = json.load(open(d / "summary.json"))
+    assert res["trace"]["calls"] == 10 and res["trace"]["avg_ns"] == 140_000
+    assert res["trace_overlapped"]["calls"] == 6 and res["trace_overlapped"]["runs"] == 1 and res["trace_overlapped"]["avg_duration_ns"] == 260_000
+    assert abs(res["trace_overlapped"]["wall_ns_per_launch"] - (5 * 130_000 + 260_000) / 6) < 1
